@@ -1,0 +1,119 @@
+"""ctypes binding of libcapnet_hip.so (C ABI declared in include/capnet.h).
+
+The library is the product: there is NO CPU fallback. If the shared object is missing, or a
+call returns a non-zero status, this module raises -- it never routes around the HIP path.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcapnet_hip.so")
+
+_f = C.POINTER(C.c_float)
+_vp = C.c_void_p
+_i = C.c_int
+_l = C.c_long
+_sz = C.c_size_t
+_ip = C.POINTER(C.c_int)
+
+# name -> (restype, argtypes); every symbol of include/capnet.h
+SIGNATURES = {
+    "capnet_last_error": (C.c_char_p, []),
+    "capnet_abi_version": (_i, []),
+    "capnet_sgemm": (_i, [_i, _i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, _vp, _i, _i, _l, _l, _l,
+                          _l, _i, _vp]),
+    "capnet_colsum": (_i, [_vp, _l, _i, _i, _vp, _i, _vp]),
+    "capnet_argmax_rows": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "capnet_trunk_create": (_i, [_i, _i, _i, C.POINTER(_vp)]),
+    "capnet_trunk_destroy": (None, [_vp]),
+    "capnet_trunk_workspace_bytes": (_sz, [_vp]),
+    "capnet_trunk_num_convs": (_i, [_vp]),
+    "capnet_trunk_final_side": (_i, [_vp]),
+    "capnet_trunk_flops": (C.c_double, [_vp]),
+    "capnet_trunk_conv_shape": (_i, [_vp, _i, _ip, _ip, _ip, _ip, _ip]),
+    "capnet_trunk_forward": (_i, [_vp, _vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp),
+                                  C.POINTER(_vp), C.POINTER(_vp), _i, C.c_float, C.c_float, _vp,
+                                  _vp, _vp, _vp]),
+    "capnet_pack_conv_weight": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "capnet_adaptive_pool_replicate": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "capnet_conv2d_fwd": (_i, [_vp, _l, _l, _l, _l, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _i,
+                               _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "capnet_conv_tiles_m": (_i, [_i, _i, _i]),
+    "capnet_bn_finalize": (_i, [_vp, _vp, _i, _i, _l, _vp, _vp, _vp, _vp, C.c_float, C.c_float,
+                                _vp, _vp, _vp]),
+    "capnet_bn_add_relu": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _vp]),
+    "capnet_bn_relu_maxpool": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "capnet_global_avgpool": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "capnet_bn1d_fwd": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _i, C.c_float, C.c_float, _vp, _vp,
+                             _vp, _vp]),
+    "capnet_bn1d_bwd": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "capnet_seq_saved_floats": (_sz, [_ip]),
+    "capnet_seq_saved_ints": (_sz, [_ip]),
+    "capnet_seq_fwd_scratch_floats": (_sz, [_ip]),
+    "capnet_seq_bwd_scratch_floats": (_sz, [_ip]),
+    "capnet_seq_forward": (_i, [_ip, _ip, C.POINTER(C.c_ubyte), _vp, _vp, _vp, C.POINTER(_vp),
+                                _vp, _vp, C.c_float, C.c_ulonglong, _i, _vp, _vp, _vp, _vp, _vp,
+                                _vp]),
+    "capnet_seq_backward": (_i, [_ip, _ip, _vp, _vp, _vp, _vp, _vp, C.POINTER(_vp), C.c_float,
+                                 C.c_ulonglong, _i, _vp]),
+    "capnet_xent_fwd": (_i, [_vp, _l, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "capnet_xent_bwd": (_i, [_vp, _l, _i, _i, _vp, _vp, _vp, _vp, _l, _vp]),
+    "capnet_clamp_adam": (_i, [_i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp),
+                               C.POINTER(_vp), C.POINTER(_l), _ip, C.c_float, C.c_float,
+                               C.c_float, C.c_float, C.c_float, _i, _vp]),
+}
+
+
+class CapnetError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load libcapnet_hip.so once; fail loudly if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise CapnetError(
+                "libcapnet_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; "
+                "g.build()'` or `make -C image-caption-emotion-indonesia_amd/csrc`. There is no "
+                "CPU fallback." % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)  # AttributeError if a declared symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(status, what=""):
+    if status != 0:
+        msg = lib().capnet_last_error()
+        raise CapnetError("%s failed (status %d): %s" %
+                          (what or "capnet call", status, msg.decode() if msg else "?"))
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def ptr_array(tensors):
+    arr = (C.c_void_p * len(tensors))()
+    for k, t in enumerate(tensors):
+        arr[k] = None if t is None else t.data_ptr()
+    return arr
+
+
+def int_array(vals):
+    return (C.c_int * len(vals))(*[int(v) for v in vals])
+
+
+def current_stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,276 @@
+// BatchNorm2d bookkeeping and the memory-bound elementwise/pooling kernels of the trunk.
+// All activations are NHWC fp32; every kernel here is HBM-bound and moves 16 B per lane.
+// Semantics follow torch.nn.BatchNorm2d as used by torchvision's resnet152 under
+// encoder.train() (stylenet/train_multitask.py:367, stylenet/model.py:23-24): batch mean and
+// BIASED variance normalise, running_var is updated with the UNBIASED variance, momentum 0.1.
+#include "common.h"
+#include "kernels.h"
+
+namespace capnet {
+
+// ---- batch statistics -> (scale, shift), running-stat update --------------------------
+// part_sum/part_sq: [tiles][C] per-workgroup partials from the conv epilogue. Reduced in
+// double so that E[x^2]-E[x]^2 does not cancel in fp32.
+constexpr int kFinCh = 32, kFinRows = 32;
+
+__global__ __launch_bounds__(kFinCh* kFinRows) void bn_finalize_kernel(
+    const float* __restrict__ part_sum, const float* __restrict__ part_sq, int tiles, int C,
+    double inv_count, double unbias, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* __restrict__ running_mean,
+    float* __restrict__ running_var, float momentum, float eps, float* __restrict__ scale,
+    float* __restrict__ shift) {
+  __shared__ double s_sum[kFinRows][kFinCh + 1];
+  __shared__ double s_sq[kFinRows][kFinCh + 1];
+  const int cx = threadIdx.x % kFinCh, ry = threadIdx.x / kFinCh;
+  const int c = blockIdx.x * kFinCh + cx;
+  double s = 0.0, q = 0.0;
+  if (c < C) {
+    for (int t = ry; t < tiles; t += kFinRows) {
+      s += (double)part_sum[(long)t * C + c];
+      q += (double)part_sq[(long)t * C + c];
+    }
+  }
+  s_sum[ry][cx] = s;
+  s_sq[ry][cx] = q;
+  __syncthreads();
+  if (ry == 0 && c < C) {
+    for (int r = 1; r < kFinRows; ++r) {
+      s += s_sum[r][cx];
+      q += s_sq[r][cx];
+    }
+    const double mean = s * inv_count;
+    double var = q * inv_count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float g = gamma ? gamma[c] : 1.f;
+    const float b = beta ? beta[c] : 0.f;
+    const float sc = g * invstd;
+    scale[c] = sc;
+    shift[c] = b - (float)mean * sc;
+    if (running_mean) {
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(var * unbias);
+    }
+  }
+}
+
+int bn_finalize(const float* part_sum, const float* part_sq, int tiles, int C, long count,
+                const float* gamma, const float* beta, float* running_mean, float* running_var,
+                float momentum, float eps, float* scale, float* shift, hipStream_t stream) {
+  CAPNET_REQUIRE(part_sum && part_sq && scale && shift && tiles > 0 && C > 0 && count > 0,
+                 "bn_finalize: bad argument");
+  const double inv = 1.0 / (double)count;
+  const double unbias = count > 1 ? (double)count / (double)(count - 1) : 1.0;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, kFinCh)), dim3(kFinCh * kFinRows), 0,
+                     stream, part_sum, part_sq, tiles, C, inv, unbias, gamma, beta, running_mean,
+                     running_var, momentum, eps, scale, shift);
+  CAPNET_LAUNCH_CHECK();
+  return kOk;
+}
+
+// eval mode: (scale, shift) from the running statistics
+__global__ void bn_eval_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                               const float* __restrict__ rm, const float* __restrict__ rv,
+                               float eps, int C, float* __restrict__ scale,
+                               float* __restrict__ shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float invstd = 1.f / sqrtf(rv[c] + eps);
+  const float sc = (gamma ? gamma[c] : 1.f) * invstd;
+  scale[c] = sc;
+  shift[c] = (beta ? beta[c] : 0.f) - rm[c] * sc;
+}
+
+int bn_eval_scale_shift(const float* gamma, const float* beta, const float* rm, const float* rv,
+                        float eps, int C, float* scale, float* shift, hipStream_t stream) {
+  CAPNET_REQUIRE(rm && rv && scale && shift && C > 0, "bn_eval_scale_shift: bad argument");
+  hipLaunchKernelGGL(bn_eval_kernel, dim3(cdiv(C, 256)), dim3(256), 0, stream, gamma, beta, rm,
+                     rv, eps, C, scale, shift);
+  CAPNET_LAUNCH_CHECK();
+  return kOk;
+}
+
+// ---- bottleneck tail: out = relu(bn3(y) + identity) or relu(bn3(y) + bn_ds(r)) ---------
+__global__ __launch_bounds__(256) void bn_add_relu_kernel(
+    const float4* __restrict__ y, const float* __restrict__ s1, const float* __restrict__ t1,
+    const float4* __restrict__ res, const float* __restrict__ s2, const float* __restrict__ t2,
+    float4* __restrict__ out, long n4, int C4) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const int c = (int)(i % C4) * 4;
+    const float4 a = y[i];
+    const float4 sc = *reinterpret_cast<const float4*>(s1 + c);
+    const float4 sh = *reinterpret_cast<const float4*>(t1 + c);
+    float4 v;
+    v.x = fmaf(a.x, sc.x, sh.x);
+    v.y = fmaf(a.y, sc.y, sh.y);
+    v.z = fmaf(a.z, sc.z, sh.z);
+    v.w = fmaf(a.w, sc.w, sh.w);
+    if (res) {
+      float4 r = res[i];
+      if (s2) {
+        const float4 sc2 = *reinterpret_cast<const float4*>(s2 + c);
+        const float4 sh2 = *reinterpret_cast<const float4*>(t2 + c);
+        r.x = fmaf(r.x, sc2.x, sh2.x);
+        r.y = fmaf(r.y, sc2.y, sh2.y);
+        r.z = fmaf(r.z, sc2.z, sh2.z);
+        r.w = fmaf(r.w, sc2.w, sh2.w);
+      }
+      v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+    }
+    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    out[i] = v;
+  }
+}
+
+int bn_add_relu(const float* y, const float* s1, const float* t1, const float* res,
+                const float* s2, const float* t2, float* out, long rows, int C,
+                hipStream_t stream) {
+  CAPNET_REQUIRE(y && s1 && t1 && out && rows > 0 && C > 0 && C % 4 == 0,
+                 "bn_add_relu: bad argument");
+  CAPNET_REQUIRE((s2 == nullptr) == (t2 == nullptr), "bn_add_relu: s2/t2 pair");
+  const long n4 = rows * (C / 4);
+  const int blocks = (int)(n4 / 256 < 1 ? 1 : (n4 / 256 > 8192 ? 8192 : n4 / 256));
+  hipLaunchKernelGGL(bn_add_relu_kernel, dim3(blocks), dim3(256), 0, stream, (const float4*)y, s1,
+                     t1, (const float4*)res, s2, t2, (float4*)out, n4, C / 4);
+  CAPNET_LAUNCH_CHECK();
+  return kOk;
+}
+
+// ---- stem tail: relu(bn1(y)) then MaxPool 3x3 / stride 2 / pad 1 -------------------------
+__global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(
+    const float* __restrict__ y, const float* __restrict__ sc, const float* __restrict__ sh,
+    float* __restrict__ out, int Bn, int H, int W, int C, int OH, int OW) {
+  const int C4 = C / 4;
+  const long total = (long)Bn * OH * OW * C4;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int c = (int)(i % C4) * 4;
+    long p = i / C4;
+    const int ow = (int)(p % OW); p /= OW;
+    const int oh = (int)(p % OH);
+    const int b = (int)(p / OH);
+    const float4 s = *reinterpret_cast<const float4*>(sc + c);
+    const float4 t = *reinterpret_cast<const float4*>(sh + c);
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int ih = oh * 2 - 1 + r;
+      if ((unsigned)ih >= (unsigned)H) continue;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int iw = ow * 2 - 1 + q;
+        if ((unsigned)iw >= (unsigned)W) continue;
+        const float4 a = *reinterpret_cast<const float4*>(y + (((long)b * H + ih) * W + iw) * C + c);
+        m.x = fmaxf(m.x, fmaxf(fmaf(a.x, s.x, t.x), 0.f));
+        m.y = fmaxf(m.y, fmaxf(fmaf(a.y, s.y, t.y), 0.f));
+        m.z = fmaxf(m.z, fmaxf(fmaf(a.z, s.z, t.z), 0.f));
+        m.w = fmaxf(m.w, fmaxf(fmaf(a.w, s.w, t.w), 0.f));
+      }
+    }
+    *reinterpret_cast<float4*>(out + (((long)b * OH + oh) * OW + ow) * C + c) = m;
+  }
+}
+
+int bn_relu_maxpool(const float* y, const float* scale, const float* shift, float* out, int Bn,
+                    int H, int W, int C, hipStream_t stream) {
+  CAPNET_REQUIRE(y && scale && shift && out && C % 4 == 0, "bn_relu_maxpool: bad argument");
+  const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+  const long total = (long)Bn * OH * OW * (C / 4);
+  const int blocks = (int)(total / 256 < 1 ? 1 : (total / 256 > 8192 ? 8192 : total / 256));
+  hipLaunchKernelGGL(bn_relu_maxpool_kernel, dim3(blocks), dim3(256), 0, stream, y, scale, shift,
+                     out, Bn, H, W, C, OH, OW);
+  CAPNET_LAUNCH_CHECK();
+  return kOk;
+}
+
+// ---- global average pool: [B][HW][C] -> [B][C] --------------------------------------------
+__global__ __launch_bounds__(256) void avgpool_kernel(const float* __restrict__ x,
+                                                      float* __restrict__ out, int Bn, int HW,
+                                                      int C, float inv) {
+  const int C4 = C / 4;
+  const long total = (long)Bn * C4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4) * 4;
+    const int b = (int)(i / C4);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int p = 0; p < HW; ++p) {
+      const float4 a = *reinterpret_cast<const float4*>(x + ((long)b * HW + p) * C + c);
+      s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+    }
+    s.x *= inv; s.y *= inv; s.z *= inv; s.w *= inv;
+    *reinterpret_cast<float4*>(out + (long)b * C + c) = s;
+  }
+}
+
+int global_avgpool(const float* x, float* out, int Bn, int HW, int C, hipStream_t stream) {
+  CAPNET_REQUIRE(x && out && C % 4 == 0 && HW > 0, "global_avgpool: bad argument");
+  const long total = (long)Bn * (C / 4);
+  hipLaunchKernelGGL(avgpool_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, x, out, Bn, HW,
+                     C, 1.f / (float)HW);
+  CAPNET_LAUNCH_CHECK();
+  return kOk;
+}
+
+// ---- AdaptiveAvgPool2d(OUT) on an NHWC map whose side divides OUT (7 -> 14 is a 2x
+// replication, stylenet/model_att.py:19-20,26) -------------------------------------------
+__global__ __launch_bounds__(256) void upsample_nhwc_kernel(const float4* __restrict__ x,
+                                                            float4* __restrict__ out, int Bn,
+                                                            int S, int OUT, int C4) {
+  const long total = (long)Bn * OUT * OUT * C4;
+  const int f = OUT / S;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4);
+    long p = i / C4;
+    const int ow = (int)(p % OUT); p /= OUT;
+    const int oh = (int)(p % OUT);
+    const int b = (int)(p / OUT);
+    out[i] = x[(((long)b * S + oh / f) * S + ow / f) * C4 + c];
+  }
+}
+
+int adaptive_pool_replicate(const float* x, float* out, int Bn, int S, int OUT, int C,
+                            hipStream_t stream) {
+  CAPNET_REQUIRE(x && out && C % 4 == 0 && S > 0 && OUT % S == 0,
+                 "adaptive_pool_replicate: output side must be a multiple of the input side");
+  const long total = (long)Bn * OUT * OUT * (C / 4);
+  const int blocks = (int)(total / 256 < 1 ? 1 : (total / 256 > 8192 ? 8192 : total / 256));
+  hipLaunchKernelGGL(upsample_nhwc_kernel, dim3(blocks), dim3(256), 0, stream, (const float4*)x,
+                     (float4*)out, Bn, S, OUT, C / 4);
+  CAPNET_LAUNCH_CHECK();
+  return kOk;
+}
+
+// ---- weight packing: OIHW (torch) -> [Cout][KH][KW][Cin] padded to Kw per row ------------
+__global__ void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout,
+                                   int Cin, int KH, int KW, int Kw) {
+  const long total = (long)Cout * Kw;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(i % Kw);
+    const int co = (int)(i / Kw);
+    float v = 0.f;
+    if (k < KH * KW * Cin) {
+      const int ci = k % Cin;
+      const int tap = k / Cin;
+      const int s = tap % KW, r = tap / KW;
+      v = w[(((long)co * Cin + ci) * KH + r) * KW + s];
+    }
+    out[i] = v;
+  }
+}
+
+int pack_conv_weight(const float* w_oihw, float* out, int Cout, int Cin, int KH, int KW, int Kw,
+                     hipStream_t stream) {
+  CAPNET_REQUIRE(w_oihw && out && Kw >= KH * KW * Cin, "pack_conv_weight: bad argument");
+  const long total = (long)Cout * Kw;
+  const int blocks = (int)(total / 256 < 1 ? 1 : (total / 256 > 4096 ? 4096 : total / 256));
+  hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, stream, w_oihw, out, Cout,
+                     Cin, KH, KW, Kw);
+  CAPNET_LAUNCH_CHECK();
+  return kOk;
+}
+
+}  // namespace capnet

@@ -1,0 +1,188 @@
+// extern "C" boundary of libcapnet_hip.so (declared in include/capnet.h).
+#include "../../include/capnet.h"
+
+#include "common.h"
+#include "kernels.h"
+
+using namespace capnet;
+
+static inline hipStream_t S(capnet_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+static SeqDims to_dims(const int* d) {
+  SeqDims r;
+  r.B = d[0]; r.T = d[1]; r.steps = d[2]; r.N = d[3]; r.E = d[4]; r.F = d[5]; r.H = d[6];
+  r.V = d[7]; r.has_features = d[8]; r.cell = d[9];
+  return r;
+}
+
+extern "C" {
+
+const char* capnet_last_error(void) { return last_error(); }
+int capnet_abi_version(void) { return 1; }
+
+int capnet_sgemm(int transA, int transB, int M, int N, int K, const float* A, long lda,
+                 const float* B, long ldb, float* C, long ldc, const float* bias, int accumulate,
+                 int batch, long strideA, long strideB, long strideC, long strideBias,
+                 int force_tile, capnet_stream_t stream) {
+  return sgemm(transA != 0, transB != 0, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, batch,
+               strideA, strideB, strideC, strideBias, force_tile, S(stream));
+}
+
+int capnet_colsum(const float* x, long ld, int rows, int C, float* out, int accumulate,
+                  capnet_stream_t stream) {
+  return colsum(x, ld, rows, C, out, accumulate, S(stream));
+}
+
+int capnet_argmax_rows(const float* x, int rows, int ld, int V, int* out, capnet_stream_t stream) {
+  CAPNET_REQUIRE(x && out && ld >= V && V > 0, "argmax_rows: bad argument");
+  return argmax_rows(x, rows, ld, V, out, S(stream));
+}
+
+int capnet_trunk_create(int batch, int height, int width, capnet_trunk_t** out) {
+  return trunk_create(batch, height, width, reinterpret_cast<Trunk**>(out));
+}
+void capnet_trunk_destroy(capnet_trunk_t* t) { trunk_destroy(reinterpret_cast<Trunk*>(t)); }
+size_t capnet_trunk_workspace_bytes(const capnet_trunk_t* t) {
+  return trunk_workspace_bytes(reinterpret_cast<const Trunk*>(t));
+}
+int capnet_trunk_num_convs(const capnet_trunk_t* t) {
+  return trunk_num_convs(reinterpret_cast<const Trunk*>(t));
+}
+int capnet_trunk_final_side(const capnet_trunk_t* t) {
+  return trunk_final_side(reinterpret_cast<const Trunk*>(t));
+}
+double capnet_trunk_flops(const capnet_trunk_t* t) {
+  return trunk_flops(reinterpret_cast<const Trunk*>(t));
+}
+int capnet_trunk_conv_shape(const capnet_trunk_t* t, int i, int* cout, int* cin, int* ksize,
+                            int* stride, int* row_stride) {
+  CAPNET_REQUIRE(t && cout && cin && ksize && stride && row_stride, "trunk_conv_shape: null");
+  return trunk_conv_shape(reinterpret_cast<const Trunk*>(t), i, cout, cin, ksize, stride,
+                          row_stride);
+}
+int capnet_trunk_forward(const capnet_trunk_t* t, const float* images_nchw,
+                         const float* const* w_packed, const float* const* bn_weight,
+                         const float* const* bn_bias, float* const* bn_running_mean,
+                         float* const* bn_running_var, int train, float momentum, float eps,
+                         void* workspace, float* out_pooled, float* out_map,
+                         capnet_stream_t stream) {
+  return trunk_forward(reinterpret_cast<const Trunk*>(t), images_nchw, w_packed, bn_weight,
+                       bn_bias, bn_running_mean, bn_running_var, train, momentum, eps,
+                       reinterpret_cast<float*>(workspace), out_pooled, out_map, S(stream));
+}
+int capnet_pack_conv_weight(const float* w_oihw, float* out, int Cout, int Cin, int KH, int KW,
+                            int row_stride, capnet_stream_t stream) {
+  return pack_conv_weight(w_oihw, out, Cout, Cin, KH, KW, row_stride, S(stream));
+}
+int capnet_adaptive_pool_replicate(const float* x, float* out, int B, int side, int out_side,
+                                   int C, capnet_stream_t stream) {
+  return adaptive_pool_replicate(x, out, B, side, out_side, C, S(stream));
+}
+
+int capnet_conv2d_fwd(const float* x, long sxb, long sxh, long sxw, long sxc,
+                      const float* w_packed, int row_stride, float* y, const float* in_scale,
+                      const float* in_shift, int relu_in, float* part_sum, float* part_sq, int B,
+                      int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                      int tile, capnet_stream_t stream) {
+  return conv2d_fwd(x, sxb, sxh, sxw, sxc, w_packed, row_stride, y, in_scale, in_shift, relu_in,
+                    part_sum, part_sq, B, H, W, Cin, Cout, KH, KW, stride, pad, tile, S(stream));
+}
+int capnet_conv_tiles_m(int M, int Cout, int tile) {
+  if (tile == 0) tile = conv_auto_tile(M, Cout);
+  return conv_tiles_m(M, tile);
+}
+int capnet_bn_finalize(const float* part_sum, const float* part_sq, int tiles, int C, long count,
+                       const float* gamma, const float* beta, float* running_mean,
+                       float* running_var, float momentum, float eps, float* scale, float* shift,
+                       capnet_stream_t stream) {
+  return bn_finalize(part_sum, part_sq, tiles, C, count, gamma, beta, running_mean, running_var,
+                     momentum, eps, scale, shift, S(stream));
+}
+int capnet_bn_add_relu(const float* y, const float* s1, const float* t1, const float* res,
+                       const float* s2, const float* t2, float* out, long rows, int C,
+                       capnet_stream_t stream) {
+  return bn_add_relu(y, s1, t1, res, s2, t2, out, rows, C, S(stream));
+}
+int capnet_bn_relu_maxpool(const float* y, const float* scale, const float* shift, float* out,
+                           int B, int H, int W, int C, capnet_stream_t stream) {
+  return bn_relu_maxpool(y, scale, shift, out, B, H, W, C, S(stream));
+}
+int capnet_global_avgpool(const float* x, float* out, int B, int HW, int C,
+                          capnet_stream_t stream) {
+  return global_avgpool(x, out, B, HW, C, S(stream));
+}
+
+int capnet_bn1d_fwd(const float* x, int B, int C, const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, int train, float momentum, float eps,
+                    float* y, float* save_mean, float* save_invstd, capnet_stream_t stream) {
+  return bn1d_fwd(x, B, C, gamma, beta, running_mean, running_var, train, momentum, eps, y,
+                  save_mean, save_invstd, S(stream));
+}
+int capnet_bn1d_bwd(const float* dy, const float* x, int B, int C, const float* gamma,
+                    const float* save_mean, const float* save_invstd, float* dx, float* dgamma,
+                    float* dbeta, capnet_stream_t stream) {
+  return bn1d_bwd(dy, x, B, C, gamma, save_mean, save_invstd, dx, dgamma, dbeta, S(stream));
+}
+
+size_t capnet_seq_saved_floats(const int* dims) { return seq_saved_floats(to_dims(dims)); }
+size_t capnet_seq_saved_ints(const int* dims) { return seq_saved_ints(to_dims(dims)); }
+size_t capnet_seq_fwd_scratch_floats(const int* dims) { return seq_fwd_scratch_floats(to_dims(dims)); }
+size_t capnet_seq_bwd_scratch_floats(const int* dims) { return seq_bwd_scratch_floats(to_dims(dims)); }
+
+int capnet_seq_forward(const int* dims, const int* batch_sizes, const unsigned char* tf_mask,
+                       const long long* captions, const float* features, const float* emb,
+                       const float* const* weights, const float* Cw, const float* Cb,
+                       float dropout_p, unsigned long long seed, int training, float* saved,
+                       int* saved_i, float* scratch, float* hiddens, int* err_flag,
+                       capnet_stream_t stream) {
+  CAPNET_REQUIRE(dims && weights, "seq_forward: null dims/weights");
+  SeqWeights w;
+  for (int g = 0; g < 4; ++g) {
+    w.Vw[g] = weights[0 + g];  w.Vb[g] = weights[4 + g];
+    w.Sw[g] = weights[8 + g];  w.Sb[g] = weights[12 + g];
+    w.Uw[g] = weights[16 + g]; w.Ub[g] = weights[20 + g];
+    w.Ww[g] = weights[24 + g]; w.Wb[g] = weights[28 + g];
+  }
+  const SeqDims d = to_dims(dims);
+  if (d.cell == kCellFactored) {
+    for (int i = 0; i < 32; ++i) CAPNET_REQUIRE(weights[i], "seq_forward: weight %d is null", i);
+  } else {
+    CAPNET_REQUIRE(d.cell == kCellLSTM, "seq_forward: unknown cell %d", d.cell);
+    CAPNET_REQUIRE(w.Vw[0] && w.Vb[0] && w.Ww[0] && w.Wb[0], "seq_forward: LSTM weight is null");
+  }
+  return seq_forward(d, batch_sizes, tf_mask, captions, features, emb, w, Cw, Cb, dropout_p, seed,
+                     training, saved, saved_i, scratch, hiddens, err_flag, S(stream));
+}
+
+int capnet_seq_backward(const int* dims, const int* batch_sizes, const float* d_hiddens,
+                        const float* hiddens, const float* saved, const int* saved_i,
+                        float* scratch, float* const* grads, float dropout_p,
+                        unsigned long long seed, int training, capnet_stream_t stream) {
+  CAPNET_REQUIRE(dims && grads, "seq_backward: null dims/grads");
+  SeqGrads g;
+  g.dVcat = grads[0]; g.dbV = grads[1]; g.dScat = grads[2]; g.dbS = grads[3]; g.dUcat = grads[4];
+  g.dbUW = grads[5]; g.dWcat = grads[6]; g.dEmb = grads[7]; g.dFeat = grads[8];
+  return seq_backward(to_dims(dims), batch_sizes, d_hiddens, hiddens, saved, saved_i, scratch, g,
+                      dropout_p, seed, training, S(stream));
+}
+
+int capnet_xent_fwd(const float* logits, long ld, int N, int V, const long long* targets,
+                    float* lse, float* row_loss, float* loss, int* err_flag,
+                    capnet_stream_t stream) {
+  return xent_fwd(logits, ld, N, V, targets, lse, row_loss, loss, err_flag, S(stream));
+}
+int capnet_xent_bwd(const float* logits, long ld, int N, int V, const long long* targets,
+                    const float* lse, const float* grad_out, float* dlogits, long ldd,
+                    capnet_stream_t stream) {
+  return xent_bwd(logits, ld, N, V, targets, lse, grad_out, dlogits, ldd, S(stream));
+}
+
+int capnet_clamp_adam(int n, float* const* params, float* const* grads, float* const* exp_avg,
+                      float* const* exp_avg_sq, const long* numel, const int* step, float lr,
+                      float beta1, float beta2, float eps, float clip, int write_grad,
+                      capnet_stream_t stream) {
+  return clamp_adam(n, params, grads, exp_avg, exp_avg_sq, numel, step, lr, beta1, beta2, eps, clip,
+                    write_grad, S(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,292 @@
+// Sequence drivers for the caption decoders: one C call runs the whole scheduled-sampling
+// recurrence (forward) or the whole BPTT (backward) as a chain of HIP launches on one stream.
+//
+// Follows DecoderFactoredLSTM.forward / forward_step (stylenet/model.py:115-196) and
+// DecoderRNN.forward (nic/model.py:74-115):
+//   * inputs are [image feature, dropout(B(w_0)), ..., dropout(B(w_{L-2}))], packed time-major
+//     (pack_padded_sequence order, batch shrinking with `batch_sizes`);
+//   * step t is teacher forced iff tf_mask[t] (the caller draws random.random() per step,
+//     model.py:181); otherwise its input is B(argmax(C h_{t-1})) WITHOUT dropout (model.py:184),
+//     or B(captions[:,0]) at t = 0;
+//   * FactoredLSTM gate pre-activation = U_g(S_g(V_g(x))) + W_g(h); c = f*c + i*c~; h = o*c.
+// MI355X mapping: the input chain of all teacher-forced rows is three batched MFMA GEMMs over
+// N = sum(lengths) rows (gate-concatenated / gate-batched weights); only the recurrent
+// 4H x H product and the pointwise gate update run per time step.
+#include <vector>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace capnet {
+
+namespace {
+
+struct Layout {
+  // saved float buffer
+  size_t X, A1, A2, G, Cst, Vcat, Scat, Ucat, Wcat, bV, bS, bUW, total;
+  // int buffer
+  size_t row_sample, row_col, row_token, prev_row, itotal;
+};
+
+Layout make_layout(const SeqDims& d) {
+  Layout L;
+  size_t o = 0;
+  auto take = [&](size_t n) { size_t r = o; o += (n + 3) / 4 * 4; return r; };
+  const size_t N = d.N, E = d.E, F = d.F, H = d.H;
+  L.X = take(N * E);
+  L.G = take(N * 4 * H);
+  L.Cst = take(N * H);
+  L.Wcat = take(4 * H * H);
+  L.bUW = take(4 * H);
+  if (d.cell == kCellFactored) {
+    L.A1 = take(N * 4 * F);
+    L.A2 = take(N * 4 * F);
+    L.Vcat = take(4 * F * E);
+    L.Scat = take(4 * F * F);
+    L.Ucat = take(4 * H * F);
+    L.bV = take(4 * F);
+    L.bS = take(4 * F);
+  } else {
+    L.A1 = L.A2 = L.Scat = L.Ucat = L.bV = L.bS = 0;
+    L.Vcat = take(4 * H * E);  // weight_ih copy (kept so backward sees the forward's weights)
+  }
+  L.total = o;
+  size_t io = 0;
+  auto itake = [&](size_t n) { size_t r = io; io += (n + 3) / 4 * 4; return r; };
+  L.row_sample = itake(N);
+  L.row_col = itake(N);
+  L.row_token = itake(N);
+  L.prev_row = itake(N);
+  L.itotal = io;
+  return L;
+}
+
+int check_dims(const SeqDims& d, const int* batch_sizes) {
+  CAPNET_REQUIRE(d.B > 0 && d.T > 0 && d.steps > 0 && d.N > 0 && d.E > 0 && d.H > 0 && d.V > 0,
+                 "decoder: bad dims B=%d T=%d steps=%d N=%d E=%d H=%d V=%d", d.B, d.T, d.steps,
+                 d.N, d.E, d.H, d.V);
+  CAPNET_REQUIRE(d.cell == kCellLSTM || d.F > 0, "decoder: factored size");
+  CAPNET_REQUIRE(batch_sizes != nullptr, "decoder: null batch_sizes");
+  long n = 0;
+  int prev = d.B;
+  for (int t = 0; t < d.steps; ++t) {
+    CAPNET_REQUIRE(batch_sizes[t] > 0 && batch_sizes[t] <= prev,
+                   "decoder: batch_sizes must be positive and non-increasing (step %d: %d after %d)",
+                   t, batch_sizes[t], prev);
+    prev = batch_sizes[t];
+    n += batch_sizes[t];
+  }
+  CAPNET_REQUIRE(n == d.N, "decoder: sum(batch_sizes)=%ld != N=%d", n, d.N);
+  CAPNET_REQUIRE(d.steps <= d.T + (d.has_features ? 1 : 0),
+                 "decoder: %d steps need more caption columns than T=%d", d.steps, d.T);
+  return kOk;
+}
+
+struct GateOrder { int gi, gf, go, gg, tanh_out; };
+GateOrder gate_order(int cell) {
+  // FactoredLSTM packs i,f,o,c~ ; nn.LSTMCell stores i,f,g,o
+  return cell == kCellFactored ? GateOrder{0, 1, 2, 3, 0} : GateOrder{0, 1, 3, 2, 1};
+}
+
+#define RC(x) do { int _rc = (x); if (_rc) return _rc; } while (0)
+
+int copy_d2d(float* dst, const float* src, size_t n, hipStream_t s) {
+  CAPNET_HIP_CHECK(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+  return kOk;
+}
+
+// gate pre-activations of rows [r0, r1) from their inputs X
+int input_chain(const SeqDims& d, const Layout& L, float* sv, int r0, int r1, hipStream_t s) {
+  const int n = r1 - r0;
+  if (n <= 0) return kOk;
+  const int E = d.E, F = d.F, H = d.H;
+  if (d.cell == kCellFactored) {
+    // A1 = X . Vcat^T + bV                          [n x 4F]
+    RC(sgemm(false, true, n, 4 * F, E, sv + L.X + (size_t)r0 * E, E, sv + L.Vcat, E,
+             sv + L.A1 + (size_t)r0 * 4 * F, 4 * F, sv + L.bV, 0, 1, 0, 0, 0, 0, 0, s));
+    // A2[:, g] = A1[:, g] . S_g^T + bS_g             4 gate groups
+    RC(sgemm(false, true, n, F, F, sv + L.A1 + (size_t)r0 * 4 * F, 4 * F, sv + L.Scat, F,
+             sv + L.A2 + (size_t)r0 * 4 * F, 4 * F, sv + L.bS, 0, 4, F, (long)F * F, F, F, 0, s));
+    // G[:, g] = A2[:, g] . U_g^T + (bU_g + bW_g)
+    RC(sgemm(false, true, n, H, F, sv + L.A2 + (size_t)r0 * 4 * F, 4 * F, sv + L.Ucat, F,
+             sv + L.G + (size_t)r0 * 4 * H, 4 * H, sv + L.bUW, 0, 4, F, (long)H * F, H, H, 0, s));
+  } else {
+    // G = X . W_ih^T + (b_ih + b_hh)
+    RC(sgemm(false, true, n, 4 * H, E, sv + L.X + (size_t)r0 * E, E, sv + L.Vcat, E,
+             sv + L.G + (size_t)r0 * 4 * H, 4 * H, sv + L.bUW, 0, 1, 0, 0, 0, 0, 0, s));
+  }
+  return kOk;
+}
+
+}  // namespace
+
+size_t seq_saved_floats(const SeqDims& d) { return make_layout(d).total; }
+size_t seq_saved_ints(const SeqDims& d) { return make_layout(d).itotal; }
+
+size_t seq_fwd_scratch_floats(const SeqDims& d) { return (size_t)d.B * d.V + 64; }
+
+size_t seq_bwd_scratch_floats(const SeqDims& d) {
+  const size_t N = d.N;
+  size_t n = N * 4 * d.H + N * d.H + 2 * (size_t)d.B * d.H + N * d.E + 256;
+  if (d.cell == kCellFactored) n += 2 * N * 4 * d.F;
+  return n;
+}
+
+int seq_forward(const SeqDims& d, const int* batch_sizes, const unsigned char* tf_mask,
+                const long long* captions, const float* features, const float* emb,
+                const SeqWeights& w, const float* Cw, const float* Cb, float dropout_p,
+                unsigned long long seed, int training, float* saved, int* saved_i, float* scratch,
+                float* hiddens, int* err_flag, hipStream_t s) {
+  RC(check_dims(d, batch_sizes));
+  CAPNET_REQUIRE(tf_mask && captions && emb && saved && saved_i && scratch && hiddens && err_flag,
+                 "seq_forward: null argument");
+  CAPNET_REQUIRE(!d.has_features || features, "seq_forward: features missing");
+  CAPNET_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "seq_forward: dropout p=%f", dropout_p);
+  const Layout L = make_layout(d);
+  const int E = d.E, F = d.F, H = d.H, N = d.N;
+  const GateOrder go = gate_order(d.cell);
+  bool any_free = false;
+  for (int t = 1; t < d.steps; ++t) any_free |= !tf_mask[t];
+  CAPNET_REQUIRE(!any_free || (Cw && Cb), "seq_forward: output projection needed for free-running steps");
+
+  // ---- row bookkeeping, built on device from kernel arguments (no copy, no sync)
+  CAPNET_REQUIRE(d.steps <= kMaxSteps, "seq_forward: %d steps > %d", d.steps, kMaxSteps);
+  std::vector<int> off(d.steps + 1, 0);
+  for (int t = 0; t < d.steps; ++t) off[t + 1] = off[t] + batch_sizes[t];
+  {
+    SeqMeta m;
+    m.N = N; m.steps = d.steps; m.has_features = d.has_features;
+    for (int t = 0; t <= d.steps; ++t) m.off[t] = off[t];
+    for (int t = 0; t < d.steps; ++t) m.tf[t] = tf_mask[t] ? 1 : 0;
+    RC(build_rows(m, saved_i + L.row_sample, saved_i + L.row_col, saved_i + L.row_token,
+                  saved_i + L.prev_row, s));
+  }
+
+  // ---- pack weights
+  float* sv = saved;
+  if (d.cell == kCellFactored) {
+    for (int g = 0; g < 4; ++g) {
+      RC(copy_d2d(sv + L.Vcat + (size_t)g * F * E, w.Vw[g], (size_t)F * E, s));
+      RC(copy_d2d(sv + L.Scat + (size_t)g * F * F, w.Sw[g], (size_t)F * F, s));
+      RC(copy_d2d(sv + L.Ucat + (size_t)g * H * F, w.Uw[g], (size_t)H * F, s));
+      RC(copy_d2d(sv + L.Wcat + (size_t)g * H * H, w.Ww[g], (size_t)H * H, s));
+      RC(copy_d2d(sv + L.bV + (size_t)g * F, w.Vb[g], F, s));
+      RC(copy_d2d(sv + L.bS + (size_t)g * F, w.Sb[g], F, s));
+      RC(vec_add(w.Ub[g], w.Wb[g], sv + L.bUW + (size_t)g * H, H, s));
+    }
+  } else {
+    RC(copy_d2d(sv + L.Vcat, w.Vw[0], (size_t)4 * H * E, s));
+    RC(copy_d2d(sv + L.Wcat, w.Ww[0], (size_t)4 * H * H, s));
+    RC(vec_add(w.Vb[0], w.Wb[0], sv + L.bUW, 4 * H, s));
+  }
+
+  // ---- inputs + input chain for every row whose input is known up front
+  CAPNET_HIP_CHECK(hipMemsetAsync(sv + L.X, 0, (size_t)N * E * sizeof(float), s));
+  RC(gather_inputs(captions, d.T, features, emb, E, d.V, saved_i + L.row_sample,
+                   saved_i + L.row_col, saved_i + L.row_token, sv + L.X, 0, N, dropout_p, seed,
+                   training && dropout_p > 0.f, 0, err_flag, s));
+  RC(input_chain(d, L, sv, 0, N, s));
+
+  // ---- recurrence
+  for (int t = 0; t < d.steps; ++t) {
+    const int b = batch_sizes[t], r0 = off[t];
+    if (t > 0) {
+      const float* h_prev = hiddens + (size_t)off[t - 1] * H;
+      if (!tf_mask[t]) {
+        // predicted = argmax(C h_{t-1}) for the b surviving rows; then this step's input chain
+        RC(sgemm(false, true, b, d.V, H, h_prev, H, Cw, H, scratch, d.V, Cb, 0, 1, 0, 0, 0, 0, 0, s));
+        RC(argmax_rows(scratch, b, d.V, d.V, saved_i + L.row_token + r0, s));
+        RC(gather_inputs(captions, d.T, features, emb, E, d.V, saved_i + L.row_sample,
+                         saved_i + L.row_col, saved_i + L.row_token, sv + L.X, r0, r0 + b,
+                         dropout_p, seed, 0, 1, err_flag, s));
+        RC(input_chain(d, L, sv, r0, r0 + b, s));
+      }
+      // G[rows] += h_{t-1} . Wcat^T
+      RC(sgemm(false, true, b, 4 * H, H, h_prev, H, sv + L.Wcat, H, sv + L.G + (size_t)r0 * 4 * H,
+               4 * H, nullptr, 1, 1, 0, 0, 0, 0, 0, s));
+    }
+    RC(lstm_pointwise_fwd(sv + L.G + (size_t)r0 * 4 * H,
+                          t > 0 ? sv + L.Cst + (size_t)off[t - 1] * H : nullptr,
+                          sv + L.Cst + (size_t)r0 * H, hiddens + (size_t)r0 * H, b, H, go.gi, go.gf,
+                          go.go, go.gg, go.tanh_out, s));
+  }
+  return kOk;
+}
+
+int seq_backward(const SeqDims& d, const int* batch_sizes, const float* dH, const float* hiddens,
+                 const float* saved, const int* saved_i, float* scratch, const SeqGrads& g,
+                 float dropout_p, unsigned long long seed, int training, hipStream_t s) {
+  RC(check_dims(d, batch_sizes));
+  CAPNET_REQUIRE(dH && hiddens && saved && saved_i && scratch, "seq_backward: null argument");
+  CAPNET_REQUIRE(g.dWcat && g.dbUW && g.dVcat && g.dEmb, "seq_backward: null gradient buffer");
+  const Layout L = make_layout(d);
+  const int E = d.E, F = d.F, H = d.H, N = d.N;
+  const GateOrder go = gate_order(d.cell);
+  std::vector<int> off(d.steps + 1, 0);
+  for (int t = 0; t < d.steps; ++t) off[t + 1] = off[t] + batch_sizes[t];
+
+  size_t o = 0;
+  auto take = [&](size_t n) { size_t r = o; o += (n + 3) / 4 * 4; return r; };
+  float* dPre = scratch + take((size_t)N * 4 * H);
+  float* Hprev = scratch + take((size_t)N * H);
+  float* dh_rec = scratch + take((size_t)d.B * H);
+  float* dc = scratch + take((size_t)d.B * H);
+  float* dX = scratch + take((size_t)N * E);
+  float* dA2 = nullptr;
+  float* dA1 = nullptr;
+  if (d.cell == kCellFactored) {
+    dA2 = scratch + take((size_t)N * 4 * F);
+    dA1 = scratch + take((size_t)N * 4 * F);
+  }
+  const float* sv = saved;
+  CAPNET_HIP_CHECK(hipMemsetAsync(dh_rec, 0, (size_t)d.B * H * sizeof(float), s));
+  CAPNET_HIP_CHECK(hipMemsetAsync(dc, 0, (size_t)d.B * H * sizeof(float), s));
+
+  for (int t = d.steps - 1; t >= 0; --t) {
+    const int b = batch_sizes[t], r0 = off[t];
+    const int b_next = (t + 1 < d.steps) ? batch_sizes[t + 1] : 0;
+    RC(lstm_pointwise_bwd(sv + L.G + (size_t)r0 * 4 * H, sv + L.Cst + (size_t)r0 * H,
+                          t > 0 ? sv + L.Cst + (size_t)off[t - 1] * H : nullptr,
+                          dH + (size_t)r0 * H, dh_rec, dc, dPre + (size_t)r0 * 4 * H, b, b_next, H,
+                          go.gi, go.gf, go.go, go.gg, go.tanh_out, s));
+    if (t > 0) {
+      // dh_{t-1}[0:b] = dPre_t . Wcat     (rows b..b_{t-1} of step t-1 have no successor)
+      RC(sgemm(false, false, b, H, 4 * H, dPre + (size_t)r0 * 4 * H, 4 * H, sv + L.Wcat, H, dh_rec,
+               H, nullptr, 0, 1, 0, 0, 0, 0, 0, s));
+    }
+  }
+  // recurrent weight gradient over all steps at once: dWcat = dPre^T . h_{t-1}
+  RC(gather_rows(hiddens, saved_i + L.prev_row, Hprev, N, H, s));
+  RC(sgemm(true, false, 4 * H, H, N, dPre, 4 * H, Hprev, H, g.dWcat, H, nullptr, 0, 1, 0, 0, 0, 0, 0, s));
+  RC(colsum(dPre, 4 * H, N, 4 * H, g.dbUW, 0, s));
+
+  if (d.cell == kCellFactored) {
+    CAPNET_REQUIRE(g.dUcat && g.dScat && g.dbS && g.dbV, "seq_backward: null factored gradient buffer");
+    // U: dU_g = dPre_g^T . A2_g ; dA2_g = dPre_g . U_g
+    RC(sgemm(true, false, H, F, N, dPre, 4 * H, sv + L.A2, 4 * F, g.dUcat, F, nullptr, 0, 4, H, F,
+             (long)H * F, 0, 0, s));
+    RC(sgemm(false, false, N, F, H, dPre, 4 * H, sv + L.Ucat, F, dA2, 4 * F, nullptr, 0, 4, H,
+             (long)H * F, F, 0, 0, s));
+    RC(colsum(dA2, 4 * F, N, 4 * F, g.dbS, 0, s));
+    // S: dS_g = dA2_g^T . A1_g ; dA1_g = dA2_g . S_g
+    RC(sgemm(true, false, F, F, N, dA2, 4 * F, sv + L.A1, 4 * F, g.dScat, F, nullptr, 0, 4, F, F,
+             (long)F * F, 0, 0, s));
+    RC(sgemm(false, false, N, F, F, dA2, 4 * F, sv + L.Scat, F, dA1, 4 * F, nullptr, 0, 4, F,
+             (long)F * F, F, 0, 0, s));
+    RC(colsum(dA1, 4 * F, N, 4 * F, g.dbV, 0, s));
+    // V: dVcat = dA1^T . X ; dX = dA1 . Vcat
+    RC(sgemm(true, false, 4 * F, E, N, dA1, 4 * F, sv + L.X, E, g.dVcat, E, nullptr, 0, 1, 0, 0, 0, 0, 0, s));
+    RC(sgemm(false, false, N, E, 4 * F, dA1, 4 * F, sv + L.Vcat, E, dX, E, nullptr, 0, 1, 0, 0, 0, 0, 0, s));
+  } else {
+    RC(sgemm(true, false, 4 * H, E, N, dPre, 4 * H, sv + L.X, E, g.dVcat, E, nullptr, 0, 1, 0, 0, 0, 0, 0, s));
+    RC(sgemm(false, false, N, E, 4 * H, dPre, 4 * H, sv + L.Vcat, E, dX, E, nullptr, 0, 1, 0, 0, 0, 0, 0, s));
+  }
+  CAPNET_HIP_CHECK(hipMemsetAsync(g.dEmb, 0, (size_t)d.V * E * sizeof(float), s));
+  if (g.dFeat) CAPNET_HIP_CHECK(hipMemsetAsync(g.dFeat, 0, (size_t)d.B * E * sizeof(float), s));
+  RC(scatter_input_grad(dX, N, E, saved_i + L.row_sample, saved_i + L.row_col,
+                        saved_i + L.row_token, g.dEmb, g.dFeat, d.V, dropout_p, seed,
+                        training && dropout_p > 0.f, s));
+  return kOk;
+}
+
+}  // namespace capnet

@@ -1,0 +1,129 @@
+// Internal C++ entry points of libcapnet_hip (one per kernel family). The extern "C"
+// boundary in capi.cpp forwards to these; nothing here allocates or synchronises.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace capnet {
+
+// gemm_f32.hip
+int sgemm(bool ta, bool tb, int M, int N, int K, const float* A, long lda, const float* B,
+          long ldb, float* C, long ldc, const float* bias, int accumulate, int batch, long sA,
+          long sB, long sC, long sBias, int force_tile, hipStream_t stream);
+
+// conv_f32.hip
+int conv2d_fwd(const float* x, long sxb, long sxh, long sxw, long sxc, const float* w_packed,
+               int Kw, float* y, const float* in_scale, const float* in_shift, int relu_in,
+               float* part_sum, float* part_sq, int Bn, int H, int W, int Cin, int Cout, int KH,
+               int KW, int stride, int pad, int tile, hipStream_t stream);
+int conv_auto_tile(int M, int Cout);
+int conv_tiles_m(int M, int tile);
+
+// bn_pool.hip
+int bn_finalize(const float* part_sum, const float* part_sq, int tiles, int C, long count,
+                const float* gamma, const float* beta, float* running_mean, float* running_var,
+                float momentum, float eps, float* scale, float* shift, hipStream_t stream);
+int bn_eval_scale_shift(const float* gamma, const float* beta, const float* rm, const float* rv,
+                        float eps, int C, float* scale, float* shift, hipStream_t stream);
+int bn_add_relu(const float* y, const float* s1, const float* t1, const float* res,
+                const float* s2, const float* t2, float* out, long rows, int C,
+                hipStream_t stream);
+int bn_relu_maxpool(const float* y, const float* scale, const float* shift, float* out, int Bn,
+                    int H, int W, int C, hipStream_t stream);
+int global_avgpool(const float* x, float* out, int Bn, int HW, int C, hipStream_t stream);
+int adaptive_pool_replicate(const float* x, float* out, int Bn, int S, int OUT, int C,
+                            hipStream_t stream);
+int pack_conv_weight(const float* w_oihw, float* out, int Cout, int Cin, int KH, int KW, int Kw,
+                     hipStream_t stream);
+
+// trunk.cpp
+struct Trunk;
+int trunk_create(int B, int H, int W, Trunk** out);
+void trunk_destroy(Trunk* t);
+size_t trunk_workspace_bytes(const Trunk* t);
+int trunk_num_convs(const Trunk* t);
+int trunk_final_side(const Trunk* t);
+int trunk_conv_shape(const Trunk* t, int i, int* cout, int* cin, int* k, int* stride, int* kw);
+double trunk_flops(const Trunk* t);
+int trunk_forward(const Trunk* t, const float* images_nchw, const float* const* w_packed,
+                  const float* const* bn_gamma, const float* const* bn_beta,
+                  float* const* bn_rmean, float* const* bn_rvar, int train, float momentum,
+                  float eps, float* workspace, float* out_pooled, float* out_map,
+                  hipStream_t stream);
+
+// seq_kernels.hip
+constexpr int kMaxSteps = 128;
+struct SeqMeta {
+  int N, steps, has_features;
+  int off[kMaxSteps + 1];
+  unsigned char tf[kMaxSteps];
+};
+int build_rows(const SeqMeta& m, int* row_sample, int* row_col, int* row_token, int* prev_row,
+               hipStream_t stream);
+int gather_inputs(const long long* captions, int T, const float* features, const float* emb, int E,
+                  int V, const int* row_sample, const int* row_col, int* row_token, float* X,
+                  int r0, int r1, float p, unsigned long long seed, int use_dropout, int dynamic,
+                  int* err_flag, hipStream_t stream);
+int vec_add(const float* a, const float* b, float* out, int n, hipStream_t stream);
+int lstm_pointwise_fwd(float* pre, const float* c_prev, float* c_out, float* h_out, int b, int H,
+                       int gi, int gf, int go, int gg, int tanh_out, hipStream_t stream);
+int lstm_pointwise_bwd(const float* gates, const float* c, const float* c_prev, const float* dH,
+                       const float* dh_rec, float* dc_io, float* dpre, int b, int b_next, int H,
+                       int gi, int gf, int go, int gg, int tanh_out, hipStream_t stream);
+int argmax_rows(const float* x, int rows, int ld, int V, int* out, hipStream_t stream);
+int gather_rows(const float* src, const int* idx, float* out, int rows, int C, hipStream_t stream);
+int colsum(const float* x, long ld, int rows, int C, float* out, int accumulate,
+           hipStream_t stream);
+int scatter_input_grad(const float* dX, int N, int E, const int* row_sample, const int* row_col,
+                       const int* row_token, float* dEmb, float* dFeat, int V, float p,
+                       unsigned long long seed, int use_dropout, hipStream_t stream);
+
+// loss_optim.hip
+int xent_fwd(const float* logits, long ld, int N, int V, const long long* targets, float* lse,
+             float* row_loss, float* loss, int* err_flag, hipStream_t stream);
+int xent_bwd(const float* logits, long ld, int N, int V, const long long* targets,
+             const float* lse, const float* gout, float* dlogits, long ldd, hipStream_t stream);
+int clamp_adam(int n_tensors, float* const* params, float* const* grads, float* const* exp_avg,
+               float* const* exp_avg_sq, const long* numel, const int* step, float lr, float b1,
+               float b2, float eps, float clip, int write_grad, hipStream_t stream);
+int bn1d_fwd(const float* x, int B, int C, const float* gamma, const float* beta, float* rmean,
+             float* rvar, int train, float momentum, float eps, float* y, float* save_mean,
+             float* save_invstd, hipStream_t stream);
+int bn1d_bwd(const float* dy, const float* x, int B, int C, const float* gamma,
+             const float* save_mean, const float* save_invstd, float* dx, float* dgamma,
+             float* dbeta, hipStream_t stream);
+
+// decoder_seq.cpp
+constexpr int kCellFactored = 0;  // DecoderFactoredLSTM (stylenet/model.py)
+constexpr int kCellLSTM = 1;      // nn.LSTMCell (nic/model.py)
+struct SeqDims {
+  int B, T, steps, N, E, F, H, V, has_features, cell;
+};
+// Factored: Vw/Vb/Sw/Sb/Uw/Ub/Ww/Wb per gate (i, f, o, c). LSTM cell: Vw[0] = weight_ih,
+// Vb[0] = bias_ih, Ww[0] = weight_hh, Wb[0] = bias_hh (gate order i, f, g, o).
+struct SeqWeights {
+  const float* Vw[4]; const float* Vb[4];
+  const float* Sw[4]; const float* Sb[4];
+  const float* Uw[4]; const float* Ub[4];
+  const float* Ww[4]; const float* Wb[4];
+};
+// packed gradients: dVcat [4F][E] (or weight_ih [4H][E]), dbV [4F], dScat [4][F][F], dbS [4F],
+// dUcat [4][H][F], dbUW [4H] (= grad of U bias = grad of W bias; LSTM: of both biases),
+// dWcat [4H][H], dEmb [V][E], dFeat [B][E] or null
+struct SeqGrads {
+  float* dVcat; float* dbV; float* dScat; float* dbS; float* dUcat; float* dbUW; float* dWcat;
+  float* dEmb; float* dFeat;
+};
+size_t seq_saved_floats(const SeqDims& d);
+size_t seq_saved_ints(const SeqDims& d);
+size_t seq_fwd_scratch_floats(const SeqDims& d);
+size_t seq_bwd_scratch_floats(const SeqDims& d);
+int seq_forward(const SeqDims& d, const int* batch_sizes, const unsigned char* tf_mask,
+                const long long* captions, const float* features, const float* emb,
+                const SeqWeights& w, const float* Cw, const float* Cb, float dropout_p,
+                unsigned long long seed, int training, float* saved, int* saved_i, float* scratch,
+                float* hiddens, int* err_flag, hipStream_t s);
+int seq_backward(const SeqDims& d, const int* batch_sizes, const float* dH, const float* hiddens,
+                 const float* saved, const int* saved_i, float* scratch, const SeqGrads& g,
+                 float dropout_p, unsigned long long seed, int training, hipStream_t s);
+
+}  // namespace capnet

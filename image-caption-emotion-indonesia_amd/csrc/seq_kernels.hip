@@ -1,0 +1,339 @@
+// Memory-bound kernels of the caption decoders (FactoredLSTM / LSTMCell recurrences):
+// embedding gather + dropout, gate pointwise forward/backward, row argmax, row gather,
+// column sums (bias gradients) and the embedding-gradient scatter.
+// Packed ("time-major") row order is torch's pack_padded_sequence order used by
+// stylenet/model.py:173-194: rows of step t are contiguous, sample order preserved.
+#include "common.h"
+#include "kernels.h"
+
+namespace capnet {
+
+// counter-based dropout mask: keep iff u(seed, sample, col, e) >= p. Recomputed in backward.
+__device__ __forceinline__ float dropout_scale(unsigned long long seed, int sample, int col, int e,
+                                               float p, float inv_keep) {
+  unsigned long long z = seed + 0x9E3779B97F4A7C15ull *
+                                    ((((unsigned long long)(unsigned)sample << 20) ^
+                                      ((unsigned long long)(unsigned)col << 10)) *
+                                         1000003ull +
+                                     (unsigned long long)(unsigned)e + 1ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  const float u = (float)(z >> 40) * (1.0f / 16777216.0f);
+  return u >= p ? inv_keep : 0.f;
+}
+
+// ---- row bookkeeping, built on device from kernel arguments (no H2D copy, no sync) -------
+// row r of step t (rows of a step are contiguous, sample j at offset j):
+//   row_sample = j, prev_row = row of the same sample at step t-1 (or -1), row_token = -1,
+//   row_col: >= 0  caption column, dropout applies        (teacher forced, model.py:182)
+//            -1    image feature                           (step 0 with features, model.py:171)
+//            -2    token predicted from h_{t-1}, no dropout (model.py:184,190-191)
+//            <= -3 caption column (-3 - col), no dropout   (t = 0 free-running: captions[:,0])
+__global__ __launch_bounds__(256) void build_rows_kernel(SeqMeta m, int* __restrict__ row_sample,
+                                                         int* __restrict__ row_col,
+                                                         int* __restrict__ row_token,
+                                                         int* __restrict__ prev_row) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= m.N) return;
+  int t = 0;
+  while (t + 1 < m.steps && r >= m.off[t + 1]) ++t;
+  const int j = r - m.off[t];
+  row_sample[r] = j;
+  row_token[r] = -1;
+  prev_row[r] = t > 0 ? m.off[t - 1] + j : -1;
+  int col;
+  if (m.tf[t]) col = m.has_features ? (t == 0 ? -1 : t - 1) : t;
+  else col = (t == 0) ? -3 : -2;
+  row_col[r] = col;
+}
+
+int build_rows(const SeqMeta& m, int* row_sample, int* row_col, int* row_token, int* prev_row,
+               hipStream_t stream) {
+  hipLaunchKernelGGL(build_rows_kernel, dim3(cdiv(m.N, 256)), dim3(256), 0, stream, m, row_sample,
+                     row_col, row_token, prev_row);
+  CAPNET_LAUNCH_CHECK();
+  return kOk;
+}
+
+// ---- build decoder inputs -------------------------------------------------------------
+// X[r] = feature[sample] or emb[token] (* dropout mask). dynamic = 0: every row whose input is
+// known before the recurrence starts; dynamic = 1: rows whose token was just predicted.
+__global__ __launch_bounds__(128) void gather_inputs_kernel(
+    const long long* __restrict__ captions, int T, const float* __restrict__ features,
+    const float* __restrict__ emb, int E, int V, const int* __restrict__ row_sample,
+    const int* __restrict__ row_col, int* __restrict__ row_token, float* __restrict__ X, int r0,
+    int r1, float p, unsigned long long seed, int use_dropout, int dynamic,
+    int* __restrict__ err_flag) {
+  const int r = r0 + blockIdx.x;
+  if (r >= r1) return;
+  const int sample = row_sample[r];
+  const int col = row_col[r];
+  if ((col == -2) != (dynamic != 0)) return;
+  const float* src;
+  bool drop = false;
+  if (col == -1) {
+    src = features + (long)sample * E;
+  } else {
+    int tok;
+    if (col == -2) {
+      tok = row_token[r];
+    } else {
+      const int cc = col >= 0 ? col : -3 - col;
+      tok = (int)captions[(long)sample * T + cc];
+      if (threadIdx.x == 0) row_token[r] = tok;
+      drop = (col >= 0) && use_dropout != 0;
+    }
+    if (tok < 0 || tok >= V) {  // out-of-range token id: flag it, read row 0 (never fault)
+      if (threadIdx.x == 0) atomicExch(err_flag, 1);
+      tok = 0;
+    }
+    src = emb + (long)tok * E;
+  }
+  const float inv_keep = p < 1.f ? 1.f / (1.f - p) : 0.f;
+  for (int e = threadIdx.x; e < E; e += blockDim.x) {
+    float v = src[e];
+    if (drop) v *= dropout_scale(seed, sample, col, e, p, inv_keep);
+    X[(long)r * E + e] = v;
+  }
+}
+
+int gather_inputs(const long long* captions, int T, const float* features, const float* emb, int E,
+                  int V, const int* row_sample, const int* row_col, int* row_token, float* X,
+                  int r0, int r1, float p, unsigned long long seed, int use_dropout, int dynamic,
+                  int* err_flag, hipStream_t stream) {
+  if (r1 <= r0) return kOk;
+  hipLaunchKernelGGL(gather_inputs_kernel, dim3(r1 - r0), dim3(128), 0, stream, captions, T,
+                     features, emb, E, V, row_sample, row_col, row_token, X, r0, r1, p, seed,
+                     use_dropout, dynamic, err_flag);
+  CAPNET_LAUNCH_CHECK();
+  return kOk;
+}
+
+// out = a + b
+__global__ void vec_add_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                               float* __restrict__ out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = a[i] + b[i];
+}
+
+int vec_add(const float* a, const float* b, float* out, int n, hipStream_t stream) {
+  CAPNET_REQUIRE(a && b && out && n > 0, "vec_add: bad argument");
+  hipLaunchKernelGGL(vec_add_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, a, b, out, n);
+  CAPNET_LAUNCH_CHECK();
+  return kOk;
+}
+
+// ---- LSTM gate pointwise ---------------------------------------------------------------
+// pre: [b][4H] pre-activations, column block gi/gf/go/gg selects the gate. In place:
+// pre is overwritten with the ACTIVATED gates (saved for backward).
+// tanh_out = 0: h = o*c            (FactoredLSTM, stylenet/model.py:152-153)
+// tanh_out = 1: h = o*tanh(c)      (nn.LSTMCell, nic/model.py:77)
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+__global__ __launch_bounds__(256) void lstm_pointwise_fwd_kernel(
+    float* __restrict__ pre, const float* __restrict__ c_prev, float* __restrict__ c_out,
+    float* __restrict__ h_out, int b, int H, int gi, int gf, int go, int gg, int tanh_out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= b * H) return;
+  const int row = idx / H, j = idx - row * H;
+  float* p = pre + (long)row * 4 * H;
+  const float i = sigmoidf_(p[gi * H + j]);
+  const float f = sigmoidf_(p[gf * H + j]);
+  const float o = sigmoidf_(p[go * H + j]);
+  const float g = tanhf(p[gg * H + j]);
+  const float cp = c_prev ? c_prev[(long)row * H + j] : 0.f;
+  const float c = f * cp + i * g;
+  p[gi * H + j] = i;
+  p[gf * H + j] = f;
+  p[go * H + j] = o;
+  p[gg * H + j] = g;
+  c_out[(long)row * H + j] = c;
+  h_out[(long)row * H + j] = tanh_out ? o * tanhf(c) : o * c;
+}
+
+int lstm_pointwise_fwd(float* pre, const float* c_prev, float* c_out, float* h_out, int b, int H,
+                       int gi, int gf, int go, int gg, int tanh_out, hipStream_t stream) {
+  if (b <= 0) return kOk;
+  hipLaunchKernelGGL(lstm_pointwise_fwd_kernel, dim3(cdiv((long)b * H, 256)), dim3(256), 0, stream,
+                     pre, c_prev, c_out, h_out, b, H, gi, gf, go, gg, tanh_out);
+  CAPNET_LAUNCH_CHECK();
+  return kOk;
+}
+
+// gates: activated [b][4H]; dh = dH_out[row] + dh_rec[row] (dh_rec rows < b_next only);
+// dc_io: in = dL/dc_t from step t+1 (rows < b_next, else 0), out = dL/dc_{t-1}.
+// dpre: [b][4H] gradient wrt pre-activations.
+__global__ __launch_bounds__(256) void lstm_pointwise_bwd_kernel(
+    const float* __restrict__ gates, const float* __restrict__ c, const float* __restrict__ c_prev,
+    const float* __restrict__ dH, const float* __restrict__ dh_rec, float* __restrict__ dc_io,
+    float* __restrict__ dpre, int b, int b_next, int H, int gi, int gf, int go, int gg,
+    int tanh_out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= b * H) return;
+  const int row = idx / H, j = idx - row * H;
+  const float* p = gates + (long)row * 4 * H;
+  const float i = p[gi * H + j], f = p[gf * H + j], o = p[go * H + j], g = p[gg * H + j];
+  const float ct = c[(long)row * H + j];
+  const float cp = c_prev ? c_prev[(long)row * H + j] : 0.f;
+  float dh = dH[(long)row * H + j];
+  float dc = 0.f;
+  if (row < b_next) {
+    dh += dh_rec[(long)row * H + j];
+    dc = dc_io[(long)row * H + j];
+  }
+  float d_o;
+  if (tanh_out) {
+    const float tc = tanhf(ct);
+    d_o = dh * tc;
+    dc += dh * o * (1.f - tc * tc);
+  } else {
+    d_o = dh * ct;
+    dc += dh * o;
+  }
+  const float di = dc * g, dg = dc * i, df = dc * cp;
+  float* q = dpre + (long)row * 4 * H;
+  q[gi * H + j] = di * i * (1.f - i);
+  q[gf * H + j] = df * f * (1.f - f);
+  q[go * H + j] = d_o * o * (1.f - o);
+  q[gg * H + j] = dg * (1.f - g * g);
+  dc_io[(long)row * H + j] = dc * f;
+}
+
+int lstm_pointwise_bwd(const float* gates, const float* c, const float* c_prev, const float* dH,
+                       const float* dh_rec, float* dc_io, float* dpre, int b, int b_next, int H,
+                       int gi, int gf, int go, int gg, int tanh_out, hipStream_t stream) {
+  if (b <= 0) return kOk;
+  hipLaunchKernelGGL(lstm_pointwise_bwd_kernel, dim3(cdiv((long)b * H, 256)), dim3(256), 0, stream,
+                     gates, c, c_prev, dH, dh_rec, dc_io, dpre, b, b_next, H, gi, gf, go, gg,
+                     tanh_out);
+  CAPNET_LAUNCH_CHECK();
+  return kOk;
+}
+
+// ---- row argmax (first maximum, like torch.max(1) on CPU) --------------------------------
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restrict__ x, int ld,
+                                                          int V, int* __restrict__ out) {
+  const int row = blockIdx.x;
+  const float* p = x + (long)row * ld;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int j = threadIdx.x; j < V; j += blockDim.x) {
+    const float v = p[j];
+    if (v > best || (v == best && j < bi)) { best = v; bi = j; }
+  }
+  __shared__ float s_v[256];
+  __shared__ int s_i[256];
+  s_v[threadIdx.x] = best;
+  s_i[threadIdx.x] = bi;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) {
+      const float v = s_v[threadIdx.x + s];
+      const int i2 = s_i[threadIdx.x + s];
+      if (v > s_v[threadIdx.x] || (v == s_v[threadIdx.x] && i2 < s_i[threadIdx.x])) {
+        s_v[threadIdx.x] = v;
+        s_i[threadIdx.x] = i2;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[row] = s_i[0] == 0x7fffffff ? 0 : s_i[0];
+}
+
+int argmax_rows(const float* x, int rows, int ld, int V, int* out, hipStream_t stream) {
+  if (rows <= 0) return kOk;
+  hipLaunchKernelGGL(argmax_rows_kernel, dim3(rows), dim3(256), 0, stream, x, ld, V, out);
+  CAPNET_LAUNCH_CHECK();
+  return kOk;
+}
+
+// ---- out[r] = idx[r] >= 0 ? src[idx[r]] : 0  (rows of width C) ----------------------------
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src,
+                                                          const int* __restrict__ idx,
+                                                          float* __restrict__ out, int rows,
+                                                          int C) {
+  const long total = (long)rows * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / C), c = (int)(i - (long)r * C);
+    const int s = idx[r];
+    out[i] = s >= 0 ? src[(long)s * C + c] : 0.f;
+  }
+}
+
+int gather_rows(const float* src, const int* idx, float* out, int rows, int C,
+                hipStream_t stream) {
+  if (rows <= 0) return kOk;
+  const long total = (long)rows * C;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((int)(cdiv(total, 256) > 4096 ? 4096 : cdiv(total, 256))),
+                     dim3(256), 0, stream, src, idx, out, rows, C);
+  CAPNET_LAUNCH_CHECK();
+  return kOk;
+}
+
+// ---- column sums: out[c] (+)= sum_r x[r][c] ------------------------------------------------
+// one workgroup per 64 columns, 4 row lanes; fixed summation order (deterministic).
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, long ld, int rows,
+                                                     int C, float* __restrict__ out,
+                                                     int accumulate) {
+  __shared__ float s[4][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cx;
+  float acc = 0.f;
+  if (c < C)
+    for (int r = ry; r < rows; r += 4) acc += x[(long)r * ld + c];
+  s[ry][cx] = acc;
+  __syncthreads();
+  if (ry == 0 && c < C) {
+    const float t = s[0][cx] + s[1][cx] + s[2][cx] + s[3][cx];
+    out[c] = accumulate ? out[c] + t : t;
+  }
+}
+
+int colsum(const float* x, long ld, int rows, int C, float* out, int accumulate,
+           hipStream_t stream) {
+  CAPNET_REQUIRE(x && out && C > 0 && rows >= 0, "colsum: bad argument");
+  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(C, 64)), dim3(256), 0, stream, x, ld, rows, C, out,
+                     accumulate);
+  CAPNET_LAUNCH_CHECK();
+  return kOk;
+}
+
+// ---- embedding / feature gradient scatter --------------------------------------------------
+// dX [N][E] -> dEmb[token] (atomic, tokens repeat) or dFeat[sample] (one row per sample).
+__global__ __launch_bounds__(128) void scatter_input_grad_kernel(
+    const float* __restrict__ dX, int E, const int* __restrict__ row_sample,
+    const int* __restrict__ row_col, const int* __restrict__ row_token, float* __restrict__ dEmb,
+    float* __restrict__ dFeat, int V, float p, unsigned long long seed, int use_dropout) {
+  const int r = blockIdx.x;
+  const int sample = row_sample[r];
+  const int col = row_col[r];
+  const float inv_keep = p < 1.f ? 1.f / (1.f - p) : 0.f;
+  if (col == -1) {
+    if (dFeat)
+      for (int e = threadIdx.x; e < E; e += blockDim.x)
+        dFeat[(long)sample * E + e] = dX[(long)r * E + e];
+    return;
+  }
+  int tok = row_token[r];
+  if (tok < 0 || tok >= V) return;
+  const bool drop = (col >= 0) && use_dropout;
+  for (int e = threadIdx.x; e < E; e += blockDim.x) {
+    float g = dX[(long)r * E + e];
+    if (drop) g *= dropout_scale(seed, sample, col, e, p, inv_keep);
+    atomicAdd(dEmb + (long)tok * E + e, g);
+  }
+}
+
+int scatter_input_grad(const float* dX, int N, int E, const int* row_sample, const int* row_col,
+                       const int* row_token, float* dEmb, float* dFeat, int V, float p,
+                       unsigned long long seed, int use_dropout, hipStream_t stream) {
+  if (N <= 0) return kOk;
+  hipLaunchKernelGGL(scatter_input_grad_kernel, dim3(N), dim3(128), 0, stream, dX, E, row_sample,
+                     row_col, row_token, dEmb, dFeat, V, p, seed, use_dropout);
+  CAPNET_LAUNCH_CHECK();
+  return kOk;
+}
+
+}  // namespace capnet

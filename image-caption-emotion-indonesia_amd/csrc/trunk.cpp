@@ -1,0 +1,243 @@
+// ResNet-152 trunk plan + forward driver (the frozen image encoder of the captioning step).
+//
+// Restates torchvision 0.2.2 `resnet152` children[:-1] / [:-2] as called from
+// stylenet/model.py:15-18,24 and stylenet/model_att.py:15-18,24:
+//   conv1 7x7/2 p3 -> BN -> ReLU -> MaxPool 3x3/2 p1 -> layer1..4 = Bottleneck x [3,8,36,3]
+//   (planes 64/128/256/512, expansion 4, 1x1 -> 3x3 (stride here) -> 1x1, 1x1(stride)+BN
+//   downsample on the first block of each layer) -> AvgPool 7.
+// The reference runs it under torch.no_grad() but in train mode, so every BN uses batch
+// statistics and updates its running stats; nothing is saved for backward.
+//
+// Data flow per bottleneck (NHWC fp32, each conv output written once / read once):
+//   X --conv1--> Y1 raw (+stats) --[bn1+relu on load] conv2--> Y2 raw (+stats)
+//     --[bn2+relu on load] conv3--> Y3 raw (+stats);  [X --convD--> D raw (+stats)]
+//   OUT = relu(bn3(Y3) + (bnD(D) | X))         (bn_add_relu)
+#include <vector>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace capnet {
+
+struct TrunkConv {
+  int Cin, Cout, k, stride, pad;
+  int H, W;    // input spatial size
+  int OH, OW;  // output spatial size
+  int Kw;      // packed weight row stride
+};
+
+struct Trunk {
+  int B, H, W;
+  std::vector<TrunkConv> convs;  // torchvision parameter order
+  // workspace layout (float offsets)
+  size_t off_x[2], off_y1, off_y2, off_y3, off_d, off_part, off_ss, total_floats;
+  std::vector<size_t> ss_off;  // per conv: offset of [scale | shift] (2*Cout floats)
+  int final_side;
+};
+
+static int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+int trunk_create(int B, int H, int W, Trunk** out) {
+  CAPNET_REQUIRE(out != nullptr, "trunk_create: null out");
+  CAPNET_REQUIRE(B > 0 && H >= 32 && W >= 32 && H % 32 == 0 && W % 32 == 0,
+                 "trunk_create: batch %d image %dx%d (sides must be multiples of 32)", B, H, W);
+  Trunk* t = new Trunk();
+  t->B = B; t->H = H; t->W = W;
+  auto add = [&](int cin, int cout, int k, int stride, int pad, int h, int w) {
+    TrunkConv c;
+    c.Cin = cin; c.Cout = cout; c.k = k; c.stride = stride; c.pad = pad; c.H = h; c.W = w;
+    c.OH = (h + 2 * pad - k) / stride + 1;
+    c.OW = (w + 2 * pad - k) / stride + 1;
+    c.Kw = round_up(k * k * cin, 16);
+    t->convs.push_back(c);
+    return c;
+  };
+  TrunkConv stem = add(3, 64, 7, 2, 3, H, W);
+  int h = (stem.OH + 2 - 3) / 2 + 1, w = (stem.OW + 2 - 3) / 2 + 1;  // maxpool
+  int inplanes = 64;
+  const int blocks[4] = {3, 8, 36, 3};
+  const int planes[4] = {64, 128, 256, 512};
+  size_t max_x = (size_t)h * w * 64, max_y1 = 0, max_y2 = 0, max_y3 = 0, max_d = 0;
+  for (int L = 0; L < 4; ++L) {
+    for (int b = 0; b < blocks[L]; ++b) {
+      const int stride = (b == 0 && L > 0) ? 2 : 1;
+      const int p = planes[L];
+      TrunkConv c1 = add(inplanes, p, 1, 1, 0, h, w);
+      TrunkConv c2 = add(p, p, 3, stride, 1, h, w);
+      TrunkConv c3 = add(p, p * 4, 1, 1, 0, c2.OH, c2.OW);
+      max_y1 = std::max(max_y1, (size_t)c1.OH * c1.OW * c1.Cout);
+      max_y2 = std::max(max_y2, (size_t)c2.OH * c2.OW * c2.Cout);
+      max_y3 = std::max(max_y3, (size_t)c3.OH * c3.OW * c3.Cout);
+      if (b == 0) {
+        TrunkConv d = add(inplanes, p * 4, 1, stride, 0, h, w);
+        max_d = std::max(max_d, (size_t)d.OH * d.OW * d.Cout);
+      }
+      h = c2.OH; w = c2.OW;
+      inplanes = p * 4;
+      max_x = std::max(max_x, (size_t)h * w * inplanes);
+    }
+  }
+  t->final_side = h;
+  CAPNET_REQUIRE(h == w, "trunk_create: only square feature maps are supported");
+  // stem raw output shares the Y3 buffer
+  max_y3 = std::max(max_y3, (size_t)stem.OH * stem.OW * 64);
+  size_t off = 0;
+  auto take = [&](size_t n) { size_t o = off; off += (n + 63) / 64 * 64; return o; };
+  t->off_x[0] = take(max_x * B);
+  t->off_x[1] = take(max_x * B);
+  t->off_y1 = take(max_y1 * B);
+  t->off_y2 = take(max_y2 * B);
+  t->off_y3 = take(max_y3 * B);
+  t->off_d = take(max_d * B);
+  size_t max_part = 0;
+  for (auto& c : t->convs) {
+    const long M = (long)B * c.OH * c.OW;
+    const int tile = conv_auto_tile((int)M, c.Cout);
+    max_part = std::max(max_part, (size_t)conv_tiles_m((int)M, tile) * c.Cout);
+  }
+  t->off_part = take(2 * max_part);
+  t->off_ss = off;
+  for (auto& c : t->convs) t->ss_off.push_back(take(2 * (size_t)c.Cout));
+  t->total_floats = off;
+  *out = t;
+  return kOk;
+}
+
+void trunk_destroy(Trunk* t) { delete t; }
+size_t trunk_workspace_bytes(const Trunk* t) { return t->total_floats * sizeof(float); }
+int trunk_num_convs(const Trunk* t) { return (int)t->convs.size(); }
+int trunk_final_side(const Trunk* t) { return t->final_side; }
+
+int trunk_conv_shape(const Trunk* t, int i, int* cout, int* cin, int* k, int* stride, int* kw) {
+  CAPNET_REQUIRE(i >= 0 && i < (int)t->convs.size(), "trunk_conv_shape: index %d", i);
+  const TrunkConv& c = t->convs[i];
+  *cout = c.Cout; *cin = c.Cin; *k = c.k; *stride = c.stride; *kw = c.Kw;
+  return kOk;
+}
+
+double trunk_flops(const Trunk* t) {
+  double f = 0;
+  for (auto& c : t->convs)
+    f += 2.0 * t->B * c.OH * c.OW * (double)c.Cout * c.k * c.k * c.Cin;
+  return f;
+}
+
+namespace {
+struct Ctx {
+  const Trunk* t;
+  const float* const* w;
+  const float* const* gamma;
+  const float* const* beta;
+  float* const* rmean;
+  float* const* rvar;
+  int train;
+  float momentum, eps;
+  float* ws;
+  hipStream_t s;
+  float* scale(int i) const { return ws + t->ss_off[i]; }
+  float* shift(int i) const { return ws + t->ss_off[i] + t->convs[i].Cout; }
+};
+
+// conv i + the (scale, shift) of the BatchNorm that follows it
+int conv_bn(const Ctx& c, int i, const float* x, long sxb, long sxh, long sxw, long sxc,
+            const float* in_scale, const float* in_shift, int relu_in, float* y) {
+  const TrunkConv& d = c.t->convs[i];
+  const long M = (long)c.t->B * d.OH * d.OW;
+  const int tile = conv_auto_tile((int)M, d.Cout);
+  float* psum = c.ws + c.t->off_part;
+  float* psq = psum + (size_t)conv_tiles_m((int)M, tile) * d.Cout;
+  int rc = conv2d_fwd(x, sxb, sxh, sxw, sxc, c.w[i], d.Kw, y, in_scale, in_shift, relu_in,
+                      c.train ? psum : nullptr, c.train ? psq : nullptr, c.t->B, d.H, d.W, d.Cin,
+                      d.Cout, d.k, d.k, d.stride, d.pad, tile, c.s);
+  if (rc) return rc;
+  if (c.train)
+    return bn_finalize(psum, psq, conv_tiles_m((int)M, tile), d.Cout, M, c.gamma[i], c.beta[i],
+                       c.rmean[i], c.rvar[i], c.momentum, c.eps, c.scale(i), c.shift(i), c.s);
+  return bn_eval_scale_shift(c.gamma[i], c.beta[i], c.rmean[i], c.rvar[i], c.eps, d.Cout,
+                             c.scale(i), c.shift(i), c.s);
+}
+}  // namespace
+
+int trunk_forward(const Trunk* t, const float* images_nchw, const float* const* w_packed,
+                  const float* const* bn_gamma, const float* const* bn_beta,
+                  float* const* bn_rmean, float* const* bn_rvar, int train, float momentum,
+                  float eps, float* workspace, float* out_pooled, float* out_map,
+                  hipStream_t stream) {
+  CAPNET_REQUIRE(t && images_nchw && w_packed && bn_gamma && bn_beta && bn_rmean && bn_rvar &&
+                     workspace,
+                 "trunk_forward: null argument");
+  CAPNET_REQUIRE(out_pooled || out_map, "trunk_forward: no output requested");
+  CAPNET_REQUIRE(aligned16(workspace), "trunk_forward: workspace must be 16-B aligned");
+  Ctx c{t, w_packed, bn_gamma, bn_beta, bn_rmean, bn_rvar, train, momentum, eps, workspace, stream};
+  const int B = t->B;
+  float* X[2] = {workspace + t->off_x[0], workspace + t->off_x[1]};
+  float* Y1 = workspace + t->off_y1;
+  float* Y2 = workspace + t->off_y2;
+  float* Y3 = workspace + t->off_y3;
+  float* D = workspace + t->off_d;
+  int rc;
+  int ci = 0;
+  // stem: NCHW image read through the generic gather loader
+  {
+    const TrunkConv& d = t->convs[0];
+    rc = conv_bn(c, 0, images_nchw, (long)3 * d.H * d.W, d.W, 1, (long)d.H * d.W, nullptr,
+                 nullptr, 0, Y3);
+    if (rc) return rc;
+    rc = bn_relu_maxpool(Y3, c.scale(0), c.shift(0), X[0], B, d.OH, d.OW, 64, stream);
+    if (rc) return rc;
+    ci = 1;
+  }
+  int cur = 0;
+  const int blocks[4] = {3, 8, 36, 3};
+  for (int L = 0; L < 4; ++L) {
+    for (int b = 0; b < blocks[L]; ++b) {
+      const int i1 = ci, i2 = ci + 1, i3 = ci + 2;
+      const int id = (b == 0) ? ci + 3 : -1;
+      ci += (b == 0) ? 4 : 3;
+      const TrunkConv& c1 = t->convs[i1];
+      const TrunkConv& c2 = t->convs[i2];
+      const TrunkConv& c3 = t->convs[i3];
+      const float* x = X[cur];
+      float* out = X[cur ^ 1];
+      auto nhwc = [](const TrunkConv& d, long* sb, long* sh, long* sw) {
+        *sw = d.Cin; *sh = (long)d.W * d.Cin; *sb = (long)d.H * d.W * d.Cin;
+      };
+      long sb, sh, sw;
+      nhwc(c1, &sb, &sh, &sw);
+      rc = conv_bn(c, i1, x, sb, sh, sw, 1, nullptr, nullptr, 0, Y1);
+      if (rc) return rc;
+      nhwc(c2, &sb, &sh, &sw);
+      rc = conv_bn(c, i2, Y1, sb, sh, sw, 1, c.scale(i1), c.shift(i1), 1, Y2);
+      if (rc) return rc;
+      nhwc(c3, &sb, &sh, &sw);
+      rc = conv_bn(c, i3, Y2, sb, sh, sw, 1, c.scale(i2), c.shift(i2), 1, Y3);
+      if (rc) return rc;
+      const long rows = (long)B * c3.OH * c3.OW;
+      if (id >= 0) {
+        const TrunkConv& cd = t->convs[id];
+        nhwc(cd, &sb, &sh, &sw);
+        rc = conv_bn(c, id, x, sb, sh, sw, 1, nullptr, nullptr, 0, D);
+        if (rc) return rc;
+        rc = bn_add_relu(Y3, c.scale(i3), c.shift(i3), D, c.scale(id), c.shift(id), out, rows,
+                         c3.Cout, stream);
+      } else {
+        rc = bn_add_relu(Y3, c.scale(i3), c.shift(i3), x, nullptr, nullptr, out, rows, c3.Cout,
+                         stream);
+      }
+      if (rc) return rc;
+      cur ^= 1;
+    }
+  }
+  const int side = t->final_side;
+  if (out_pooled) {
+    rc = global_avgpool(X[cur], out_pooled, B, side * side, 2048, stream);
+    if (rc) return rc;
+  }
+  if (out_map) {
+    CAPNET_HIP_CHECK(hipMemcpyAsync(out_map, X[cur], (size_t)B * side * side * 2048 * sizeof(float),
+                                    hipMemcpyDeviceToDevice, stream));
+  }
+  return kOk;
+}
+
+}  // namespace capnet

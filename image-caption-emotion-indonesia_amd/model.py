@@ -1,0 +1,369 @@
+"""StyleNet models on the MI355X kernels: EncoderCNN and DecoderFactoredLSTM.
+
+Mirrors the class surface of the reference's stylenet/model.py (constructor signatures,
+attribute names, state_dict keys, forward()/forward_step() semantics); all arithmetic runs in
+libcapnet_hip.so through capnet.ops. Differences from the reference are listed in DESIGN.md.
+"""
+import ctypes as C
+import math
+import random
+import sys
+
+import torch
+import torch.nn as nn
+
+from . import _lib, ops
+from ._lib import CapnetError, check, current_stream, ptr, ptr_array
+
+random.seed(0)  # stylenet/model.py:7
+device = torch.device('cuda' if torch.cuda.is_available() else 'cpu')  # stylenet/model.py:8
+
+
+# ---------------------------------------------------------------------------------------
+# parameter containers (same state_dict keys as torch.nn / torchvision modules; their
+# forward() goes through the HIP operators, never through a torch kernel)
+# ---------------------------------------------------------------------------------------
+class Linear(nn.Module):
+
+    def __init__(self, in_features, out_features, bias=True):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.weight = nn.Parameter(torch.empty(out_features, in_features))
+        self.bias = nn.Parameter(torch.empty(out_features)) if bias else None
+        bound = 1.0 / math.sqrt(in_features)
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if bias:
+            nn.init.uniform_(self.bias, -bound, bound)
+
+    def forward(self, x):
+        shape = x.shape
+        y = ops.linear(x.reshape(-1, shape[-1]), self.weight, self.bias)
+        return y.reshape(*shape[:-1], self.out_features)
+
+
+class Embedding(nn.Module):
+
+    def __init__(self, num_embeddings, embedding_dim):
+        super().__init__()
+        self.num_embeddings, self.embedding_dim = num_embeddings, embedding_dim
+        self.weight = nn.Parameter(torch.empty(num_embeddings, embedding_dim).normal_())
+
+    def forward(self, idx):
+        return ops.embedding(idx, self.weight)
+
+
+class Dropout(nn.Module):
+    """Holds p; the mask itself is generated inside the decoder kernels."""
+
+    def __init__(self, p):
+        super().__init__()
+        self.p = p
+
+
+class _Conv(nn.Module):
+    """Conv2d parameter container (weight [Cout, Cin, k, k], no bias)."""
+
+    def __init__(self, cin, cout, k, stride, pad):
+        super().__init__()
+        self.stride, self.pad = stride, pad
+        self.weight = nn.Parameter(torch.empty(cout, cin, k, k))
+        nn.init.kaiming_normal_(self.weight, mode='fan_out', nonlinearity='relu')
+
+
+class _BN2d(nn.Module):
+    """BatchNorm2d parameter/buffer container."""
+
+    def __init__(self, c, momentum=0.1, eps=1e-5):
+        super().__init__()
+        self.momentum, self.eps = momentum, eps
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+        self.register_buffer('running_mean', torch.zeros(c))
+        self.register_buffer('running_var', torch.ones(c))
+        self.register_buffer('num_batches_tracked', torch.tensor(0, dtype=torch.long))
+
+
+class _Marker(nn.Module):
+    """Parameter-less position holder (ReLU / MaxPool / AvgPool slots of the nn.Sequential)."""
+
+
+class _Bottleneck(nn.Module):
+
+    def __init__(self, inplanes, planes, stride, downsample):
+        super().__init__()
+        self.conv1 = _Conv(inplanes, planes, 1, 1, 0)
+        self.bn1 = _BN2d(planes)
+        self.conv2 = _Conv(planes, planes, 3, stride, 1)
+        self.bn2 = _BN2d(planes)
+        self.conv3 = _Conv(planes, planes * 4, 1, 1, 0)
+        self.bn3 = _BN2d(planes * 4)
+        self.relu = _Marker()
+        if downsample:
+            self.downsample = nn.Sequential(_Conv(inplanes, planes * 4, 1, stride, 0),
+                                            _BN2d(planes * 4))
+        else:
+            self.downsample = None
+
+
+def _resnet152_children(with_avgpool):
+    """torchvision resnet152 children[:-1] / [:-2] as parameter containers (same key names)."""
+    mods = [_Conv(3, 64, 7, 2, 3), _BN2d(64), _Marker(), _Marker()]
+    inplanes = 64
+    for li, (planes, blocks) in enumerate(zip((64, 128, 256, 512), (3, 8, 36, 3))):
+        layer = []
+        for b in range(blocks):
+            stride = 2 if (b == 0 and li > 0) else 1
+            layer.append(_Bottleneck(inplanes, planes, stride, downsample=(b == 0)))
+            inplanes = planes * 4
+        mods.append(nn.Sequential(*layer))
+    if with_avgpool:
+        mods.append(_Marker())
+    return nn.Sequential(*mods)
+
+
+class _TrunkRunner:
+    """Owns the C-side plan, workspace and packed weights of one ResNet-152 trunk."""
+
+    def __init__(self, resnet):
+        self.resnet = resnet
+        self.convs, self.bns = [], []
+        seq = list(resnet.children())
+        self.convs.append(seq[0]); self.bns.append(seq[1])
+        for layer in seq[4:8]:
+            for blk in layer.children():
+                self.convs += [blk.conv1, blk.conv2, blk.conv3]
+                self.bns += [blk.bn1, blk.bn2, blk.bn3]
+                if blk.downsample is not None:
+                    self.convs.append(blk.downsample[0]); self.bns.append(blk.downsample[1])
+        self.plans = {}
+        self.packed = None
+        self.packed_key = None
+
+    def _plan(self, b, h, w, dev):
+        key = (b, h, w, str(dev))
+        p = self.plans.get(key)
+        if p is None:
+            L = _lib.lib()
+            handle = C.c_void_p()
+            check(L.capnet_trunk_create(b, h, w, C.byref(handle)), "capnet_trunk_create")
+            n = L.capnet_trunk_num_convs(handle)
+            if n != len(self.convs):
+                raise CapnetError("trunk plan has %d convolutions, module has %d" % (n, len(self.convs)))
+            nbytes = L.capnet_trunk_workspace_bytes(handle)
+            ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+            p = {"handle": handle, "ws": ws, "side": L.capnet_trunk_final_side(handle),
+                 "flops": L.capnet_trunk_flops(handle)}
+            self.plans[key] = p
+        return p
+
+    def _pack(self, plan, dev):
+        key = (str(dev),) + tuple((c.weight.data_ptr(), c.weight._version) for c in self.convs)
+        if self.packed_key != key:
+            L = _lib.lib()
+            packed = []
+            vals = [C.c_int() for _ in range(5)]
+            for i, c in enumerate(self.convs):
+                check(L.capnet_trunk_conv_shape(plan["handle"], i, *[C.byref(v) for v in vals]))
+                cout, cin, k, stride, kw = [v.value for v in vals]
+                if tuple(c.weight.shape) != (cout, cin, k, k) or c.stride != stride:
+                    raise CapnetError("conv %d: module shape %s does not match the plan" %
+                                      (i, tuple(c.weight.shape)))
+                packed.append(ops.pack_conv_weight(c.weight.detach(), kw))
+            self.packed, self.packed_key = packed, key
+        return self.packed
+
+    def forward(self, images, train, want_pooled, want_map):
+        ops._need_cuda(images)
+        if images.dim() != 4 or images.shape[1] != 3:
+            raise CapnetError("images must be [B, 3, H, W]")
+        images = images.contiguous()
+        b, _, h, w = images.shape
+        dev = images.device
+        plan = self._plan(b, h, w, dev)
+        packed = self._pack(plan, dev)
+        side = plan["side"]
+        pooled = torch.empty((b, 2048), dtype=torch.float32, device=dev) if want_pooled else None
+        fmap = torch.empty((b, side, side, 2048), dtype=torch.float32, device=dev) if want_map else None
+        bn0 = self.bns[0]
+        check(_lib.lib().capnet_trunk_forward(
+            plan["handle"], ptr(images), ptr_array(packed),
+            ptr_array([bn.weight for bn in self.bns]), ptr_array([bn.bias for bn in self.bns]),
+            ptr_array([bn.running_mean for bn in self.bns]),
+            ptr_array([bn.running_var for bn in self.bns]), int(train), bn0.momentum, bn0.eps,
+            ptr(plan["ws"]), ptr(pooled), ptr(fmap), current_stream()), "capnet_trunk_forward")
+        if train:
+            torch._foreach_add_([bn.num_batches_tracked for bn in self.bns], 1)
+        return pooled, fmap
+
+
+class _BN1d(nn.Module):
+    """nn.BatchNorm1d(embed_size, momentum=0.01) of the encoder head."""
+
+    def __init__(self, c, momentum=0.1, eps=1e-5):
+        super().__init__()
+        self.momentum, self.eps = momentum, eps
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+        self.register_buffer('running_mean', torch.zeros(c))
+        self.register_buffer('running_var', torch.ones(c))
+        self.register_buffer('num_batches_tracked', torch.tensor(0, dtype=torch.long))
+
+    def forward(self, x):
+        y = ops.batch_norm1d(x, self.weight, self.bias, self.running_mean, self.running_var,
+                             self.training, self.momentum, self.eps)
+        if self.training:
+            self.num_batches_tracked += 1
+        return y
+
+
+class EncoderCNN(nn.Module):
+    """stylenet/model.py:11-27 (identical to nic/model.py:10-26).
+
+    The reference builds torchvision's resnet152(pretrained=True); neither torchvision nor its
+    weights exist offline, so the trunk starts from torchvision's own initialisation
+    (kaiming-normal fan_out convolutions, BN weight 1 / bias 0) and takes pretrained tensors
+    through load_state_dict (same keys: resnet.0.weight, resnet.4.0.conv1.weight, ...).
+    """
+
+    def __init__(self, embed_size):
+        super(EncoderCNN, self).__init__()
+        self.resnet = _resnet152_children(with_avgpool=True)
+        self.linear = Linear(2048, embed_size)
+        self.bn = _BN1d(embed_size, momentum=0.01)
+        self._runner = [None]  # not a submodule
+
+    def _trunk(self):
+        if self._runner[0] is None:
+            self._runner[0] = _TrunkRunner(self.resnet)
+        return self._runner[0]
+
+    def forward(self, images):
+        with torch.no_grad():
+            features, _ = self._trunk().forward(images, self.training, True, False)
+        features = features.reshape(features.size(0), -1)
+        features = self.bn(self.linear(features))
+        return features
+
+
+# ---------------------------------------------------------------------------------------
+# decoders
+# ---------------------------------------------------------------------------------------
+def _draw_tf_mask(n_steps, teacher_forcing_ratio):
+    """One random.random() draw per time step, in step order (stylenet/model.py:181)."""
+    return [random.random() < teacher_forcing_ratio for _ in range(n_steps)]
+
+
+def _dropout_seed(training, p):
+    if training and p > 0:
+        return int(torch.randint(0, 2 ** 62, (1,)).item())
+    return 0
+
+
+_MODES = ("factual", "happy", "sad", "angry")
+
+
+class DecoderFactoredLSTM(nn.Module):
+    """stylenet/model.py:30-294. `num_layers` is accepted and ignored, as in the reference."""
+
+    def __init__(self,
+                 embed_size,
+                 hidden_size,
+                 factored_size,
+                 vocab_size,
+                 num_layers,
+                 feature_size=2048,
+                 bias=True,
+                 dropout=0.22,
+                 max_seq_length=40):
+        super(DecoderFactoredLSTM, self).__init__()
+        if not bias:
+            raise CapnetError("DecoderFactoredLSTM: bias=False is not supported by the HIP path")
+        self.feature_size = feature_size
+        self.hidden_size = hidden_size
+        self.factored_size = factored_size
+        self.embed_size = embed_size
+        self.vocab_size = vocab_size
+        self.max_seq_length = max_seq_length
+
+        self.dropout = Dropout(dropout)
+        self.B = Embedding(vocab_size, embed_size)
+
+        # registration order follows stylenet/model.py:52-97 (state_dict order)
+        for g in "ifoc":
+            setattr(self, "U_" + g, Linear(factored_size, hidden_size, bias=bias))
+            setattr(self, "S_f" + g, Linear(factored_size, factored_size, bias=bias))
+            setattr(self, "V_" + g, Linear(embed_size, factored_size, bias=bias))
+            setattr(self, "W_" + g, Linear(hidden_size, hidden_size, bias=bias))
+        for emo in ("happy", "sad", "angry"):
+            for g in "ifoc":
+                setattr(self, "S_%s_%s" % (emo, g), Linear(factored_size, factored_size, bias=bias))
+        self.C = Linear(hidden_size, vocab_size, bias=bias)
+
+        self.reset_parameters()
+        self.init_weights()
+
+    def reset_parameters(self):
+        for p in self.parameters():
+            if p.data.ndimension() >= 2:
+                nn.init.xavier_uniform_(p.data)
+            else:
+                nn.init.zeros_(p.data)
+
+    def init_weights(self):
+        self.B.weight.data.uniform_(-0.1, 0.1)
+        self.C.bias.data.fill_(0)
+        self.C.weight.data.uniform_(-0.1, 0.1)
+
+    def _S(self, mode):
+        if mode == "factual":
+            return [getattr(self, "S_f" + g) for g in "ifoc"]
+        if mode in _MODES:
+            return [getattr(self, "S_%s_%s" % (mode, g)) for g in "ifoc"]
+        # the reference only writes this message and then silently skips S (model.py:144-145);
+        # here an unknown mode is an error.
+        sys.stderr.write("mode name wrong!")
+        raise ValueError("unknown mode %r (expected one of %s)" % (mode, ", ".join(_MODES)))
+
+    def _weights(self, mode):
+        V = [getattr(self, "V_" + g) for g in "ifoc"]
+        S = self._S(mode)
+        U = [getattr(self, "U_" + g) for g in "ifoc"]
+        W = [getattr(self, "W_" + g) for g in "ifoc"]
+        out = []
+        for grp in (V, S, U, W):
+            out += [m.weight for m in grp]
+            out += [m.bias for m in grp]
+        return out
+
+    def forward_step(self, embedded, states, mode):
+        h_t, c_t = states
+        V = [getattr(self, "V_" + g) for g in "ifoc"]
+        S = self._S(mode)
+        U = [getattr(self, "U_" + g) for g in "ifoc"]
+        W = [getattr(self, "W_" + g) for g in "ifoc"]
+        pre = torch.cat([U[k](S[k](V[k](embedded))) + W[k](h_t) for k in range(4)], 1)
+        h_t, c_t = ops.lstm_pointwise(pre, c_t, ops.CELL_FACTORED)
+        return h_t, (h_t, c_t)
+
+    def forward(self,
+                captions,
+                lengths,
+                features=None,
+                teacher_forcing_ratio=0.8,
+                mode='factual'):
+        batch_sizes = ops.batch_sizes_from_lengths(lengths)
+        weights = self._weights(mode)
+        cfg = {
+            "cell": ops.CELL_FACTORED,
+            "batch_sizes": batch_sizes,
+            "tf_mask": _draw_tf_mask(len(batch_sizes), teacher_forcing_ratio),
+            "hidden_size": self.hidden_size,
+            "factored_size": self.factored_size,
+            "dropout": self.dropout.p if self.training else 0.0,
+            "seed": _dropout_seed(self.training, self.dropout.p),
+            "training": self.training,
+        }
+        hiddens = ops.decoder_sequence(cfg, captions, features, self.B.weight, self.C.weight,
+                                       self.C.bias, weights)
+        outputs = self.C(hiddens)
+        return outputs

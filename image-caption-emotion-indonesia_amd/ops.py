@@ -1,0 +1,360 @@
+"""Host-side operators over the C ABI: plain wrappers and torch.autograd.Functions.
+
+PyTorch is plumbing here (device memory, streams, autograd bookkeeping). Every arithmetic
+step of the hot path is a HIP kernel in libcapnet_hip.so reached through ctypes; nothing in
+this file computes on the CPU or through a torch operator. Inputs must be CUDA fp32 tensors.
+"""
+import ctypes as C
+
+import torch
+from torch.autograd.function import once_differentiable
+
+from . import _lib
+from ._lib import CapnetError, check, current_stream, int_array, ptr, ptr_array
+
+CELL_FACTORED = 0
+CELL_LSTM = 1
+
+_err_flags = {}
+
+
+def _need_cuda(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise CapnetError("capnet operators run on the GPU only (got a %s tensor); there is "
+                              "no CPU fallback" % t.device)
+        if t.dtype not in (torch.float32, torch.int64, torch.int32):
+            raise CapnetError("unsupported dtype %s" % t.dtype)
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def err_flag(device):
+    """Per-device int32 flag set by kernels on out-of-range token ids / targets."""
+    key = torch.device(device).index or 0
+    f = _err_flags.get(key)
+    if f is None:
+        f = torch.zeros(1, dtype=torch.int32, device=device)
+        _err_flags[key] = f
+    return f
+
+
+def check_device_errors():
+    """Synchronising check of the device-side error flags (call where the loop already syncs)."""
+    for f in _err_flags.values():
+        v = int(f.item())
+        if v:
+            f.zero_()
+            raise CapnetError("device-side error flag %d: %s" %
+                              (v, {1: "token id out of range", 2: "target out of range"}.get(v, "?")))
+
+
+# ---------------------------------------------------------------------------------------
+# plain wrappers
+# ---------------------------------------------------------------------------------------
+def sgemm(A, B, transA=False, transB=False, bias=None, out=None, accumulate=False, force_tile=0):
+    """out[M,N] (+)= op(A) @ op(B) + bias, 2-D contiguous operands."""
+    _need_cuda(A, B, bias, out)
+    A, B = _c(A), _c(B)
+    M, K = (A.shape[1], A.shape[0]) if transA else (A.shape[0], A.shape[1])
+    if transB:
+        N, Kb = B.shape
+    else:
+        Kb, N = B.shape
+    if K != Kb:
+        raise CapnetError("sgemm: inner dimensions differ (%d vs %d)" % (K, Kb))
+    if out is None:
+        if accumulate:
+            raise CapnetError("sgemm: accumulate needs an output tensor")
+        out = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    if not out.is_contiguous() or tuple(out.shape) != (M, N):
+        raise CapnetError("sgemm: bad output tensor")
+    check(_lib.lib().capnet_sgemm(int(transA), int(transB), M, N, K, ptr(A), A.shape[1], ptr(B),
+                                  B.shape[1], ptr(out), N, ptr(bias), int(accumulate), 1, 0, 0, 0,
+                                  0, force_tile, current_stream()), "capnet_sgemm")
+    return out
+
+
+def colsum(x, out=None):
+    _need_cuda(x)
+    x = _c(x)
+    if out is None:
+        out = torch.empty(x.shape[1], dtype=torch.float32, device=x.device)
+    check(_lib.lib().capnet_colsum(ptr(x), x.shape[1], x.shape[0], x.shape[1], ptr(out), 0,
+                                   current_stream()), "capnet_colsum")
+    return out
+
+
+def argmax_rows(x):
+    _need_cuda(x)
+    x = _c(x)
+    out = torch.empty(x.shape[0], dtype=torch.int32, device=x.device)
+    check(_lib.lib().capnet_argmax_rows(ptr(x), x.shape[0], x.shape[1], x.shape[1], ptr(out),
+                                        current_stream()), "capnet_argmax_rows")
+    return out
+
+
+def pack_conv_weight(w_oihw, row_stride):
+    _need_cuda(w_oihw)
+    w = _c(w_oihw)
+    co, ci, kh, kw = w.shape
+    out = torch.empty((co, row_stride), dtype=torch.float32, device=w.device)
+    check(_lib.lib().capnet_pack_conv_weight(ptr(w), ptr(out), co, ci, kh, kw, row_stride,
+                                             current_stream()), "capnet_pack_conv_weight")
+    return out
+
+
+def clamp_adam(params, grads, exp_avg, exp_avg_sq, steps, lr, beta1, beta2, eps, clip,
+               write_grad=True):
+    """Fused element-wise clamp + Adam over a list of tensors (in place)."""
+    n = len(params)
+    if n == 0:
+        return
+    _need_cuda(*params, *grads, *exp_avg, *exp_avg_sq)
+    for p, g in zip(params, grads):
+        if not (p.is_contiguous() and g.is_contiguous()) or p.numel() != g.numel():
+            raise CapnetError("clamp_adam: parameters and gradients must be contiguous and equal-sized")
+    numel = (C.c_long * n)(*[p.numel() for p in params])
+    check(_lib.lib().capnet_clamp_adam(n, ptr_array(params), ptr_array(grads), ptr_array(exp_avg),
+                                       ptr_array(exp_avg_sq), numel, int_array(steps), lr, beta1,
+                                       beta2, eps, clip if clip else 0.0, int(write_grad),
+                                       current_stream()), "capnet_clamp_adam")
+
+
+# ---------------------------------------------------------------------------------------
+# autograd: nn.Linear
+# ---------------------------------------------------------------------------------------
+class LinearFn(torch.autograd.Function):
+    """y = x @ w.T + b   (x [M,K], w [N,K])."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        _need_cuda(x, w, b)
+        x, w = _c(x), _c(w)
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return sgemm(x, w, transB=True, bias=b)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = _c(dy)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = sgemm(dy, w)                      # [M,N] @ [N,K]
+        if ctx.needs_input_grad[1]:
+            dw = sgemm(dy, x, transA=True)         # dy^T [N,M] @ x [M,K]
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = colsum(dy)
+        return dx, dw, db
+
+
+def linear(x, w, b=None):
+    return LinearFn.apply(x, w, b)
+
+
+# ---------------------------------------------------------------------------------------
+# autograd: nn.CrossEntropyLoss (mean)
+# ---------------------------------------------------------------------------------------
+class CrossEntropyFn(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, logits, targets):
+        _need_cuda(logits, targets)
+        logits, targets = _c(logits), _c(targets)
+        if targets.dtype != torch.int64:
+            raise CapnetError("targets must be int64")
+        n, v = logits.shape
+        if targets.numel() != n:
+            raise CapnetError("cross entropy: %d logits rows vs %d targets" % (n, targets.numel()))
+        lse = torch.empty(n, dtype=torch.float32, device=logits.device)
+        row_loss = torch.empty(n, dtype=torch.float32, device=logits.device)
+        loss = torch.empty((), dtype=torch.float32, device=logits.device)
+        check(_lib.lib().capnet_xent_fwd(ptr(logits), v, n, v, ptr(targets), ptr(lse),
+                                         ptr(row_loss), ptr(loss), ptr(err_flag(logits.device)),
+                                         current_stream()), "capnet_xent_fwd")
+        ctx.save_for_backward(logits, targets, lse)
+        return loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        logits, targets, lse = ctx.saved_tensors
+        n, v = logits.shape
+        gout = _c(gout.to(torch.float32)).reshape(1)
+        dlogits = torch.empty_like(logits)
+        check(_lib.lib().capnet_xent_bwd(ptr(logits), v, n, v, ptr(targets), ptr(lse), ptr(gout),
+                                         ptr(dlogits), v, current_stream()), "capnet_xent_bwd")
+        return dlogits, None
+
+
+def cross_entropy(logits, targets):
+    return CrossEntropyFn.apply(logits, targets)
+
+
+# ---------------------------------------------------------------------------------------
+# autograd: nn.BatchNorm1d (encoder head)
+# ---------------------------------------------------------------------------------------
+class BatchNorm1dFn(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, train, momentum, eps):
+        _need_cuda(x, gamma, beta, running_mean, running_var)
+        x = _c(x)
+        b, c = x.shape
+        y = torch.empty_like(x)
+        mean = torch.empty(c, dtype=torch.float32, device=x.device)
+        invstd = torch.empty(c, dtype=torch.float32, device=x.device)
+        check(_lib.lib().capnet_bn1d_fwd(ptr(x), b, c, ptr(gamma), ptr(beta), ptr(running_mean),
+                                         ptr(running_var), int(train), momentum, eps, ptr(y),
+                                         ptr(mean), ptr(invstd), current_stream()),
+              "capnet_bn1d_fwd")
+        ctx.train = train
+        ctx.save_for_backward(x, gamma, mean, invstd)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        if not ctx.train:
+            raise CapnetError("BatchNorm1d backward is implemented for train mode only")
+        x, gamma, mean, invstd = ctx.saved_tensors
+        dy = _c(dy)
+        b, c = x.shape
+        dx = torch.empty_like(x)
+        dgamma = torch.empty_like(gamma)
+        dbeta = torch.empty_like(gamma)
+        check(_lib.lib().capnet_bn1d_bwd(ptr(dy), ptr(x), b, c, ptr(gamma), ptr(mean), ptr(invstd),
+                                         ptr(dx), ptr(dgamma), ptr(dbeta), current_stream()),
+              "capnet_bn1d_bwd")
+        return dx, dgamma, dbeta, None, None, None, None, None
+
+
+def batch_norm1d(x, gamma, beta, running_mean, running_var, train, momentum, eps):
+    return BatchNorm1dFn.apply(x, gamma, beta, running_mean, running_var, train, momentum, eps)
+
+
+# ---------------------------------------------------------------------------------------
+# autograd: whole-sequence decoder recurrence
+# ---------------------------------------------------------------------------------------
+def batch_sizes_from_lengths(lengths):
+    """pack_padded_sequence(..., lengths).batch_sizes for lengths sorted in decreasing order."""
+    lengths = [int(l) for l in lengths]
+    if not lengths or any(l <= 0 for l in lengths):
+        raise CapnetError("lengths must be positive")
+    if any(lengths[i] < lengths[i + 1] for i in range(len(lengths) - 1)):
+        raise CapnetError("lengths must be sorted in decreasing order (pack_padded_sequence contract)")
+    return [sum(1 for l in lengths if l > t) for t in range(lengths[0])]
+
+
+class DecoderSeqFn(torch.autograd.Function):
+    """hiddens[N,H] of the scheduled-sampling recurrence; one C call forward, one backward.
+
+    weights: cell 0 -> 32 tensors (V w x4, V b x4, S w x4, S b x4, U w x4, U b x4, W w x4, W b x4)
+             cell 1 -> (weight_ih, bias_ih, weight_hh, bias_hh)
+    """
+
+    @staticmethod
+    def forward(ctx, cfg, captions, features, emb, Cw, Cb, *weights):
+        cell = cfg["cell"]
+        _need_cuda(captions, features, emb, Cw, Cb, *weights)
+        captions = _c(captions)
+        if captions.dtype != torch.int64:
+            raise CapnetError("captions must be int64")
+        dev = emb.device
+        bs = cfg["batch_sizes"]
+        tf = cfg["tf_mask"]
+        B, T = captions.shape
+        V, E = emb.shape
+        H = cfg["hidden_size"]
+        F = cfg.get("factored_size", 0)
+        N = sum(bs)
+        if len(tf) != len(bs):
+            raise CapnetError("tf_mask has %d entries for %d steps" % (len(tf), len(bs)))
+        if bs[0] != B:
+            raise CapnetError("batch_sizes[0]=%d but captions has %d rows" % (bs[0], B))
+        dims = [B, T, len(bs), N, E, F, H, V, int(features is not None), cell]
+        ws = [_c(w) for w in weights]
+        if cell == CELL_FACTORED:
+            if len(ws) != 32:
+                raise CapnetError("factored cell takes 32 weight tensors")
+            wptrs = ws
+        else:
+            if len(ws) != 4:
+                raise CapnetError("LSTM cell takes 4 weight tensors")
+            wptrs = [None] * 32
+            wptrs[0], wptrs[4], wptrs[24], wptrs[28] = ws
+        if features is not None:
+            features = _c(features)
+            if tuple(features.shape) != (B, E):
+                raise CapnetError("features must be [batch, embed_size]")
+        emb_c, Cw_c, Cb_c = _c(emb), _c(Cw), _c(Cb)
+        cdims = int_array(dims)
+        L = _lib.lib()
+        saved = torch.empty(L.capnet_seq_saved_floats(cdims), dtype=torch.float32, device=dev)
+        saved_i = torch.empty(L.capnet_seq_saved_ints(cdims), dtype=torch.int32, device=dev)
+        scratch = torch.empty(L.capnet_seq_fwd_scratch_floats(cdims), dtype=torch.float32, device=dev)
+        hiddens = torch.empty((N, H), dtype=torch.float32, device=dev)
+        tfm = (C.c_ubyte * len(tf))(*[1 if x else 0 for x in tf])
+        check(L.capnet_seq_forward(cdims, int_array(bs), tfm, ptr(captions), ptr(features),
+                                   ptr(emb_c), ptr_array(wptrs), ptr(Cw_c), ptr(Cb_c),
+                                   float(cfg["dropout"]), int(cfg["seed"]), int(cfg["training"]),
+                                   ptr(saved), ptr(saved_i), ptr(scratch), ptr(hiddens),
+                                   ptr(err_flag(dev)), current_stream()), "capnet_seq_forward")
+        ctx.cfg = cfg
+        ctx.dims = dims
+        ctx.n_weights = len(ws)
+        ctx.has_features = features is not None
+        ctx.save_for_backward(saved, saved_i, hiddens)
+        return hiddens
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, d_hiddens):
+        saved, saved_i, hiddens = ctx.saved_tensors
+        cfg, dims = ctx.cfg, ctx.dims
+        B, T, steps, N, E, F, H, V, _, cell = dims
+        dev = saved.device
+        d_hiddens = _c(d_hiddens)
+        L = _lib.lib()
+        cdims = int_array(dims)
+        scratch = torch.empty(L.capnet_seq_bwd_scratch_floats(cdims), dtype=torch.float32, device=dev)
+
+        def new(*shape):
+            return torch.empty(shape, dtype=torch.float32, device=dev)
+
+        dEmb = new(V, E)
+        dFeat = new(B, E) if ctx.has_features else None
+        dW = new(4 * H, H)
+        dbUW = new(4 * H)
+        if cell == CELL_FACTORED:
+            dV, dbV, dS, dbS, dU = new(4 * F, E), new(4 * F), new(4, F, F), new(4 * F), new(4, H, F)
+        else:
+            dV, dbV, dS, dbS, dU = new(4 * H, E), None, None, None, None
+        grads = [dV, dbV, dS, dbS, dU, dbUW, dW, dEmb, dFeat]
+        check(L.capnet_seq_backward(cdims, int_array(cfg["batch_sizes"]), ptr(d_hiddens),
+                                    ptr(hiddens), ptr(saved), ptr(saved_i), ptr(scratch),
+                                    ptr_array(grads), float(cfg["dropout"]), int(cfg["seed"]),
+                                    int(cfg["training"]), current_stream()), "capnet_seq_backward")
+        if cell == CELL_FACTORED:
+            wg = ([dV[g * F:(g + 1) * F] for g in range(4)] +
+                  [dbV[g * F:(g + 1) * F] for g in range(4)] +
+                  [dS[g] for g in range(4)] +
+                  [dbS[g * F:(g + 1) * F] for g in range(4)] +
+                  [dU[g] for g in range(4)] +
+                  [dbUW[g * H:(g + 1) * H] for g in range(4)] +
+                  [dW[g * H:(g + 1) * H] for g in range(4)] +
+                  [dbUW[g * H:(g + 1) * H].clone() for g in range(4)])
+        else:
+            wg = [dV, dbUW, dW, dbUW.clone()]
+        # cfg, captions, features, emb, Cw, Cb, *weights
+        return (None, None, dFeat, dEmb, None, None) + tuple(wg)
+
+
+def decoder_sequence(cfg, captions, features, emb, Cw, Cb, weights):
+    return DecoderSeqFn.apply(cfg, captions, features, emb, Cw, Cb, *weights)

@@ -1,0 +1,176 @@
+/* capnet.h -- C ABI of libcapnet_hip.so: the MI355X (gfx950) training-step kernels of the
+ * StyleNet / NIC captioning path.
+ *
+ * The reference (deryrahman/image-caption-emotion-indonesia) has no native/FFI layer: its
+ * boundary is the Python class surface of stylenet/model.py, nic/model.py and the loops in
+ * stylenet/train_multitask.py. Each entry point below names the torch call(s) of the
+ * reference it replaces (file:line under /root/reference). The Python mirror of those classes
+ * binds these symbols through ctypes.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative status otherwise;
+ *     capnet_last_error() returns the message of the calling thread's last failure;
+ *   - all `float*` / `long long*` / `int*` data pointers are CALLER-OWNED DEVICE pointers
+ *     (tensor.data_ptr()); arrays documented as "host" are ordinary host memory;
+ *   - `stream` is a hipStream_t; nothing here allocates device memory, synchronises the
+ *     stream or touches the default stream, so every call can be captured in a hipGraph;
+ *   - arithmetic is fp32 with fp32 accumulation (v_mfma_f32_32x32x2_f32 == fmaf chain).
+ */
+#ifndef CAPNET_H_
+#define CAPNET_H_
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* capnet_stream_t; /* hipStream_t */
+typedef struct capnet_trunk capnet_trunk_t;
+
+#define CAPNET_OK 0
+#define CAPNET_ERR_INVALID_ARG (-1)
+#define CAPNET_ERR_HIP (-2)
+
+const char* capnet_last_error(void);
+int capnet_abi_version(void);
+
+/* ---- dense projections --------------------------------------------------------------
+ * C[M x N] (+)= op(A) . op(B) + bias[N], row-major, `batch` independent problems at the given
+ * element strides. transA=0: A is [M][K]; 1: [K][M]. transB=0: B is [K][N]; 1: [N][K].
+ * Replaces every nn.Linear forward and autograd matmul of the decoders and the encoder head:
+ * stylenet/model.py:119-150 (V/S/U/W gates), :189-194 (C), :19,26 (encoder.linear);
+ * nic/model.py:52,77,105-113. force_tile: 0 = auto, 64 or 128. */
+int capnet_sgemm(int transA, int transB, int M, int N, int K, const float* A, long lda,
+                 const float* B, long ldb, float* C, long ldc, const float* bias, int accumulate,
+                 int batch, long strideA, long strideB, long strideC, long strideBias,
+                 int force_tile, capnet_stream_t stream);
+
+/* out[c] (+)= sum_r x[r][c]  -- bias gradients (autograd of nn.Linear bias). */
+int capnet_colsum(const float* x, long ld, int rows, int C, float* out, int accumulate,
+                  capnet_stream_t stream);
+
+/* out[row] = index of the first maximum of x[row][0:V]  -- `output.max(1)` at
+ * stylenet/model.py:190, nic/model.py:109. */
+int capnet_argmax_rows(const float* x, int rows, int ld, int V, int* out, capnet_stream_t stream);
+
+/* ---- ResNet-152 trunk -------------------------------------------------------------------
+ * torchvision resnet152 children[:-1] (pooled [B][2048]) or [:-2] (NHWC map [B][S][S][2048]),
+ * as run under torch.no_grad() by EncoderCNN.forward: stylenet/model.py:15-18,23-25,
+ * stylenet/model_att.py:15-18,23-24, nic/model.py:14-17,22-24. train != 0 reproduces
+ * encoder.train() (stylenet/train_multitask.py:367): batch statistics + running-stat update
+ * (momentum 0.1, eps 1e-5); train == 0 uses the running statistics.
+ * Convolution i (torchvision parameter order, 155 of them) takes its weights PACKED as
+ * [Cout][KH][KW][Cin] rows padded to `row_stride` floats (capnet_pack_conv_weight). */
+int capnet_trunk_create(int batch, int height, int width, capnet_trunk_t** out);
+void capnet_trunk_destroy(capnet_trunk_t* t);
+size_t capnet_trunk_workspace_bytes(const capnet_trunk_t* t);
+int capnet_trunk_num_convs(const capnet_trunk_t* t);
+int capnet_trunk_final_side(const capnet_trunk_t* t);
+double capnet_trunk_flops(const capnet_trunk_t* t); /* 2*MACs of all convolutions, this batch */
+int capnet_trunk_conv_shape(const capnet_trunk_t* t, int i, int* cout, int* cin, int* ksize,
+                            int* stride, int* row_stride);
+/* w_packed / bn_* : HOST arrays of num_convs DEVICE pointers. out_pooled and/or out_map may
+ * be NULL (at least one must be given). */
+int capnet_trunk_forward(const capnet_trunk_t* t, const float* images_nchw,
+                         const float* const* w_packed, const float* const* bn_weight,
+                         const float* const* bn_bias, float* const* bn_running_mean,
+                         float* const* bn_running_var, int train, float momentum, float eps,
+                         void* workspace, float* out_pooled, float* out_map,
+                         capnet_stream_t stream);
+/* OIHW (torch Conv2d.weight) -> packed rows */
+int capnet_pack_conv_weight(const float* w_oihw, float* out, int Cout, int Cin, int KH, int KW,
+                            int row_stride, capnet_stream_t stream);
+/* nn.AdaptiveAvgPool2d(out_side) on an NHWC map whose side divides out_side (7 -> 14 is a
+ * 2x replication): stylenet/model_att.py:19-20,26-28. */
+int capnet_adaptive_pool_replicate(const float* x, float* out, int B, int side, int out_side,
+                                   int C, capnet_stream_t stream);
+
+/* single building blocks of the trunk, exported for the parity tests */
+int capnet_conv2d_fwd(const float* x, long sxb, long sxh, long sxw, long sxc,
+                      const float* w_packed, int row_stride, float* y, const float* in_scale,
+                      const float* in_shift, int relu_in, float* part_sum, float* part_sq, int B,
+                      int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                      int tile, capnet_stream_t stream);
+int capnet_conv_tiles_m(int M, int Cout, int tile);
+int capnet_bn_finalize(const float* part_sum, const float* part_sq, int tiles, int C, long count,
+                       const float* gamma, const float* beta, float* running_mean,
+                       float* running_var, float momentum, float eps, float* scale, float* shift,
+                       capnet_stream_t stream);
+int capnet_bn_add_relu(const float* y, const float* s1, const float* t1, const float* res,
+                       const float* s2, const float* t2, float* out, long rows, int C,
+                       capnet_stream_t stream);
+int capnet_bn_relu_maxpool(const float* y, const float* scale, const float* shift, float* out,
+                           int B, int H, int W, int C, capnet_stream_t stream);
+int capnet_global_avgpool(const float* x, float* out, int B, int HW, int C,
+                          capnet_stream_t stream);
+
+/* ---- encoder head: nn.BatchNorm1d(embed, momentum=0.01) -- stylenet/model.py:20,26 ------- */
+int capnet_bn1d_fwd(const float* x, int B, int C, const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, int train, float momentum, float eps,
+                    float* y, float* save_mean, float* save_invstd, capnet_stream_t stream);
+int capnet_bn1d_bwd(const float* dy, const float* x, int B, int C, const float* gamma,
+                    const float* save_mean, const float* save_invstd, float* dx, float* dgamma,
+                    float* dbeta, capnet_stream_t stream);
+
+/* ---- caption decoders: whole-sequence forward / BPTT ------------------------------------
+ * dims (host int[10]) = {B, T, steps, N, E, F, H, V, has_features, cell}
+ *   B batch, T caption columns, steps = max(lengths), N = sum(lengths) packed rows,
+ *   E embed, F factored (ignored for cell 1), H hidden, V vocab,
+ *   cell 0 = DecoderFactoredLSTM.forward  (stylenet/model.py:157-196, forward_step :115-155)
+ *   cell 1 = DecoderRNN.forward           (nic/model.py:81-115, nn.LSTMCell :52,77)
+ * batch_sizes (host int[steps]) = pack_padded_sequence(...).batch_sizes; tf_mask (host
+ * uint8[steps]) = the per-step `random.random() < teacher_forcing_ratio` draws (model.py:181).
+ * weights (host array of 32 device pointers):
+ *   cell 0: [0..3]=V_{i,f,o,c}.weight [F][E]  [4..7]=V bias  [8..11]=S_g.weight (mode-selected)
+ *           [12..15]=S bias  [16..19]=U_g.weight [H][F]  [20..23]=U bias
+ *           [24..27]=W_g.weight [H][H]  [28..31]=W bias
+ *   cell 1: [0]=lstm.weight_ih [4H][E]  [4]=lstm.bias_ih  [24]=lstm.weight_hh  [28]=lstm.bias_hh
+ * emb = B.weight / embed.weight [V][E]; Cw/Cb = output projection (only read on free-running
+ * steps, for the argmax feedback). hiddens [N][H] is the packed `torch.cat(hiddens, 0)`.
+ * saved / saved_i / scratch: caller-provided device buffers of the sizes queried below; saved
+ * buffers must reach the matching backward call untouched. err_flag: device int, set non-zero
+ * when a token id is out of range (the caller checks it when it next synchronises). */
+size_t capnet_seq_saved_floats(const int* dims);
+size_t capnet_seq_saved_ints(const int* dims);
+size_t capnet_seq_fwd_scratch_floats(const int* dims);
+size_t capnet_seq_bwd_scratch_floats(const int* dims);
+int capnet_seq_forward(const int* dims, const int* batch_sizes, const unsigned char* tf_mask,
+                       const long long* captions, const float* features, const float* emb,
+                       const float* const* weights, const float* Cw, const float* Cb,
+                       float dropout_p, unsigned long long seed, int training, float* saved,
+                       int* saved_i, float* scratch, float* hiddens, int* err_flag,
+                       capnet_stream_t stream);
+/* grads (host array of 9 device pointers, all written, not accumulated):
+ *   [0] dV  [4F][E] (cell 1: d weight_ih [4H][E])   [1] dV bias [4F]      (cell 1: unused)
+ *   [2] dS  [4][F][F] (mode-selected S)              [3] dS bias [4F]
+ *   [4] dU  [4][H][F]                                [5] dbias [4H] (U bias = W bias; cell 1:
+ *                                                        bias_ih = bias_hh)
+ *   [6] dW  [4H][H] (cell 1: d weight_hh)            [7] d emb [V][E]   [8] d features [B][E]|NULL
+ * Gate order inside the packed blocks: cell 0 i,f,o,c ; cell 1 i,f,g,o (nn.LSTMCell). */
+int capnet_seq_backward(const int* dims, const int* batch_sizes, const float* d_hiddens,
+                        const float* hiddens, const float* saved, const int* saved_i,
+                        float* scratch, float* const* grads, float dropout_p,
+                        unsigned long long seed, int training, capnet_stream_t stream);
+
+/* ---- loss: nn.CrossEntropyLoss() (mean) -- stylenet/train_multitask.py:134,383 ---------- */
+int capnet_xent_fwd(const float* logits, long ld, int N, int V, const long long* targets,
+                    float* lse, float* row_loss, float* loss, int* err_flag,
+                    capnet_stream_t stream);
+int capnet_xent_bwd(const float* logits, long ld, int N, int V, const long long* targets,
+                    const float* lse, const float* grad_out, float* dlogits, long ldd,
+                    capnet_stream_t stream);
+
+/* ---- optimiser: utils.clip_gradient (element-wise clamp, stylenet/utils.py:51-60) fused with
+ * torch.optim.Adam.step (stylenet/train_multitask.py:166-167,389; no weight decay, no amsgrad).
+ * Host arrays of n device pointers / sizes / per-tensor step counts (>= 1, already
+ * incremented). clip <= 0 disables the clamp; write_grad != 0 also stores the clamped grad. */
+int capnet_clamp_adam(int n, float* const* params, float* const* grads, float* const* exp_avg,
+                      float* const* exp_avg_sq, const long* numel, const int* step, float lr,
+                      float beta1, float beta2, float eps, float clip, int write_grad,
+                      capnet_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CAPNET_H_ */

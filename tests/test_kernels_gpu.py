@@ -1,0 +1,246 @@
+"""GPU parity of the individual HIP kernels against plain torch CPU references (fp64 where the
+op is a contraction). Everything goes through the C ABI (capnet._lib / capnet.ops)."""
+import ctypes as C
+
+import pytest
+import torch
+
+import capnet
+from capnet import ops
+from capnet._lib import check, current_stream, lib, ptr, ptr_array, int_array
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_err(a, b):
+    a = a.double().cpu()
+    b = b.double().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+@pytest.mark.parametrize("tile", [64, 128])
+@pytest.mark.parametrize("ta,tb", [(False, True), (False, False), (True, False), (True, True)])
+@pytest.mark.parametrize("M,N,K", [(64, 64, 32), (130, 70, 50), (257, 300, 301), (33, 2048, 512),
+                                   (1037, 512, 300)])
+def test_sgemm_layouts(dev, tile, ta, tb, M, N, K):
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    A = torch.randn((K, M) if ta else (M, K), generator=g)
+    B = torch.randn((N, K) if tb else (K, N), generator=g)
+    bias = torch.randn(N, generator=g)
+    ref = (A.double().t() if ta else A.double()) @ (B.double().t() if tb else B.double()) + bias.double()
+    out = ops.sgemm(A.to(dev), B.to(dev), transA=ta, transB=tb, bias=bias.to(dev), force_tile=tile)
+    assert rel_err(out, ref) < 2e-6
+    # asymmetric check of orientation: A = I picks rows of op(B)
+    acc = torch.ones((M, N), device=dev)
+    out2 = ops.sgemm(A.to(dev), B.to(dev), transA=ta, transB=tb, out=acc.clone(), accumulate=True,
+                     force_tile=tile)
+    assert rel_err(out2, ref - bias.double() + 1.0) < 2e-6
+
+
+def test_sgemm_batched_strided(dev):
+    # the gate-batched S/U products of the FactoredLSTM chain: 4 groups inside [n, 4F] buffers
+    n, F, H = 77, 48, 40
+    g = torch.Generator().manual_seed(5)
+    A1 = torch.randn(n, 4 * F, generator=g)
+    S = torch.randn(4, H, F, generator=g)
+    b = torch.randn(4 * H, generator=g)
+    out = torch.zeros(n, 4 * H, device=dev)
+    A1d, Sd, bd = A1.to(dev), S.to(dev), b.to(dev)
+    check(lib().capnet_sgemm(0, 1, n, H, F, ptr(A1d), 4 * F, ptr(Sd), F, ptr(out), 4 * H, ptr(bd),
+                             0, 4, F, H * F, H, H, 0, current_stream()))
+    ref = torch.cat([A1[:, k * F:(k + 1) * F].double() @ S[k].double().t() for k in range(4)], 1) + b.double()
+    assert rel_err(out, ref) < 2e-6
+
+
+def _conv_ref(x_nchw, w, stride, pad, scale=None, shift=None, relu=False):
+    x = x_nchw.double()
+    if scale is not None:
+        x = x * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+        if relu:
+            x = x.clamp_min(0)
+    return torch.nn.functional.conv2d(x, w.double(), stride=stride, padding=pad)
+
+
+@pytest.mark.parametrize("tile", [0, 64, 128, 12864])
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,stride,pad,pre", [
+    (2, 14, 14, 64, 64, 3, 1, 1, True),
+    (3, 9, 11, 32, 96, 3, 2, 1, True),
+    (2, 8, 8, 128, 256, 1, 1, 0, False),
+    (2, 8, 8, 128, 80, 1, 2, 0, True),
+])
+def test_conv_fast_path(dev, tile, B, H, W, Cin, Cout, k, stride, pad, pre):
+    g = torch.Generator().manual_seed(B + H + Cin + Cout + k)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) * 0.1
+    scale = torch.rand(Cin, generator=g) + 0.5 if pre else None
+    shift = torch.randn(Cin, generator=g) if pre else None
+    ref = _conv_ref(x, w, stride, pad, scale, shift, relu=pre)           # NCHW
+    OH, OW = ref.shape[2], ref.shape[3]
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)                     # NHWC
+    Kw = (k * k * Cin + 15) // 16 * 16
+    wp = ops.pack_conv_weight(w.to(dev), Kw)
+    y = torch.empty(B * OH * OW, Cout, device=dev)
+    M = B * OH * OW
+    tiles = lib().capnet_conv_tiles_m(M, Cout, tile)
+    psum = torch.zeros(tiles, Cout, device=dev)
+    psq = torch.zeros(tiles, Cout, device=dev)
+    sd = scale.to(dev) if pre else None
+    hd = shift.to(dev) if pre else None
+    check(lib().capnet_conv2d_fwd(ptr(xd), H * W * Cin, W * Cin, Cin, 1, ptr(wp), Kw, ptr(y),
+                                  ptr(sd), ptr(hd), int(pre), ptr(psum), ptr(psq), B, H, W, Cin,
+                                  Cout, k, k, stride, pad, tile, current_stream()))
+    ref_nhwc = ref.permute(0, 2, 3, 1).reshape(M, Cout)
+    assert rel_err(y, ref_nhwc) < 3e-6
+    assert rel_err(psum.sum(0), ref_nhwc.sum(0)) < 1e-5
+    assert rel_err(psq.sum(0), (ref_nhwc ** 2).sum(0)) < 1e-5
+
+
+def test_conv_stem_generic_nchw(dev):
+    B, H, W = 2, 64, 64
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B, 3, H, W, generator=g)
+    w = torch.randn(64, 3, 7, 7, generator=g) * 0.1
+    ref = _conv_ref(x, w, 2, 3)
+    OH, OW = ref.shape[2], ref.shape[3]
+    Kw = 160
+    wp = ops.pack_conv_weight(w.to(dev), Kw)
+    xd = x.to(dev)
+    y = torch.empty(B * OH * OW, 64, device=dev)
+    check(lib().capnet_conv2d_fwd(ptr(xd), 3 * H * W, W, 1, H * W, ptr(wp), Kw, ptr(y), None, None,
+                                  0, None, None, B, H, W, 3, 64, 7, 7, 2, 3, 0, current_stream()))
+    assert rel_err(y, ref.permute(0, 2, 3, 1).reshape(-1, 64)) < 3e-6
+
+
+def test_bn_finalize_and_tails(dev):
+    g = torch.Generator().manual_seed(3)
+    rows, Cc = 1000, 96
+    y = torch.randn(rows, Cc, generator=g) * 2 + 0.7
+    tiles = 8
+    part = y.view(tiles, rows // tiles, Cc)
+    psum, psq = part.sum(1).to(dev), (part ** 2).sum(1).to(dev)
+    gamma, beta = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g)
+    rm, rv = torch.zeros(Cc), torch.ones(Cc)
+    bn = torch.nn.BatchNorm1d(Cc)
+    with torch.no_grad():
+        bn.weight.copy_(gamma); bn.bias.copy_(beta)
+    bn.train()
+    ref = bn(y)
+    scale, shift = torch.empty(Cc, device=dev), torch.empty(Cc, device=dev)
+    rmd, rvd = rm.to(dev), rv.to(dev)
+    gd, bd, yd = gamma.to(dev), beta.to(dev), y.to(dev)   # keep device tensors alive across calls
+    check(lib().capnet_bn_finalize(ptr(psum), ptr(psq), tiles, Cc, rows, ptr(gd), ptr(bd),
+                                   ptr(rmd), ptr(rvd), 0.1, 1e-5, ptr(scale), ptr(shift),
+                                   current_stream()))
+    out = yd * scale + shift
+    assert rel_err(out, ref) < 2e-5
+    assert rel_err(rmd, bn.running_mean) < 1e-5
+    assert rel_err(rvd, bn.running_var) < 1e-5
+    # bottleneck tail
+    res = torch.randn(rows, Cc, generator=g)
+    o = torch.empty(rows, Cc, device=dev)
+    resd = res.to(dev)
+    check(lib().capnet_bn_add_relu(ptr(yd), ptr(scale), ptr(shift), ptr(resd), None,
+                                   None, ptr(o), rows, Cc, current_stream()))
+    assert rel_err(o, (ref + res).clamp_min(0)) < 2e-5
+    check(lib().capnet_bn_add_relu(ptr(yd), ptr(scale), ptr(shift), ptr(resd),
+                                   ptr(scale), ptr(shift), ptr(o), rows, Cc, current_stream()))
+    ref2 = (ref + res * scale.cpu() + shift.cpu()).clamp_min(0)
+    assert rel_err(o, ref2) < 2e-5
+
+
+def test_maxpool_avgpool_upsample(dev):
+    g = torch.Generator().manual_seed(4)
+    B, H, W, Cc = 2, 12, 12, 64
+    y = torch.randn(B, H, W, Cc, generator=g)
+    sc, sh = torch.rand(Cc, generator=g) - 0.3, torch.randn(Cc, generator=g)   # some negative scales
+    ref = torch.nn.functional.max_pool2d(((y * sc + sh).clamp_min(0)).permute(0, 3, 1, 2), 3, 2, 1)
+    out = torch.empty(B, 6, 6, Cc, device=dev)
+    yd, scd, shd = y.to(dev), sc.to(dev), sh.to(dev)
+    check(lib().capnet_bn_relu_maxpool(ptr(yd), ptr(scd), ptr(shd), ptr(out),
+                                       B, H, W, Cc, current_stream()))
+    assert rel_err(out, ref.permute(0, 2, 3, 1)) < 1e-6
+    x = torch.randn(B, 49, 128, generator=g)
+    o = torch.empty(B, 128, device=dev)
+    xd = x.to(dev)
+    check(lib().capnet_global_avgpool(ptr(xd), ptr(o), B, 49, 128, current_stream()))
+    assert rel_err(o, x.mean(1)) < 1e-6
+    m = torch.randn(B, 7, 7, 32, generator=g)
+    up = torch.empty(B, 14, 14, 32, device=dev)
+    md = m.to(dev)
+    check(lib().capnet_adaptive_pool_replicate(ptr(md), ptr(up), B, 7, 14, 32, current_stream()))
+    ref = torch.nn.functional.adaptive_avg_pool2d(m.permute(0, 3, 1, 2), 14).permute(0, 2, 3, 1)
+    assert rel_err(up, ref) < 1e-6
+
+
+def test_linear_xent_autograd(dev):
+    g = torch.Generator().manual_seed(9)
+    N, H, V = 37, 48, 211
+    x = torch.randn(N, H, generator=g)
+    w = torch.randn(V, H, generator=g) * 0.2
+    b = torch.randn(V, generator=g) * 0.1
+    t = torch.randint(0, V, (N,), generator=g)
+    xr, wr, br = [v.clone().double().requires_grad_() for v in (x, w, b)]
+    loss_ref = torch.nn.functional.cross_entropy(xr @ wr.t() + br, t)
+    loss_ref.backward()
+    xd, wd, bd = [v.to(dev).requires_grad_() for v in (x, w, b)]
+    loss = ops.cross_entropy(ops.linear(xd, wd, bd), t.to(dev))
+    loss.backward()
+    assert abs(loss.item() - loss_ref.item()) / loss_ref.item() < 1e-6
+    assert rel_err(xd.grad, xr.grad) < 1e-5
+    assert rel_err(wd.grad, wr.grad) < 1e-5
+    assert rel_err(bd.grad, br.grad) < 1e-5
+    ops.check_device_errors()
+
+
+def test_bn1d_autograd(dev):
+    g = torch.Generator().manual_seed(10)
+    B, Cc = 16, 50
+    x = torch.randn(B, Cc, generator=g) * 3 + 1
+    bn = torch.nn.BatchNorm1d(Cc, momentum=0.01).double()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.normal_()
+    xr = x.clone().double().requires_grad_()
+    dy = torch.randn(B, Cc, generator=g)
+    yr = bn(xr)
+    yr.backward(dy.double())
+    gam, bet = bn.weight.detach().float().to(dev).requires_grad_(), bn.bias.detach().float().to(dev).requires_grad_()
+    rm, rv = torch.zeros(Cc, device=dev), torch.ones(Cc, device=dev)
+    xd = x.to(dev).requires_grad_()
+    y = ops.batch_norm1d(xd, gam, bet, rm, rv, True, 0.01, 1e-5)
+    y.backward(dy.to(dev))
+    assert rel_err(y, yr) < 1e-5
+    assert rel_err(xd.grad, xr.grad) < 1e-4
+    assert rel_err(gam.grad, bn.weight.grad) < 1e-5
+    assert rel_err(bet.grad, bn.bias.grad) < 1e-5
+    assert rel_err(rm, bn.running_mean) < 1e-5 and rel_err(rv, bn.running_var) < 1e-5
+
+
+def test_clamp_adam_matches_torch(dev):
+    g = torch.Generator().manual_seed(12)
+    shapes = [(300, 17), (5,), (2049,), (64, 64)]
+    ps = [torch.randn(s, generator=g) for s in shapes]
+    ref_p = [p.clone().requires_grad_() for p in ps]
+    opt = torch.optim.Adam(ref_p, lr=2e-4, betas=(0.9, 0.999), eps=1e-8)
+    dp = [p.to(dev) for p in ps]
+    m = [torch.zeros_like(p) for p in dp]
+    v = [torch.zeros_like(p) for p in dp]
+    for step in range(1, 4):
+        grads = [torch.randn(s, generator=g) * 2 for s in shapes]
+        for p, gr in zip(ref_p, grads):
+            p.grad = gr.clone().clamp_(-0.5, 0.5)
+        opt.step()
+        dg = [gr.to(dev) for gr in grads]
+        ops.clamp_adam(dp, dg, m, v, [step] * len(dp), 2e-4, 0.9, 0.999, 1e-8, 0.5)
+        for a, b_, gg, gr in zip(dp, ref_p, dg, grads):
+            assert (a.cpu() - b_.detach()).abs().max().item() < 1e-7
+            assert torch.equal(gg.cpu(), gr.clamp(-0.5, 0.5))
+
+
+def test_argmax_first_max(dev):
+    x = torch.zeros(5, 1000)
+    x[0, 7] = 1; x[0, 900] = 1
+    x[1, 999] = 3
+    x[2] = -1; x[2, 0] = -0.5
+    x[3, 255] = 2; x[3, 256] = 2
+    out = ops.argmax_rows(x.to(dev)).cpu().tolist()
+    assert out == [7, 999, 0, 255, 0]
