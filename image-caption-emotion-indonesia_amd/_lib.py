@@ -56,11 +56,14 @@ SIGNATURES = {
                                 _vp]),
     "capnet_seq_backward": (_i, [_ip, _ip, _vp, _vp, _vp, _vp, _vp, C.POINTER(_vp), C.c_float,
                                  C.c_ulonglong, _i, _vp]),
+    "capnet_embedding_fwd": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _vp]),
+    "capnet_lstm_pointwise_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "capnet_xent_fwd": (_i, [_vp, _l, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "capnet_xent_bwd": (_i, [_vp, _l, _i, _i, _vp, _vp, _vp, _vp, _l, _vp]),
     "capnet_clamp_adam": (_i, [_i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp),
                                C.POINTER(_vp), C.POINTER(_l), _ip, C.c_float, C.c_float,
                                C.c_float, C.c_float, C.c_float, _i, _vp]),
+    "capnet_clamp": (_i, [_vp, _l, C.c_float, C.c_float, _vp]),
 }
 
 

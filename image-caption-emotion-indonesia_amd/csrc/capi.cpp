@@ -124,6 +124,19 @@ int capnet_bn1d_bwd(const float* dy, const float* x, int B, int C, const float* 
   return bn1d_bwd(dy, x, B, C, gamma, save_mean, save_invstd, dx, dgamma, dbeta, S(stream));
 }
 
+int capnet_embedding_fwd(const long long* idx, int n, const float* emb, int E, int V, float* out,
+                         int* err_flag, capnet_stream_t stream) {
+  return embedding_fwd(idx, n, emb, E, V, out, err_flag, S(stream));
+}
+int capnet_lstm_pointwise_fwd(float* pre, const float* c_prev, float* c_out, float* h_out, int b,
+                              int H, int cell, capnet_stream_t stream) {
+  CAPNET_REQUIRE(pre && c_out && h_out && b >= 0 && H > 0, "lstm_pointwise_fwd: bad argument");
+  if (cell == kCellFactored)
+    return lstm_pointwise_fwd(pre, c_prev, c_out, h_out, b, H, 0, 1, 2, 3, 0, S(stream));
+  CAPNET_REQUIRE(cell == kCellLSTM, "lstm_pointwise_fwd: unknown cell %d", cell);
+  return lstm_pointwise_fwd(pre, c_prev, c_out, h_out, b, H, 0, 1, 3, 2, 1, S(stream));
+}
+
 size_t capnet_seq_saved_floats(const int* dims) { return seq_saved_floats(to_dims(dims)); }
 size_t capnet_seq_saved_ints(const int* dims) { return seq_saved_ints(to_dims(dims)); }
 size_t capnet_seq_fwd_scratch_floats(const int* dims) { return seq_fwd_scratch_floats(to_dims(dims)); }
@@ -183,6 +196,10 @@ int capnet_clamp_adam(int n, float* const* params, float* const* grads, float* c
                       capnet_stream_t stream) {
   return clamp_adam(n, params, grads, exp_avg, exp_avg_sq, numel, step, lr, beta1, beta2, eps, clip,
                     write_grad, S(stream));
+}
+
+int capnet_clamp(float* x, long n, float lo, float hi, capnet_stream_t stream) {
+  return clamp_inplace(x, n, lo, hi, S(stream));
 }
 
 }  // extern "C"

@@ -63,6 +63,8 @@ int gather_inputs(const long long* captions, int T, const float* features, const
                   int V, const int* row_sample, const int* row_col, int* row_token, float* X,
                   int r0, int r1, float p, unsigned long long seed, int use_dropout, int dynamic,
                   int* err_flag, hipStream_t stream);
+int embedding_fwd(const long long* idx, int n, const float* emb, int E, int V, float* out,
+                  int* err_flag, hipStream_t stream);
 int vec_add(const float* a, const float* b, float* out, int n, hipStream_t stream);
 int lstm_pointwise_fwd(float* pre, const float* c_prev, float* c_out, float* h_out, int b, int H,
                        int gi, int gf, int go, int gg, int tanh_out, hipStream_t stream);
@@ -85,6 +87,7 @@ int xent_bwd(const float* logits, long ld, int N, int V, const long long* target
 int clamp_adam(int n_tensors, float* const* params, float* const* grads, float* const* exp_avg,
                float* const* exp_avg_sq, const long* numel, const int* step, float lr, float b1,
                float b2, float eps, float clip, int write_grad, hipStream_t stream);
+int clamp_inplace(float* x, long n, float lo, float hi, hipStream_t stream);
 int bn1d_fwd(const float* x, int B, int C, const float* gamma, const float* beta, float* rmean,
              float* rvar, int train, float momentum, float eps, float* y, float* save_mean,
              float* save_invstd, hipStream_t stream);

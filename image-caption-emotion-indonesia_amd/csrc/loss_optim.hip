@@ -192,6 +192,24 @@ int clamp_adam(int n_tensors, float* const* params, float* const* grads, float* 
   return kOk;
 }
 
+// ---- stand-alone element-wise clamp (utils.clip_gradient with a foreign optimiser) -----------
+__global__ __launch_bounds__(256) void clamp_kernel(float* __restrict__ x, long n, float lo,
+                                                    float hi) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long)gridDim.x * blockDim.x)
+    x[i] = fminf(fmaxf(x[i], lo), hi);
+}
+
+int clamp_inplace(float* x, long n, float lo, float hi, hipStream_t stream) {
+  CAPNET_REQUIRE(x && n >= 0 && lo <= hi, "clamp_inplace: bad argument");
+  if (n == 0) return kOk;
+  const long blocks = cdiv(n, 256);
+  hipLaunchKernelGGL(clamp_kernel, dim3((int)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, stream,
+                     x, n, lo, hi);
+  CAPNET_LAUNCH_CHECK();
+  return kOk;
+}
+
 // ---- BatchNorm1d over [B][C] (encoder head) -----------------------------------------------
 __global__ __launch_bounds__(64) void bn1d_fwd_kernel(const float* __restrict__ x, int B, int C,
                                                       const float* __restrict__ gamma,

@@ -110,6 +110,30 @@ int gather_inputs(const long long* captions, int T, const float* features, const
   return kOk;
 }
 
+// ---- plain embedding lookup (sample()/forward_step path): out[r] = emb[idx[r]] -------------
+__global__ __launch_bounds__(128) void embedding_fwd_kernel(const long long* __restrict__ idx,
+                                                            const float* __restrict__ emb, int E,
+                                                            int V, float* __restrict__ out,
+                                                            int* __restrict__ err_flag) {
+  const int r = blockIdx.x;
+  long long t = idx[r];
+  if (t < 0 || t >= V) {
+    if (threadIdx.x == 0) atomicExch(err_flag, 1);
+    t = 0;
+  }
+  for (int e = threadIdx.x; e < E; e += blockDim.x) out[(long)r * E + e] = emb[t * E + e];
+}
+
+int embedding_fwd(const long long* idx, int n, const float* emb, int E, int V, float* out,
+                  int* err_flag, hipStream_t stream) {
+  CAPNET_REQUIRE(idx && emb && out && err_flag && E > 0 && V > 0, "embedding_fwd: bad argument");
+  if (n <= 0) return kOk;
+  hipLaunchKernelGGL(embedding_fwd_kernel, dim3(n), dim3(128), 0, stream, idx, emb, E, V, out,
+                     err_flag);
+  CAPNET_LAUNCH_CHECK();
+  return kOk;
+}
+
 // out = a + b
 __global__ void vec_add_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                float* __restrict__ out, int n) {

@@ -98,6 +98,33 @@ def argmax_rows(x):
     return out
 
 
+def embedding(idx, weight):
+    """weight[idx] (no autograd: used by forward_step()/sample())."""
+    _need_cuda(idx, weight)
+    idx, w = _c(idx), _c(weight.detach())
+    if idx.dtype != torch.int64:
+        raise CapnetError("embedding indices must be int64")
+    out = torch.empty(tuple(idx.shape) + (w.shape[1],), dtype=torch.float32, device=w.device)
+    check(_lib.lib().capnet_embedding_fwd(ptr(idx), idx.numel(), ptr(w), w.shape[1], w.shape[0],
+                                          ptr(out), ptr(err_flag(w.device)), current_stream()),
+          "capnet_embedding_fwd")
+    return out
+
+
+def lstm_pointwise(pre, c_prev, cell):
+    """(h, c) from gate pre-activations [b, 4H] and the previous cell state (no autograd)."""
+    _need_cuda(pre, c_prev)
+    pre = pre.detach().clone().contiguous()
+    c_prev = _c(c_prev.detach())
+    b, h4 = pre.shape
+    H = h4 // 4
+    c = torch.empty((b, H), dtype=torch.float32, device=pre.device)
+    h = torch.empty((b, H), dtype=torch.float32, device=pre.device)
+    check(_lib.lib().capnet_lstm_pointwise_fwd(ptr(pre), ptr(c_prev), ptr(c), ptr(h), b, H, cell,
+                                               current_stream()), "capnet_lstm_pointwise_fwd")
+    return h, c
+
+
 def pack_conv_weight(w_oihw, row_stride):
     _need_cuda(w_oihw)
     w = _c(w_oihw)

@@ -1,0 +1,83 @@
+"""Adam with the reference's element-wise gradient clamp fused into the update kernel.
+
+Replaces `torch.optim.Adam(params, lr=...)` + `clip_gradient(optimizer, grad_clip)` +
+`optimizer.step()` of stylenet/train_multitask.py:166-167,388-389 (betas (0.9, 0.999),
+eps 1e-8, README.md:28-33). Parameters whose .grad is None are skipped and keep their own
+step count, as torch >= 2.0 does after zero_grad(set_to_none=True).
+"""
+import torch
+
+from . import ops
+from ._lib import CapnetError
+
+
+class Adam:
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        params = list(params)
+        if not params:
+            raise ValueError("optimizer got an empty parameter list")
+        if isinstance(params[0], dict):
+            groups = params
+        else:
+            groups = [{"params": params}]
+        self.param_groups = []
+        seen = set()
+        for g in groups:
+            g = dict(g)
+            g["params"] = list(g["params"])
+            g.setdefault("lr", lr)
+            g.setdefault("betas", betas)
+            g.setdefault("eps", eps)
+            for p in g["params"]:
+                if id(p) in seen:
+                    raise ValueError("some parameters appear in more than one parameter group")
+                seen.add(id(p))
+            self.param_groups.append(g)
+        self.state = {}
+        self._pending_clip = None
+        self.grad_sync = None  # optional callable(list_of_params) run before the update (data parallel)
+
+    def zero_grad(self, set_to_none=True):
+        for g in self.param_groups:
+            for p in g["params"]:
+                if p.grad is not None:
+                    if set_to_none:
+                        p.grad = None
+                    else:
+                        p.grad.detach_()
+                        p.grad.zero_()
+
+    def set_pending_clip(self, grad_clip):
+        """Called by utils.clip_gradient: the clamp is applied inside the next step()'s kernel
+        (and written back to .grad, so the visible effect equals clamp_ followed by step)."""
+        self._pending_clip = float(grad_clip)
+
+    @torch.no_grad()
+    def step(self):
+        clip = self._pending_clip
+        self._pending_clip = None
+        if self.grad_sync is not None:
+            self.grad_sync([p for g in self.param_groups for p in g["params"] if p.grad is not None])
+        for g in self.param_groups:
+            ps, gs, ms, vs, steps = [], [], [], [], []
+            for p in g["params"]:
+                if p.grad is None:
+                    continue
+                if not p.is_cuda:
+                    raise CapnetError("capnet.optim.Adam updates GPU parameters only")
+                st = self.state.get(p)
+                if st is None:
+                    st = {"step": 0, "exp_avg": torch.zeros_like(p), "exp_avg_sq": torch.zeros_like(p)}
+                    self.state[p] = st
+                st["step"] += 1
+                if not p.grad.is_contiguous():
+                    p.grad = p.grad.contiguous()
+                ps.append(p.data)
+                gs.append(p.grad)
+                ms.append(st["exp_avg"])
+                vs.append(st["exp_avg_sq"])
+                steps.append(st["step"])
+            b1, b2 = g["betas"]
+            ops.clamp_adam(ps, gs, ms, vs, steps, g["lr"], b1, b2, g["eps"], clip or 0.0,
+                           write_grad=True)

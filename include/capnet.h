@@ -153,6 +153,15 @@ int capnet_seq_backward(const int* dims, const int* batch_sizes, const float* d_
                         float* scratch, float* const* grads, float dropout_p,
                         unsigned long long seed, int training, capnet_stream_t stream);
 
+/* Single-step pieces used by forward_step() / sample() (no autograd):
+ *   out[r] = emb[idx[r]]                      -- self.B(k_prev_words), stylenet/model.py:221
+ *   gate pointwise on pre-activations [b][4H] (in place: overwritten by the activated gates),
+ *   cell 0: blocks i,f,o,c~ and h = o*c (model.py:147-153); cell 1: i,f,g,o and h = o*tanh(c). */
+int capnet_embedding_fwd(const long long* idx, int n, const float* emb, int E, int V, float* out,
+                         int* err_flag, capnet_stream_t stream);
+int capnet_lstm_pointwise_fwd(float* pre, const float* c_prev, float* c_out, float* h_out, int b,
+                              int H, int cell, capnet_stream_t stream);
+
 /* ---- loss: nn.CrossEntropyLoss() (mean) -- stylenet/train_multitask.py:134,383 ---------- */
 int capnet_xent_fwd(const float* logits, long ld, int N, int V, const long long* targets,
                     float* lse, float* row_loss, float* loss, int* err_flag,
@@ -169,6 +178,9 @@ int capnet_clamp_adam(int n, float* const* params, float* const* grads, float* c
                       float* const* exp_avg_sq, const long* numel, const int* step, float lr,
                       float beta1, float beta2, float eps, float clip, int write_grad,
                       capnet_stream_t stream);
+
+/* x[i] = min(max(x[i], lo), hi): utils.clip_gradient alone (stylenet/utils.py:57-60). */
+int capnet_clamp(float* x, long n, float lo, float hi, capnet_stream_t stream);
 
 #ifdef __cplusplus
 }

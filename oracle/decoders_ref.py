@@ -1,0 +1,105 @@
+"""CPU restatement of the reference decoders' forward pass. TEST INFRASTRUCTURE.
+
+Functional (parameters passed as a dict keyed like the reference's state_dict) so the same
+code checks tiny golden cases and full-size runs; gradients come from torch autograd, as in
+the reference (loss.backward(), stylenet/train_multitask.py:386).
+
+  factored_lstm_forward  <- DecoderFactoredLSTM.forward / forward_step, stylenet/model.py:115-196
+  lstm_forward           <- DecoderRNN.forward / forward_step,          nic/model.py:74-115
+The teacher-forcing decisions are an explicit list (one bool per time step); callers draw them
+with `random.random() < ratio` in step order, which is what stylenet/model.py:181 does.
+"""
+import torch
+import torch.nn.functional as Fn
+
+MODE_S = {
+    "factual": ["S_fi", "S_ff", "S_fo", "S_fc"],
+    "happy": ["S_happy_i", "S_happy_f", "S_happy_o", "S_happy_c"],
+    "sad": ["S_sad_i", "S_sad_f", "S_sad_o", "S_sad_c"],
+    "angry": ["S_angry_i", "S_angry_f", "S_angry_o", "S_angry_c"],
+}
+
+
+def _lin(p, name, x):
+    return Fn.linear(x, p[name + ".weight"], p[name + ".bias"])
+
+
+def factored_step(p, x, h, c, mode):
+    """stylenet/model.py:115-155: returns (h', c')."""
+    pre = []
+    for g, s in zip("ifoc", MODE_S[mode]):
+        v = _lin(p, "V_" + g, x)
+        v = _lin(p, s, v)
+        pre.append(_lin(p, "U_" + g, v) + _lin(p, "W_" + g, h))
+    i_t, f_t, o_t = torch.sigmoid(pre[0]), torch.sigmoid(pre[1]), torch.sigmoid(pre[2])
+    c_tilda = torch.tanh(pre[3])
+    c = f_t * c + i_t * c_tilda
+    h = o_t * c                     # no tanh on the cell (model.py:153)
+    return h, c
+
+
+def lstmcell_step(p, x, h, c):
+    """nn.LSTMCell (nic/model.py:52,77): gates i,f,g,o; h = o*tanh(c)."""
+    gates = Fn.linear(x, p["lstm.weight_ih"], p["lstm.bias_ih"]) + \
+        Fn.linear(h, p["lstm.weight_hh"], p["lstm.bias_hh"])
+    i, f, g, o = gates.chunk(4, 1)
+    c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
+    h = torch.sigmoid(o) * torch.tanh(c)
+    return h, c
+
+
+def batch_sizes(lengths):
+    return [sum(1 for l in lengths if l > t) for t in range(max(lengths))]
+
+
+def _run(step, emb_w, out_w, out_b, captions, lengths, features, tf_mask, hidden_size,
+         drop_mask=None):
+    """Shared loop of stylenet/model.py:157-196 / nic/model.py:81-115.
+
+    drop_mask: optional [B, T, E] multiplicative dropout mask (already scaled by 1/(1-p)).
+    Returns packed logits [N, V] and the list of predicted token tensors per step.
+    """
+    B = captions.size(0)
+    embeddings = emb_w[captions]                                  # B(captions)
+    if drop_mask is not None:
+        embeddings = embeddings * drop_mask                       # self.dropout(embeddings)
+    if features is not None:
+        embeddings = torch.cat((features.unsqueeze(1), embeddings), 1)
+    bs = batch_sizes(lengths)
+    assert len(tf_mask) == len(bs)
+    h = torch.zeros(B, hidden_size, dtype=emb_w.dtype)
+    c = torch.zeros(B, hidden_size, dtype=emb_w.dtype)
+    hiddens, preds = [], []
+    predicted = captions[:, 0:1]
+    for i, b in enumerate(bs):
+        if tf_mask[i]:
+            x = embeddings[:b, i, :]
+        else:
+            x = emb_w[predicted][:b, 0, :]                        # no dropout on the feedback
+        h, c = h[:b], c[:b]
+        h, c = step(x, h, c)
+        hiddens.append(h)
+        output = Fn.linear(h, out_w, out_b)
+        predicted = output.max(1)[1].unsqueeze(1)
+        preds.append(predicted)
+    hiddens = torch.cat(hiddens, 0)
+    return Fn.linear(hiddens, out_w, out_b), preds
+
+
+def factored_lstm_forward(p, captions, lengths, features, tf_mask, mode="factual", drop_mask=None):
+    H = p["W_i.weight"].shape[0]
+    return _run(lambda x, h, c: factored_step(p, x, h, c, mode), p["B.weight"], p["C.weight"],
+                p["C.bias"], captions, lengths, features, tf_mask, H, drop_mask)[0]
+
+
+def lstm_forward(p, captions, lengths, features, tf_mask, drop_mask=None):
+    H = p["lstm.weight_hh"].shape[1]
+    return _run(lambda x, h, c: lstmcell_step(p, x, h, c), p["embed.weight"], p["linear.weight"],
+                p["linear.bias"], captions, lengths, features, tf_mask, H, drop_mask)[0]
+
+
+def packed_targets(captions, lengths):
+    """pack_padded_sequence(captions, lengths, batch_first=True)[0]
+    (stylenet/train_multitask.py:377-379)."""
+    bs = batch_sizes(lengths)
+    return torch.cat([captions[:b, t] for t, b in enumerate(bs)], 0)

@@ -1,0 +1,234 @@
+"""GPU parity of the decoders (through the Python mirror classes and the C ABI) against
+(a) fixtures produced by the reference's own classes and (b) the CPU oracle on larger seeded
+cases. fp32 tolerance: 1e-4 relative on the loss is the north-star bar; these tests hold
+2e-5 on logits/grads at tiny sizes and 1e-4 at full size."""
+import random
+
+import pytest
+import torch
+
+import capnet
+from capnet import ops, synthetic
+from capnet.model import DecoderFactoredLSTM
+from capnet.nic_model import DecoderRNN
+from capnet.optim import Adam
+from capnet.utils import clip_gradient
+from helpers import golden_case, golden_params, load_golden, rel_err, t
+from oracle import decoders_ref as D
+from oracle import step_ref as S
+
+pytestmark = pytest.mark.gpu
+
+
+def _packed_targets(captions, lengths):
+    return D.packed_targets(captions, lengths)
+
+
+def _run_product(dec, captions, lengths, feats, seed, ratio, dev, **kw):
+    dec.zero_grad()
+    f = None
+    if feats is not None:
+        f = feats.to(dev).requires_grad_(True)
+    random.seed(seed)
+    if isinstance(dec, DecoderRNN):
+        out = dec(captions.to(dev), lengths, f, teacher_forcing_ratio=ratio)
+    else:
+        out = dec(captions.to(dev), lengths, f, teacher_forcing_ratio=ratio, **kw)
+    loss = ops.cross_entropy(out, _packed_targets(captions, lengths).to(dev))
+    loss.backward()
+    ops.check_device_errors()
+    return out, loss, f
+
+
+def _compare_with_case(dec, out, loss, f, c, tol=2e-5):
+    assert rel_err(out, c["logits"]) < tol
+    assert abs(loss.item() - float(c["loss"])) / float(c["loss"]) < 1e-6
+    n = 0
+    for k, p in dec.named_parameters():
+        key = "grad." + k
+        if key in c:
+            assert p.grad is not None, k
+            assert rel_err(p.grad, c[key]) < 5e-5, k
+            n += 1
+        else:
+            assert p.grad is None, k      # other modes' S matrices get no gradient (SURVEY A-11)
+    assert n > 0
+    if f is not None:
+        if float(abs(c["dfeatures"]).max()) == 0.0:
+            assert f.grad is None or float(f.grad.abs().max()) == 0.0
+        else:
+            assert rel_err(f.grad, c["dfeatures"]) < 5e-5
+
+
+@pytest.mark.parametrize("cname,seed,ratio", [("tf1_factual", 100, 1.0), ("tf0_factual", 101, 0.0),
+                                              ("tfmix_factual", 3, 0.6), ("tfmix_happy", 5, 0.6),
+                                              ("tfmix_angry_nofeat", 8, 0.6)])
+def test_factored_matches_reference_fixture(dev, cname, seed, ratio):
+    z = load_golden("decoder_factored_tiny.npz")
+    E, H, F, V = z["dims"].tolist()
+    dec = DecoderFactoredLSTM(E, H, F, V, 1, dropout=0.0)
+    dec.load_state_dict(golden_params(z))
+    dec.to(dev).train()
+    c = golden_case(z, cname)
+    feats = t(z["features"]) if int(c["with_features"]) else None
+    out, loss, f = _run_product(dec, t(z["captions"]), z["lengths"].tolist(), feats, seed, ratio, dev,
+                                mode=str(c["mode"]))
+    _compare_with_case(dec, out, loss, f, c)
+
+
+@pytest.mark.parametrize("cname,seed,ratio", [("tf1", 100, 1.0), ("tf0", 101, 0.0), ("tfmix", 3, 0.6)])
+def test_nic_matches_reference_fixture(dev, cname, seed, ratio):
+    z = load_golden("decoder_nic_tiny.npz")
+    E, H, _, V = z["dims"].tolist()
+    dec = DecoderRNN(E, H, V, 1, dropout=0.0)
+    dec.load_state_dict(golden_params(z))
+    dec.to(dev).train()
+    c = golden_case(z, cname)
+    out, loss, f = _run_product(dec, t(z["captions"]), z["lengths"].tolist(), t(z["features"]), seed,
+                                ratio, dev)
+    _compare_with_case(dec, out, loss, f, c)
+
+
+def test_forward_step_matches_reference_fixture(dev):
+    z = load_golden("decoder_factored_tiny.npz")
+    E, H, F, V = z["dims"].tolist()
+    dec = DecoderFactoredLSTM(E, H, F, V, 1, dropout=0.0)
+    dec.load_state_dict(golden_params(z))
+    dec.to(dev).eval()
+    x, h0, c0 = [t(z[k]).to(dev) for k in ("step.x", "step.h0", "step.c0")]
+    with torch.no_grad():
+        for mode in ("factual", "happy", "sad", "angry"):
+            h, (h2, c) = dec.forward_step(x, (h0, c0), mode)
+            assert rel_err(h, z["step.%s.h" % mode]) < 2e-5
+            assert rel_err(c, z["step.%s.c" % mode]) < 2e-5
+    with pytest.raises(ValueError):
+        dec.forward_step(x, (h0, c0), "joyful")
+
+
+def test_clamp_adam_sequence_matches_reference_fixture(dev):
+    z = load_golden("decoder_factored_tiny.npz")
+    a = load_golden("decoder_factored_tiny_adam.npz")
+    E, H, F, V = z["dims"].tolist()
+    dec = DecoderFactoredLSTM(E, H, F, V, 1, dropout=0.0)
+    dec.load_state_dict(golden_params(z))
+    dec.to(dev).train()
+    captions, lengths, feats = t(z["captions"]), z["lengths"].tolist(), t(z["features"])
+    opt = Adam(dec.parameters(), lr=float(a["lr"]))
+    targets = _packed_targets(captions, lengths).to(dev)
+    for it, mode in enumerate([str(m) for m in a["modes"]]):
+        random.seed(int(a["seeds"][it]))
+        out = dec(captions.to(dev), lengths, feats.to(dev), teacher_forcing_ratio=float(a["ratio"]), mode=mode)
+        loss = ops.cross_entropy(out, targets)
+        dec.zero_grad()
+        loss.backward()
+        clip_gradient(opt, float(a["clip"]))
+        opt.step()
+        assert abs(loss.item() - float(a["losses"][it])) / float(a["losses"][it]) < 1e-5
+    for k, v in dec.state_dict().items():
+        assert rel_err(v, a["final." + k]) < 2e-5, k
+
+
+def _oracle_case(dec, p, forward, B, V, seed, ratio, dev, ragged_len=None, **kw):
+    _, captions, lengths = synthetic.make_batch(B, V, seed=seed, images=False, min_len=3,
+                                                max_len=ragged_len or 12)
+    g = torch.Generator().manual_seed(seed + 1)
+    feats = torch.randn(B, dec.embed_size, generator=g)
+    random.seed(seed)
+    tf = [random.random() < ratio for _ in range(max(lengths))]
+    loss_r, grads_r, dfeat_r, logits_r = S.decoder_loss_and_grads(forward, p, captions, lengths, feats,
+                                                                 tf, **kw)
+    out, loss, f = _run_product(dec, captions, lengths, feats, seed, ratio, dev, **kw)
+    assert rel_err(out, logits_r) < 5e-5
+    assert abs(loss.item() - loss_r.item()) / loss_r.item() < 1e-5
+    for k, prm in dec.named_parameters():
+        gr = grads_r[k]
+        if gr is None:
+            assert prm.grad is None, k
+        else:
+            assert rel_err(prm.grad, gr) < 2e-4, k
+    if dfeat_r is not None:
+        assert rel_err(f.grad, dfeat_r) < 2e-4
+
+
+@pytest.mark.parametrize("B,V,E,F,H,mode,ratio", [
+    (9, 203, 20, 24, 28, "sad", 0.7),        # ragged everything (non multiples of 4)
+    (33, 1000, 300, 64, 96, "factual", 0.8),
+    (64, 7411, 300, 512, 512, "factual", 0.8),   # full-size cell, ragged vocabulary
+])
+def test_factored_matches_oracle_seeded(dev, B, V, E, F, H, mode, ratio):
+    dec = DecoderFactoredLSTM(E, H, F, V, 1, dropout=0.0)
+    p = synthetic.decoder_state(dec.state_dict(), seed=B, bias_range=0.05)
+    dec.load_state_dict(p)
+    dec.to(dev).train()
+    _oracle_case(dec, p, D.factored_lstm_forward, B, V, 17 + B, ratio, dev, mode=mode)
+
+
+def test_nic_matches_oracle_seeded(dev):
+    B, V, E, H = 8, 8192, 300, 512           # BASELINE config 1 decoder
+    dec = DecoderRNN(E, H, V, 1, dropout=0.0)
+    p = synthetic.decoder_state(dec.state_dict(), seed=3, bias_range=0.05)
+    dec.load_state_dict(p)
+    dec.to(dev).train()
+    _oracle_case(dec, p, D.lstm_forward, B, V, 5, 0.8, dev, ragged_len=24)
+
+
+def test_factored_full_size_losses_match_reference_scalars(dev):
+    """BASELINE config 2 decoder: 4 clamp+Adam steps, losses vs the reference's own run."""
+    z = load_golden("decoder_factored_full_scalars.npz")
+    E, H, F, V, B = z["dims"].tolist()
+    dec = DecoderFactoredLSTM(E, H, F, V, 1, dropout=0.0)
+    dec.load_state_dict(synthetic.decoder_state(dec.state_dict(), seed=1234))
+    dec.to(dev).train()
+    _, captions, lengths = synthetic.make_batch(B, V, seed=0, images=False)
+    g = torch.Generator().manual_seed(77)
+    feats = torch.randn(B, E, generator=g).to(dev)
+    opt = Adam(dec.parameters(), lr=2e-4)
+    targets = _packed_targets(captions, lengths).to(dev)
+    cap_d = captions.to(dev)
+    random.seed(0)
+    gn = dict(zip([str(s) for s in z["grad_names"]], z["grad_norms"].tolist()))
+    for it in range(4):
+        out = dec(cap_d, lengths, feats, teacher_forcing_ratio=0.8, mode="factual")
+        loss = ops.cross_entropy(out, targets)
+        dec.zero_grad()
+        loss.backward()
+        if it == 0:
+            for k, prm in dec.named_parameters():
+                if k in gn:
+                    assert abs(prm.grad.norm().item() - gn[k]) / (gn[k] + 1e-12) < 1e-3, k
+        clip_gradient(opt, 0.5)
+        opt.step()
+        assert abs(loss.item() - float(z["losses"][it])) / float(z["losses"][it]) < 1e-4, it
+    ops.check_device_errors()
+
+
+def test_dropout_is_deterministic_and_scaled(dev):
+    E, H, F, V, B = 32, 32, 32, 101, 6
+    dec = DecoderFactoredLSTM(E, H, F, V, 1, dropout=0.5).to(dev).train()
+    _, captions, lengths = synthetic.make_batch(B, V, seed=1, images=False, min_len=3, max_len=9)
+    feats = torch.randn(B, E).to(dev)
+    torch.manual_seed(5); random.seed(1)
+    a = dec(captions.to(dev), lengths, feats, teacher_forcing_ratio=1.0)
+    torch.manual_seed(5); random.seed(1)
+    b = dec(captions.to(dev), lengths, feats, teacher_forcing_ratio=1.0)
+    torch.manual_seed(6); random.seed(1)
+    c = dec(captions.to(dev), lengths, feats, teacher_forcing_ratio=1.0)
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    dec.eval()
+    random.seed(1)
+    d1 = dec(captions.to(dev), lengths, feats, teacher_forcing_ratio=1.0)
+    dec.dropout.p = 0.0
+    dec.train(); random.seed(1)
+    d2 = dec(captions.to(dev), lengths, feats, teacher_forcing_ratio=1.0)
+    assert torch.equal(d1, d2)
+
+
+def test_bad_inputs_raise(dev):
+    dec = DecoderFactoredLSTM(8, 8, 8, 11, 1, dropout=0.0).to(dev)
+    cap = torch.ones(2, 4, dtype=torch.long, device=dev)
+    with pytest.raises(capnet.CapnetError):
+        dec(cap, [2, 4], torch.zeros(2, 8, device=dev))          # not sorted decreasing
+    cap[0, 1] = 99                                                # token id >= vocab
+    dec(cap, [4, 2], torch.zeros(2, 8, device=dev), teacher_forcing_ratio=1.0)
+    with pytest.raises(capnet.CapnetError):
+        ops.check_device_errors()

@@ -232,7 +232,7 @@ def test_clamp_adam_matches_torch(dev):
         dg = [gr.to(dev) for gr in grads]
         ops.clamp_adam(dp, dg, m, v, [step] * len(dp), 2e-4, 0.9, 0.999, 1e-8, 0.5)
         for a, b_, gg, gr in zip(dp, ref_p, dg, grads):
-            assert (a.cpu() - b_.detach()).abs().max().item() < 1e-7
+            assert (a.cpu() - b_.detach()).abs().max().item() < 5e-7   # 1-2 ulp of O(1) values
             assert torch.equal(gg.cpu(), gr.clamp(-0.5, 0.5))
 
 

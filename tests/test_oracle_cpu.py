@@ -1,0 +1,91 @@
+"""The CPU oracle against the fixtures produced by the reference's own classes
+(tools/gen_golden.py ran stylenet/model.py and nic/model.py verbatim). No GPU needed."""
+import random
+
+import pytest
+import torch
+
+from helpers import golden_case, golden_params, load_golden, rel_err, t
+from oracle import decoders_ref as D
+from oracle import step_ref as S
+
+TOL = 2e-6
+
+
+def _check(forward, z, cname, **kw):
+    c = golden_case(z, cname)
+    p = golden_params(z)
+    captions, lengths = t(z["captions"]), z["lengths"].tolist()
+    feats = t(z["features"]) if c.get("with_features", 1) else None
+    tf = [bool(x) for x in c["tf_mask"]]
+    loss, grads, dfeat, logits = S.decoder_loss_and_grads(forward, p, captions, lengths, feats, tf, **kw)
+    assert rel_err(logits, c["logits"]) < TOL
+    assert abs(loss.item() - float(c["loss"])) < 1e-6
+    n = 0
+    for k, g in grads.items():
+        key = "grad." + k
+        if key in c:
+            assert rel_err(g, c[key]) < 1e-5, k
+            n += 1
+        else:
+            assert g is None or float(g.abs().max()) == 0.0, k
+    assert n > 0
+    if feats is not None:
+        assert rel_err(dfeat if dfeat is not None else torch.zeros_like(feats), c["dfeatures"]) < 1e-5 \
+            or float(abs(c["dfeatures"]).max()) == 0.0
+
+
+@pytest.mark.parametrize("cname", ["tf1_factual", "tf0_factual", "tfmix_factual", "tfmix_happy",
+                                   "tfmix_angry_nofeat"])
+def test_factored_forward_backward_matches_reference(cname):
+    z = load_golden("decoder_factored_tiny.npz")
+    _check(D.factored_lstm_forward, z, cname, mode=str(z["case.%s.mode" % cname]))
+
+
+@pytest.mark.parametrize("cname", ["tf1", "tf0", "tfmix"])
+def test_nic_forward_backward_matches_reference(cname):
+    z = load_golden("decoder_nic_tiny.npz")
+    _check(D.lstm_forward, z, cname)
+
+
+def test_forward_step_matches_reference():
+    z = load_golden("decoder_factored_tiny.npz")
+    p = golden_params(z)
+    x, h0, c0 = t(z["step.x"]), t(z["step.h0"]), t(z["step.c0"])
+    for mode in ("factual", "happy", "sad", "angry"):
+        h, c = D.factored_step(p, x, h0, c0, mode)
+        assert rel_err(h, z["step.%s.h" % mode]) < TOL
+        assert rel_err(c, z["step.%s.c" % mode]) < TOL
+
+
+def test_tf_draws_follow_python_random():
+    # the fixtures' masks are `random.random() < ratio` draws, one per step (model.py:181)
+    z = load_golden("decoder_factored_tiny.npz")
+    random.seed(3)
+    assert [random.random() < 0.6 for _ in range(7)] == [bool(x) for x in z["case.tfmix_factual.tf_mask"]]
+
+
+def test_clamp_adam_steps_match_reference():
+    z = load_golden("decoder_factored_tiny.npz")
+    a = load_golden("decoder_factored_tiny_adam.npz")
+    p = {k: v.clone() for k, v in golden_params(z).items()}
+    captions, lengths, feats = t(z["captions"]), z["lengths"].tolist(), t(z["features"])
+    opt = S.AdamRef(lr=float(a["lr"]))
+    for it, mode in enumerate([str(m) for m in a["modes"]]):
+        random.seed(int(a["seeds"][it]))
+        tf = [random.random() < float(a["ratio"]) for _ in range(max(lengths))]
+        loss, grads, _, _ = S.decoder_loss_and_grads(D.factored_lstm_forward, p, captions, lengths,
+                                                     feats, tf, mode=mode)
+        assert abs(loss.item() - float(a["losses"][it])) < 2e-6
+        S.clip_gradient_(grads.values(), float(a["clip"]))
+        opt.step(p, grads)
+    for k, v in p.items():
+        assert rel_err(v, a["final." + k]) < 1e-5, k
+
+
+def test_packed_targets_match_torch():
+    from torch.nn.utils.rnn import pack_padded_sequence
+    z = load_golden("decoder_factored_tiny.npz")
+    captions, lengths = t(z["captions"]), z["lengths"].tolist()
+    assert torch.equal(D.packed_targets(captions, lengths),
+                       pack_padded_sequence(captions, lengths, batch_first=True)[0])

@@ -1,0 +1,219 @@
+"""Generates tests/golden/*.npz by running the REFERENCE's own decoder classes on CPU.
+
+Runs only in the build container (it imports /root/reference/stylenet/model.py and
+/root/reference/nic/model.py verbatim, with an empty stub for the absent torchvision package --
+torchvision is only touched inside EncoderCNN.__init__, which is never constructed here).
+Nothing from /root/reference is copied: only inputs and outputs are stored.
+
+    python tools/gen_golden.py            # writes tests/golden/
+"""
+import importlib.util
+import os
+import random
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.nn.utils.rnn import pack_padded_sequence
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import capnet  # noqa: E402
+from capnet import synthetic  # noqa: E402
+
+REF = "/root/reference"
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def load_ref(pkg, modname):
+    for stub in ("torchvision", "torchvision.models"):
+        if stub not in sys.modules:
+            sys.modules[stub] = types.ModuleType(stub)
+    sys.modules["torchvision"].models = sys.modules["torchvision.models"]
+    path = os.path.join(REF, pkg, modname + ".py")
+    spec = importlib.util.spec_from_file_location("ref_%s_%s" % (pkg, modname), path)
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def tf_draws(seed, n, ratio):
+    random.seed(seed)
+    return [random.random() < ratio for _ in range(n)]
+
+
+def run_case(dec, fwd_kwargs, captions, lengths, features, seed, ratio):
+    """forward + CrossEntropy + backward exactly as stylenet/train_multitask.py:377-386."""
+    dec.zero_grad()
+    feat = None
+    if features is not None:
+        feat = features.clone().requires_grad_(True)
+    random.seed(seed)
+    if feat is None and "features" not in fwd_kwargs:
+        outputs = dec(captions, lengths, teacher_forcing_ratio=ratio, **fwd_kwargs)
+    else:
+        outputs = dec(captions, lengths, feat, teacher_forcing_ratio=ratio, **fwd_kwargs)
+    targets = pack_padded_sequence(captions, lengths, batch_first=True)[0]
+    loss = nn.CrossEntropyLoss()(outputs, targets)
+    loss.backward()
+    res = {"logits": outputs.detach().numpy(), "loss": loss.detach().numpy(),
+           "tf_mask": np.array(tf_draws(seed, max(lengths), ratio), dtype=np.uint8)}
+    if feat is not None:
+        # step 0 not teacher forced -> the image feature is never used (model.py:181-184)
+        res["dfeatures"] = (feat.grad if feat.grad is not None else torch.zeros_like(feat)).numpy()
+    for k, p in dec.named_parameters():
+        if p.grad is not None:
+            res["grad." + k] = p.grad.detach().numpy().copy()
+    return res
+
+
+def save(name, arrays):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name)
+    np.savez_compressed(path, **arrays)
+    print("wrote %s (%.1f KB)" % (path, os.path.getsize(path) / 1024))
+
+
+def tiny_inputs(V, E, seed):
+    g = torch.Generator().manual_seed(seed)
+    lengths = [7, 5, 5, 2]
+    B, T = 4, 7
+    captions = torch.randint(4, V, (B, T), generator=g)
+    captions[:, 0] = 1
+    for i, l in enumerate(lengths):
+        captions[i, l - 1] = 2
+        captions[i, l:] = 0
+    features = torch.randn(B, E, generator=g)
+    return captions, lengths, features
+
+
+def gen_factored_tiny():
+    ref = load_ref("stylenet", "model")
+    E, H, F, V = 12, 16, 16, 37
+    dec = ref.DecoderFactoredLSTM(E, H, F, V, 1, dropout=0.0)
+    dec.train()
+    state = synthetic.decoder_state(dec.state_dict(), seed=7, bias_range=0.1)
+    dec.load_state_dict(state)
+    captions, lengths, features = tiny_inputs(V, E, 21)
+    arrays = {"captions": captions.numpy(), "lengths": np.array(lengths), "features": features.numpy(),
+              "dims": np.array([E, H, F, V])}
+    for k, v in state.items():
+        arrays["param." + k] = v.numpy()
+    cases = [("tf1_factual", dict(mode="factual"), True, 100, 1.0),
+             ("tf0_factual", dict(mode="factual"), True, 101, 0.0),
+             ("tfmix_factual", dict(mode="factual"), True, 3, 0.6),
+             ("tfmix_happy", dict(mode="happy"), True, 5, 0.6),
+             ("tfmix_angry_nofeat", dict(mode="angry"), False, 8, 0.6)]
+    names = []
+    for cname, kw, with_feat, seed, ratio in cases:
+        r = run_case(dec, kw, captions, lengths, features if with_feat else None, seed, ratio)
+        names.append(cname)
+        arrays["case.%s.mode" % cname] = np.array(kw["mode"])
+        arrays["case.%s.with_features" % cname] = np.array(int(with_feat))
+        for k, v in r.items():
+            arrays["case.%s.%s" % (cname, k)] = v
+        print(cname, "tf", r["tf_mask"].tolist(), "loss", float(r["loss"]))
+    arrays["cases"] = np.array(names)
+    # one forward_step (G1)
+    g = torch.Generator().manual_seed(33)
+    x, h, c = torch.randn(3, E, generator=g), torch.randn(3, H, generator=g), torch.randn(3, H, generator=g)
+    for mode in ("factual", "happy", "sad", "angry"):
+        hh, (_, cc) = dec.forward_step(x, (h, c), mode)
+        arrays["step.%s.h" % mode] = hh.detach().numpy()
+        arrays["step.%s.c" % mode] = cc.detach().numpy()
+    arrays["step.x"], arrays["step.h0"], arrays["step.c0"] = x.numpy(), h.numpy(), c.numpy()
+    save("decoder_factored_tiny.npz", arrays)
+
+    # clamp + Adam over 3 steps with the reference's clip_gradient (stylenet/utils.py:51-60)
+    utils = load_ref("stylenet", "utils")
+    dec.load_state_dict(state)
+    opt = torch.optim.Adam(dec.parameters(), lr=2e-2, betas=(0.9, 0.999), eps=1e-8)
+    steps = {"losses": [], "modes": []}
+    for it, mode in enumerate(["factual", "happy", "factual", "factual"]):
+        random.seed(50 + it)
+        feat = features.clone()
+        outputs = dec(captions, lengths, feat, teacher_forcing_ratio=0.6, mode=mode)
+        targets = pack_padded_sequence(captions, lengths, batch_first=True)[0]
+        loss = nn.CrossEntropyLoss()(outputs, targets)
+        dec.zero_grad()
+        loss.backward()
+        utils.clip_gradient(opt, 0.01)
+        opt.step()
+        steps["losses"].append(float(loss))
+        steps["modes"].append(mode)
+    arr2 = {"losses": np.array(steps["losses"]), "modes": np.array(steps["modes"]),
+            "seeds": np.array([50, 51, 52, 53]), "lr": np.array(2e-2), "clip": np.array(0.01),
+            "ratio": np.array(0.6)}
+    for k, v in dec.state_dict().items():
+        arr2["final." + k] = v.numpy()
+    print("adam losses", steps["losses"])
+    save("decoder_factored_tiny_adam.npz", arr2)
+
+
+def gen_nic_tiny():
+    ref = load_ref("nic", "model")
+    E, H, V = 12, 16, 37
+    dec = ref.DecoderRNN(E, H, V, 1, dropout=0.0)
+    dec.train()
+    state = synthetic.decoder_state(dec.state_dict(), seed=9, bias_range=0.1)
+    dec.load_state_dict(state)
+    captions, lengths, features = tiny_inputs(V, E, 22)
+    arrays = {"captions": captions.numpy(), "lengths": np.array(lengths), "features": features.numpy(),
+              "dims": np.array([E, H, 0, V])}
+    for k, v in state.items():
+        arrays["param." + k] = v.numpy()
+    names = []
+    for cname, seed, ratio in [("tf1", 100, 1.0), ("tf0", 101, 0.0), ("tfmix", 3, 0.6)]:
+        r = run_case(dec, {}, captions, lengths, features, seed, ratio)
+        names.append(cname)
+        for k, v in r.items():
+            arrays["case.%s.%s" % (cname, k)] = v
+        print("nic", cname, "tf", r["tf_mask"].tolist(), "loss", float(r["loss"]))
+    arrays["cases"] = np.array(names)
+    save("decoder_nic_tiny.npz", arrays)
+
+
+def gen_factored_full():
+    """Config 2 decoder at full size (E=300, F=H=512, V=8192, B=64): scalars only."""
+    ref = load_ref("stylenet", "model")
+    utils = load_ref("stylenet", "utils")
+    E, H, F, V, B = 300, 512, 512, 8192, 64
+    dec = ref.DecoderFactoredLSTM(E, H, F, V, 1, dropout=0.0)
+    dec.train()
+    dec.load_state_dict(synthetic.decoder_state(dec.state_dict(), seed=1234))
+    _, captions, lengths = synthetic.make_batch(B, V, seed=0, images=False)
+    g = torch.Generator().manual_seed(77)
+    features = torch.randn(B, E, generator=g)
+    opt = torch.optim.Adam(dec.parameters(), lr=2e-4, betas=(0.9, 0.999), eps=1e-8)
+    losses, gnorms = [], {}
+    random.seed(0)
+    for it in range(4):
+        outputs = dec(captions, lengths, features, teacher_forcing_ratio=0.8, mode="factual")
+        targets = pack_padded_sequence(captions, lengths, batch_first=True)[0]
+        loss = nn.CrossEntropyLoss()(outputs, targets)
+        dec.zero_grad()
+        loss.backward()
+        if it == 0:
+            for k, p in dec.named_parameters():
+                if p.grad is not None:
+                    gnorms[k] = float(p.grad.norm())
+        utils.clip_gradient(opt, 0.5)
+        opt.step()
+        losses.append(float(loss))
+        print("full step", it, float(loss))
+    arrays = {"losses": np.array(losses), "dims": np.array([E, H, F, V, B]),
+              "grad_names": np.array(list(gnorms.keys())), "grad_norms": np.array(list(gnorms.values()))}
+    save("decoder_factored_full_scalars.npz", arrays)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    which = sys.argv[1:] or ["factored_tiny", "nic_tiny", "factored_full"]
+    if "factored_tiny" in which:
+        gen_factored_tiny()
+    if "nic_tiny" in which:
+        gen_nic_tiny()
+    if "factored_full" in which:
+        gen_factored_full()
