@@ -89,3 +89,24 @@ def test_packed_targets_match_torch():
     captions, lengths = t(z["captions"]), z["lengths"].tolist()
     assert torch.equal(D.packed_targets(captions, lengths),
                        pack_padded_sequence(captions, lengths, batch_first=True)[0])
+
+
+def test_trunk_oracle_fp32_against_fp64_fixture():
+    """oracle/resnet152_ref.py in fp32 vs its own fp64 fixture: structure check (58.1 M conv+BN
+    parameters, 155 convolutions) and a measurement of the fp32 noise floor at B=3."""
+    import capnet  # noqa: F401
+    from capnet import synthetic
+    from oracle.resnet152_ref import resnet152_children
+    z = load_golden("trunk_b3.npz")
+    net = resnet152_children(True)
+    sd = net.state_dict()
+    assert sum(v.numel() for v in sd.values() if v.dim() == 4) == 57992384   # conv weights
+    assert sum(1 for v in sd.values() if v.dim() == 4) == 155
+    st = synthetic.trunk_state({"resnet." + k: v for k, v in sd.items()}, seed=1234)
+    net.load_state_dict({k[len("resnet."):]: v for k, v in st.items()})
+    net.train()
+    imgs = synthetic.make_batch(int(z["B"]), 100, seed=0)[0]
+    with torch.no_grad():
+        y = net(imgs).reshape(int(z["B"]), -1)
+    e = rel_err(y, z["pooled_train"])
+    assert 1e-6 < e < 2e-3, e

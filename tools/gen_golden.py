@@ -208,6 +208,64 @@ def gen_factored_full():
     save("decoder_factored_full_scalars.npz", arrays)
 
 
+def gen_trunk():
+    """ResNet-152 trunk + encoder head through the ORACLE restatement, evaluated in FLOAT64.
+
+    torchvision is absent (parity unpinned vs the reference), so this pins the oracle to itself.
+    Why fp64: at B=3 the train-mode BatchNorms of layer4 see 147 samples per channel and the
+    152-layer chain amplifies rounding; the fp32 CPU oracle itself sits 7.4e-4 (max-abs relative)
+    from the fp64 result. Storing the fp64 values lets the GPU test and the fp32 oracle test be
+    judged against the same, rounding-free numbers (tolerance 2e-3)."""
+    from oracle.resnet152_ref import EncoderCNNRef, EncoderCNNAttRef
+    B = 3
+    enc = EncoderCNNRef(300)
+    sd = enc.state_dict()
+    new = synthetic.trunk_state({k: v for k, v in sd.items() if k.startswith("resnet.")}, seed=1234)
+    new["linear.weight"] = synthetic.param_tensor("linear.weight", sd["linear.weight"].shape, 1234, "xavier")
+    new["linear.bias"] = synthetic.param_tensor("linear.bias", sd["linear.bias"].shape, 1234, "bias", 0.05)
+    new["bn.weight"] = synthetic.param_tensor("bn.weight", sd["bn.weight"].shape, 1234, "bias", 0.5) + 1.0
+    new["bn.bias"] = synthetic.param_tensor("bn.bias", sd["bn.bias"].shape, 1234, "bias", 0.2)
+    for k in ("bn.running_mean", "bn.running_var", "bn.num_batches_tracked"):
+        new[k] = sd[k]
+    enc.load_state_dict(new)
+    enc = enc.double()
+    imgs = synthetic.make_batch(B, 100, seed=0)[0].double()
+    enc.train()
+    with torch.no_grad():
+        pooled = enc.resnet(imgs).reshape(B, -1)
+    feats = enc(imgs)     # second train-mode pass: running stats now updated twice
+    f32 = lambda x: x.detach().float().numpy().copy()
+    arrays = {"B": np.array(B), "pooled_train": f32(pooled), "encoder_out_train": f32(feats),
+              "rm_stem": f32(enc.resnet[1].running_mean), "rv_stem": f32(enc.resnet[1].running_var),
+              "rm_last": f32(enc.resnet[7][2].bn3.running_mean),
+              "rv_last": f32(enc.resnet[7][2].bn3.running_var),
+              "nbt_last": enc.resnet[7][2].bn3.num_batches_tracked.numpy().copy(),
+              "head_rm": f32(enc.bn.running_mean), "head_rv": f32(enc.bn.running_var)}
+    # eval mode with running stats == batch stats of this input (one momentum-1.0 train pass)
+    enc = EncoderCNNRef(300)
+    enc.load_state_dict(new)
+    enc = enc.double()
+    for m in enc.resnet.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            m.momentum = 1.0
+    enc.train()
+    with torch.no_grad():
+        enc.resnet(imgs)
+    enc.eval()
+    with torch.no_grad():
+        arrays["pooled_eval"] = f32(enc.resnet(imgs).reshape(B, -1))
+    # attention encoder: NHWC 14x14 map
+    att = EncoderCNNAttRef(14)
+    att.resnet.load_state_dict({k[len("resnet."):]: v for k, v in new.items() if k.startswith("resnet.")})
+    att = att.double()
+    att.train()
+    fmap = att(imgs)
+    arrays["att_map_train_b0"] = f32(fmap[0])       # [14,14,2048] of image 0 only
+    arrays["att_map_checksum"] = np.array([float(fmap.sum()), float(fmap.abs().sum())])
+    print("pooled mean/std", float(pooled.mean()), float(pooled.std()), "eval", float(arrays["pooled_eval"].mean()))
+    save("trunk_b3.npz", arrays)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     which = sys.argv[1:] or ["factored_tiny", "nic_tiny", "factored_full"]
@@ -217,3 +275,5 @@ if __name__ == "__main__":
         gen_nic_tiny()
     if "factored_full" in which:
         gen_factored_full()
+    if "trunk" in which:
+        gen_trunk()
