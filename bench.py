@@ -1,0 +1,252 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of the full StyleNet train step on MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = ResNet-152 trunk forward (train-mode BN, no_grad) + encoder head + FactoredLSTM-512
+decoder forward (teacher forcing 0.8, dropout 0.5) + softmax-NLL + backward + element-wise clamp
++ Adam, on a batch of 64 synthetic 224x224 images per GPU (BASELINE.json configs[1]; weak
+scaling for N > 1 with one RCCL all-reduce of the flat gradient buffer per step). Inputs are
+resident in HBM before the timed region. Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import random
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_F32_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: FP32 matrix peak (dense)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="images per GPU")
+    ap.add_argument("--vocab", type=int, default=8192)
+    ap.add_argument("--decoder", default="factored", choices=["factored", "nic"])
+    ap.add_argument("--dropout", type=float, default=0.5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-conv-events", action="store_true",
+                    help="do not bracket conv kernels with hipEvents (roofline becomes null)")
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    return ap.parse_args()
+
+
+def log(msg):
+    sys.stderr.write("[bench %s] %s\n" % (time.strftime("%H:%M:%S"), msg))
+    sys.stderr.flush()
+
+
+def host_cores():
+    """CPU share of this process: min(affinity, cgroup quota); the GPU boxes give 16 per GPU."""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
+
+
+def cpu_baseline(args, steps):
+    """The CPU oracle (oracle/: torch-CPU restatement of the reference step) timed on this
+    host's cores, same workload shape: batch 64, ResNet-152 + FactoredLSTM-512, V=8192."""
+    from capnet import synthetic
+    from oracle import decoders_ref as D
+    from oracle import step_ref as S
+    from oracle.resnet152_ref import EncoderCNNRef
+    import torch.nn.functional as Fn
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    log("cpu baseline on %d threads" % cores)
+    B, V = args.batch, args.vocab
+    enc = EncoderCNNRef(300)
+    enc.train()
+    from capnet.model import DecoderFactoredLSTM
+    shapes = {k: v for k, v in DecoderFactoredLSTM(300, 512, 512, V, 1).state_dict().items()}
+    p = synthetic.decoder_state(shapes, seed=1234)
+    imgs, captions, lengths = synthetic.make_batch(B, V, seed=0)
+    opt = S.AdamRef(lr=2e-4)
+    random.seed(0)
+    times, losses = [], []
+    for it in range(steps + 1):
+        t0 = time.perf_counter()
+        tf = [random.random() < 0.8 for _ in range(max(lengths))]
+        leaves = {k: v.detach().clone().requires_grad_(True) for k, v in p.items()}
+        feats = enc(imgs)
+        logits = D.factored_lstm_forward(leaves, captions, lengths, feats, tf, "factual")
+        loss = Fn.cross_entropy(logits, D.packed_targets(captions, lengths))
+        enc.zero_grad()
+        loss.backward()
+        grads = {k: v.grad for k, v in leaves.items()}
+        S.clip_gradient_(grads.values(), 0.5)
+        with torch.no_grad():
+            opt.step(p, grads)
+            hp = {("enc." + k): v for k, v in enc.named_parameters() if not k.startswith("resnet.")}
+            hg = {k: v.grad for k, v in hp.items()}
+            S.clip_gradient_([g for g in hg.values() if g is not None], 0.5)
+            opt.step(hp, hg)
+        dt = time.perf_counter() - t0
+        log("cpu step %d: %.2f s, loss %.5f" % (it, dt, float(loss)))
+        if it > 0:
+            times.append(dt)
+        losses.append(float(loss))
+    t = sorted(times)[len(times) // 2]
+    return {"value": round(B / t, 3), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": "%d full train steps at batch %d after 1 warm-up step (median %.2f s/step), "
+                      "oracle/ torch-CPU fp32, dropout 0" % (steps, B, t),
+            "loss_first": losses[0]}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d"
+                             % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no GPU visible); there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import capnet
+    from capnet import ops, synthetic
+    from capnet.model import DecoderFactoredLSTM, EncoderCNN
+    from capnet.nic_model import DecoderRNN
+    from capnet.parallel import DataParallelAdam
+    from capnet.train import CrossEntropyLoss, train_step
+
+    B, V = args.batch, args.vocab
+    torch.manual_seed(1234)
+    encoder = EncoderCNN(300)
+    if args.decoder == "factored":
+        decoder = DecoderFactoredLSTM(300, 512, 512, V, 1, dropout=args.dropout)
+    else:
+        decoder = DecoderRNN(300, 512, V, 1, dropout=args.dropout)
+    decoder.load_state_dict(synthetic.decoder_state(decoder.state_dict(), seed=1234))
+    encoder.to(dev).train()
+    decoder.to(dev).train()
+    params = list(decoder.parameters()) + list(encoder.linear.parameters()) + list(encoder.bn.parameters())
+    optimizer = DataParallelAdam(params, lr=2e-4, overlap=True).attach(encoder)
+    criterion = CrossEntropyLoss()
+
+    # every rank can rebuild every rank's lengths (seeded), so token weights and the global
+    # number of steps need no communication
+    all_lengths = [synthetic.make_batch(B, V, seed=r, images=False)[2] for r in range(world)]
+    n_global = sum(sum(l) for l in all_lengths)
+    global_steps = max(l[0] for l in all_lengths)
+    images, captions, lengths = synthetic.make_batch(B, V, seed=rank)
+    images, captions = images.to(dev), captions.to(dev)
+    # SUM all-reduce of grads scaled by N_rank/N_global == gradient of the global token-mean loss
+    loss_scale = float(sum(lengths)) / n_global if world > 1 else None
+    random.seed(0)
+
+    def step():
+        tf = [random.random() < 0.8 for _ in range(global_steps)]
+        return train_step(encoder, decoder, optimizer, criterion, images, captions, lengths, 0.5,
+                          tf_mask=tf, loss_scale=loss_scale)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    log("rank %d/%d ready: batch %d, %d tokens, %d steps" % (rank, world, B, sum(lengths), lengths[0]))
+    first = None
+    for _ in range(args.warmup):
+        l = step()
+        first = l if first is None else first
+    runner = encoder._trunk()
+    plan = runner._plan(B, 224, 224, dev)
+    lib = capnet.lib()
+    if not args.no_conv_events:
+        lib.capnet_trunk_set_timing(plan["handle"], 1)
+    barrier()
+    log("warm-up done, timing %d steps" % args.steps)
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(args.steps):
+        last = step()
+    optimizer.wait_for_update()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    log("timed region: %.3f s" % elapsed)
+    lib.capnet_trunk_set_timing(plan["handle"], 0)
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+    ops.check_device_errors()
+
+    roofline = None
+    if not args.no_conv_events:
+        ms, n, fl = C.c_double(), C.c_long(), C.c_double()
+        capnet._lib.check(lib.capnet_trunk_collect_timing(plan["handle"], C.byref(ms), C.byref(n), C.byref(fl)))
+        if n.value > 0:
+            achieved = fl.value / (ms.value * 1e-3) / 1e12
+            roofline = {"bound": "mfma", "kernel": "conv_f32_kernel (implicit-GEMM conv, v_mfma_f32_32x32x2_f32)",
+                        "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                        "launches": n.value, "avg_launch_us": round(ms.value * 1e3 / n.value, 2),
+                        "flops_per_launch": fl.value / n.value}
+
+    if rank == 0:
+        total_images = B * world * args.steps
+        out = {
+            "metric": "images/sec (train step) + NLL loss match, batch=64 ResNet152+FactoredLSTM-512",
+            "value": round(total_images / elapsed, 2),
+            "unit": "images/sec",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "configs[1]: StyleNet FactoredLSTM (factored 512, hidden 512, 1 layer, "
+                                   "emb 300, V=%d) + ResNet-152 train-mode trunk, batch %d/GPU, 224x224, "
+                                   "tf 0.8, dropout %.2f, clamp 0.5 + Adam 2e-4" % (V, B, args.dropout),
+                       "decoder": args.decoder, "global_batch": B * world,
+                       "parallelism": "dp%d" % world},
+            "loss_first": round(float(first.item()), 5) if first is not None else None,
+            "loss_last": round(float(last.item()), 5),
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, args.cpu_steps)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -66,7 +66,7 @@ int capnet_trunk_forward(const capnet_trunk_t* t, const float* images_nchw,
                          float* const* bn_running_var, int train, float momentum, float eps,
                          void* workspace, float* out_pooled, float* out_map,
                          capnet_stream_t stream) {
-  return trunk_forward(reinterpret_cast<const Trunk*>(t), images_nchw, w_packed, bn_weight,
+  return trunk_forward(reinterpret_cast<Trunk*>(const_cast<capnet_trunk_t*>(t)), images_nchw, w_packed, bn_weight,
                        bn_bias, bn_running_mean, bn_running_var, train, momentum, eps,
                        reinterpret_cast<float*>(workspace), out_pooled, out_map, S(stream));
 }
@@ -196,6 +196,33 @@ int capnet_clamp_adam(int n, float* const* params, float* const* grads, float* c
                       capnet_stream_t stream) {
   return clamp_adam(n, params, grads, exp_avg, exp_avg_sq, numel, step, lr, beta1, beta2, eps, clip,
                     write_grad, S(stream));
+}
+
+int capnet_trunk_set_timing(capnet_trunk_t* t, int enable) {
+  return trunk_set_timing(reinterpret_cast<Trunk*>(t), enable);
+}
+int capnet_trunk_collect_timing(capnet_trunk_t* t, double* conv_ms, long* conv_launches,
+                                double* conv_flops) {
+  return trunk_collect_timing(reinterpret_cast<Trunk*>(t), conv_ms, conv_launches, conv_flops);
+}
+
+int capnet_packed_targets(const long long* captions, int T, int steps, const int* batch_sizes,
+                          long long* out, capnet_stream_t stream) {
+  CAPNET_REQUIRE(batch_sizes && steps > 0 && steps <= kMaxSteps, "packed_targets: steps %d", steps);
+  SeqMeta m;
+  m.steps = steps; m.has_features = 0; m.off[0] = 0;
+  for (int t = 0; t < steps; ++t) {
+    CAPNET_REQUIRE(batch_sizes[t] > 0, "packed_targets: batch_sizes[%d]", t);
+    m.off[t + 1] = m.off[t] + batch_sizes[t];
+    m.tf[t] = 1;
+  }
+  m.N = m.off[steps];
+  return packed_targets(m, captions, T, out, S(stream));
+}
+
+int capnet_pack_tensors(int n, float* const* tensors, const long* numel, float* flat,
+                        int direction, float scale, capnet_stream_t stream) {
+  return pack_tensors(n, tensors, numel, flat, direction, scale, S(stream));
 }
 
 int capnet_clamp(float* x, long n, float lo, float hi, capnet_stream_t stream) {

@@ -44,7 +44,9 @@ int trunk_num_convs(const Trunk* t);
 int trunk_final_side(const Trunk* t);
 int trunk_conv_shape(const Trunk* t, int i, int* cout, int* cin, int* k, int* stride, int* kw);
 double trunk_flops(const Trunk* t);
-int trunk_forward(const Trunk* t, const float* images_nchw, const float* const* w_packed,
+int trunk_set_timing(Trunk* t, int enable);
+int trunk_collect_timing(Trunk* t, double* conv_ms, long* conv_launches, double* conv_flops);
+int trunk_forward(Trunk* t, const float* images_nchw, const float* const* w_packed,
                   const float* const* bn_gamma, const float* const* bn_beta,
                   float* const* bn_rmean, float* const* bn_rvar, int train, float momentum,
                   float eps, float* workspace, float* out_pooled, float* out_map,
@@ -65,6 +67,8 @@ int gather_inputs(const long long* captions, int T, const float* features, const
                   int* err_flag, hipStream_t stream);
 int embedding_fwd(const long long* idx, int n, const float* emb, int E, int V, float* out,
                   int* err_flag, hipStream_t stream);
+int packed_targets(const SeqMeta& m, const long long* captions, int T, long long* out,
+                   hipStream_t stream);
 int vec_add(const float* a, const float* b, float* out, int n, hipStream_t stream);
 int lstm_pointwise_fwd(float* pre, const float* c_prev, float* c_out, float* h_out, int b, int H,
                        int gi, int gf, int go, int gg, int tanh_out, hipStream_t stream);
@@ -87,6 +91,8 @@ int xent_bwd(const float* logits, long ld, int N, int V, const long long* target
 int clamp_adam(int n_tensors, float* const* params, float* const* grads, float* const* exp_avg,
                float* const* exp_avg_sq, const long* numel, const int* step, float lr, float b1,
                float b2, float eps, float clip, int write_grad, hipStream_t stream);
+int pack_tensors(int n_tensors, float* const* tensors, const long* numel, float* flat, int dir,
+                 float scale, hipStream_t stream);
 int clamp_inplace(float* x, long n, float lo, float hi, hipStream_t stream);
 int bn1d_fwd(const float* x, int B, int C, const float* gamma, const float* beta, float* rmean,
              float* rvar, int train, float momentum, float eps, float* y, float* save_mean,

@@ -192,6 +192,61 @@ int clamp_adam(int n_tensors, float* const* params, float* const* grads, float* 
   return kOk;
 }
 
+// ---- flat gradient buffer: gather many tensors into one (for ONE RCCL all-reduce) and back --
+struct PackTable {
+  float* t[kAdamMaxTensors];
+  long n[kAdamMaxTensors];
+  long flat_off[kAdamMaxTensors];
+  int chunk_start[kAdamMaxTensors + 1];
+  int count;
+};
+
+// dir 0: flat[off + i] = t[i] ; dir 1: t[i] = flat[off + i] * scale
+__global__ __launch_bounds__(256) void pack_kernel(PackTable t, float* __restrict__ flat, int dir,
+                                                   float scale) {
+  int ti = 0;
+  const int blk = blockIdx.x;
+  while (ti + 1 < t.count && blk >= t.chunk_start[ti + 1]) ++ti;
+  const long base = (long)(blk - t.chunk_start[ti]) * kAdamChunk;
+  float* __restrict__ x = t.t[ti];
+  float* __restrict__ f = flat + t.flat_off[ti];
+  const long n = t.n[ti];
+  for (int k = 0; k < kAdamChunk / 256; ++k) {
+    const long i = base + k * 256 + threadIdx.x;
+    if (i >= n) break;
+    if (dir == 0) f[i] = x[i];
+    else x[i] = f[i] * scale;
+  }
+}
+
+int pack_tensors(int n_tensors, float* const* tensors, const long* numel, float* flat, int dir,
+                 float scale, hipStream_t stream) {
+  CAPNET_REQUIRE(n_tensors >= 0 && (n_tensors == 0 || (tensors && numel && flat)),
+                 "pack_tensors: bad argument");
+  int i = 0;
+  long off = 0;
+  while (i < n_tensors) {
+    PackTable t;
+    t.count = 0;
+    int chunks = 0;
+    while (i < n_tensors && t.count < kAdamMaxTensors) {
+      CAPNET_REQUIRE(numel[i] >= 0 && (numel[i] == 0 || tensors[i]), "pack_tensors: tensor %d", i);
+      if (numel[i] == 0) { ++i; continue; }
+      const int k = t.count++;
+      t.t[k] = tensors[i]; t.n[k] = numel[i]; t.flat_off[k] = off;
+      t.chunk_start[k] = chunks;
+      chunks += cdiv(numel[i], kAdamChunk);
+      off += numel[i];
+      ++i;
+    }
+    t.chunk_start[t.count] = chunks;
+    if (t.count == 0) break;
+    hipLaunchKernelGGL(pack_kernel, dim3(chunks), dim3(256), 0, stream, t, flat, dir, scale);
+  }
+  CAPNET_LAUNCH_CHECK();
+  return kOk;
+}
+
 // ---- stand-alone element-wise clamp (utils.clip_gradient with a foreign optimiser) -----------
 __global__ __launch_bounds__(256) void clamp_kernel(float* __restrict__ x, long n, float lo,
                                                     float hi) {

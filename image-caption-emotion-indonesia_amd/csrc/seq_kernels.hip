@@ -134,6 +134,26 @@ int embedding_fwd(const long long* idx, int n, const float* emb, int E, int V, f
   return kOk;
 }
 
+// ---- pack_padded_sequence(captions, lengths, batch_first=True)[0] for int64 captions ---------
+__global__ __launch_bounds__(256) void packed_targets_kernel(SeqMeta m,
+                                                             const long long* __restrict__ captions,
+                                                             int T, long long* __restrict__ out) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= m.N) return;
+  int t = 0;
+  while (t + 1 < m.steps && r >= m.off[t + 1]) ++t;
+  out[r] = captions[(long)(r - m.off[t]) * T + t];
+}
+
+int packed_targets(const SeqMeta& m, const long long* captions, int T, long long* out,
+                   hipStream_t stream) {
+  CAPNET_REQUIRE(captions && out && m.steps <= T, "packed_targets: bad argument");
+  hipLaunchKernelGGL(packed_targets_kernel, dim3(cdiv(m.N, 256)), dim3(256), 0, stream, m, captions,
+                     T, out);
+  CAPNET_LAUNCH_CHECK();
+  return kOk;
+}
+
 // out = a + b
 __global__ void vec_add_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                float* __restrict__ out, int n) {

@@ -33,6 +33,11 @@ struct Trunk {
   size_t off_x[2], off_y1, off_y2, off_y3, off_d, off_part, off_ss, total_floats;
   std::vector<size_t> ss_off;  // per conv: offset of [scale | shift] (2*Cout floats)
   int final_side;
+  // optional per-convolution hipEvent timing (bench.py roofline): pairs recorded on the launch
+  // stream around every conv kernel while enabled, summed by trunk_collect_timing
+  bool timing = false;
+  std::vector<hipEvent_t> ev;
+  double timed_flops = 0;
 };
 
 static int round_up(int v, int m) { return (v + m - 1) / m * m; }
@@ -103,7 +108,37 @@ int trunk_create(int B, int H, int W, Trunk** out) {
   return kOk;
 }
 
-void trunk_destroy(Trunk* t) { delete t; }
+void trunk_destroy(Trunk* t) {
+  if (!t) return;
+  for (hipEvent_t e : t->ev) (void)hipEventDestroy(e);
+  delete t;
+}
+
+int trunk_set_timing(Trunk* t, int enable) {
+  CAPNET_REQUIRE(t != nullptr, "trunk_set_timing: null");
+  t->timing = enable != 0;
+  return kOk;
+}
+
+// Synchronises on the recorded events; returns total conv-kernel ms, launches and flops since
+// the last collect.
+int trunk_collect_timing(Trunk* t, double* conv_ms, long* conv_launches, double* conv_flops) {
+  CAPNET_REQUIRE(t && conv_ms && conv_launches && conv_flops, "trunk_collect_timing: null");
+  double ms = 0;
+  for (size_t i = 0; i + 1 < t->ev.size(); i += 2) {
+    CAPNET_HIP_CHECK(hipEventSynchronize(t->ev[i + 1]));
+    float e = 0;
+    CAPNET_HIP_CHECK(hipEventElapsedTime(&e, t->ev[i], t->ev[i + 1]));
+    ms += e;
+  }
+  *conv_ms = ms;
+  *conv_launches = (long)(t->ev.size() / 2);
+  *conv_flops = t->timed_flops;
+  for (hipEvent_t e : t->ev) (void)hipEventDestroy(e);
+  t->ev.clear();
+  t->timed_flops = 0;
+  return kOk;
+}
 size_t trunk_workspace_bytes(const Trunk* t) { return t->total_floats * sizeof(float); }
 int trunk_num_convs(const Trunk* t) { return (int)t->convs.size(); }
 int trunk_final_side(const Trunk* t) { return t->final_side; }
@@ -124,7 +159,7 @@ double trunk_flops(const Trunk* t) {
 
 namespace {
 struct Ctx {
-  const Trunk* t;
+  Trunk* t;
   const float* const* w;
   const float* const* gamma;
   const float* const* beta;
@@ -146,9 +181,21 @@ int conv_bn(const Ctx& c, int i, const float* x, long sxb, long sxh, long sxw, l
   const int tile = conv_auto_tile((int)M, d.Cout);
   float* psum = c.ws + c.t->off_part;
   float* psq = psum + (size_t)conv_tiles_m((int)M, tile) * d.Cout;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (c.t->timing) {
+    CAPNET_HIP_CHECK(hipEventCreate(&e0));
+    CAPNET_HIP_CHECK(hipEventCreate(&e1));
+    CAPNET_HIP_CHECK(hipEventRecord(e0, c.s));
+  }
   int rc = conv2d_fwd(x, sxb, sxh, sxw, sxc, c.w[i], d.Kw, y, in_scale, in_shift, relu_in,
                       c.train ? psum : nullptr, c.train ? psq : nullptr, c.t->B, d.H, d.W, d.Cin,
                       d.Cout, d.k, d.k, d.stride, d.pad, tile, c.s);
+  if (c.t->timing) {
+    CAPNET_HIP_CHECK(hipEventRecord(e1, c.s));
+    c.t->ev.push_back(e0);
+    c.t->ev.push_back(e1);
+    c.t->timed_flops += 2.0 * (double)M * d.Cout * d.k * d.k * d.Cin;
+  }
   if (rc) return rc;
   if (c.train)
     return bn_finalize(psum, psq, conv_tiles_m((int)M, tile), d.Cout, M, c.gamma[i], c.beta[i],
@@ -158,7 +205,7 @@ int conv_bn(const Ctx& c, int i, const float* x, long sxb, long sxh, long sxw, l
 }
 }  // namespace
 
-int trunk_forward(const Trunk* t, const float* images_nchw, const float* const* w_packed,
+int trunk_forward(Trunk* t, const float* images_nchw, const float* const* w_packed,
                   const float* const* bn_gamma, const float* const* bn_beta,
                   float* const* bn_rmean, float* const* bn_rvar, int train, float momentum,
                   float eps, float* workspace, float* out_pooled, float* out_map,

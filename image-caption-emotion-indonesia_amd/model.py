@@ -231,16 +231,26 @@ class EncoderCNN(nn.Module):
         self.linear = Linear(2048, embed_size)
         self.bn = _BN1d(embed_size, momentum=0.01)
         self._runner = [None]  # not a submodule
+        # optional callable run between the frozen trunk and the trainable head: a data-parallel
+        # optimiser uses it to make the compute stream wait for the previous step's update,
+        # which it overlapped with this step's trunk forward (capnet.parallel)
+        self.pre_head_hook = None
 
     def _trunk(self):
         if self._runner[0] is None:
             self._runner[0] = _TrunkRunner(self.resnet)
         return self._runner[0]
 
-    def forward(self, images):
+    def trunk_features(self, images):
+        """children[:-1] of the ResNet under no_grad (model.py:23-25): pooled [B, 2048]."""
         with torch.no_grad():
             features, _ = self._trunk().forward(images, self.training, True, False)
-        features = features.reshape(features.size(0), -1)
+        return features.reshape(features.size(0), -1)
+
+    def forward(self, images):
+        features = self.trunk_features(images)
+        if self.pre_head_hook is not None:
+            self.pre_head_hook()
         features = self.bn(self.linear(features))
         return features
 
@@ -251,6 +261,14 @@ class EncoderCNN(nn.Module):
 def _draw_tf_mask(n_steps, teacher_forcing_ratio):
     """One random.random() draw per time step, in step order (stylenet/model.py:181)."""
     return [random.random() < teacher_forcing_ratio for _ in range(n_steps)]
+
+
+def _resolve_tf_mask(tf_mask, n_steps, teacher_forcing_ratio):
+    if tf_mask is None:
+        return _draw_tf_mask(n_steps, teacher_forcing_ratio)
+    if len(tf_mask) < n_steps:
+        raise CapnetError("tf_mask has %d entries, %d steps needed" % (len(tf_mask), n_steps))
+    return [bool(x) for x in tf_mask[:n_steps]]
 
 
 def _dropout_seed(training, p):
@@ -350,13 +368,16 @@ class DecoderFactoredLSTM(nn.Module):
                 lengths,
                 features=None,
                 teacher_forcing_ratio=0.8,
-                mode='factual'):
+                mode='factual',
+                tf_mask=None):
+        """tf_mask (extension): explicit per-step teacher-forcing decisions; by default they
+        are drawn from the global `random` module, one per step, as the reference does."""
         batch_sizes = ops.batch_sizes_from_lengths(lengths)
         weights = self._weights(mode)
         cfg = {
             "cell": ops.CELL_FACTORED,
             "batch_sizes": batch_sizes,
-            "tf_mask": _draw_tf_mask(len(batch_sizes), teacher_forcing_ratio),
+            "tf_mask": _resolve_tf_mask(tf_mask, len(batch_sizes), teacher_forcing_ratio),
             "hidden_size": self.hidden_size,
             "factored_size": self.factored_size,
             "dropout": self.dropout.p if self.training else 0.0,

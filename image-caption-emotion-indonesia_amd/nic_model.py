@@ -8,8 +8,8 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .model import (Dropout, Embedding, EncoderCNN, Linear, _draw_tf_mask,  # noqa: F401
-                    _dropout_seed)
+from .model import (Dropout, Embedding, EncoderCNN, Linear, _dropout_seed,  # noqa: F401
+                    _resolve_tf_mask)
 
 
 class LSTMCell(nn.Module):
@@ -71,12 +71,12 @@ class DecoderRNN(nn.Module):
         h_t, c_t = self.lstm(embedded, states)
         return h_t, (h_t, c_t)
 
-    def forward(self, captions, lengths, features, teacher_forcing_ratio=0.8):
+    def forward(self, captions, lengths, features, teacher_forcing_ratio=0.8, tf_mask=None):
         batch_sizes = ops.batch_sizes_from_lengths(lengths)
         cfg = {
             "cell": ops.CELL_LSTM,
             "batch_sizes": batch_sizes,
-            "tf_mask": _draw_tf_mask(len(batch_sizes), teacher_forcing_ratio),
+            "tf_mask": _resolve_tf_mask(tf_mask, len(batch_sizes), teacher_forcing_ratio),
             "hidden_size": self.hidden_size,
             "dropout": self.dropout.p if self.training else 0.0,
             "seed": _dropout_seed(self.training, self.dropout.p),

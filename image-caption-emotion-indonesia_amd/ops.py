@@ -125,6 +125,35 @@ def lstm_pointwise(pre, c_prev, cell):
     return h, c
 
 
+def packed_targets(captions, lengths):
+    """pack_padded_sequence(captions, lengths, batch_first=True)[0] for int64 captions."""
+    _need_cuda(captions)
+    captions = _c(captions)
+    bs = batch_sizes_from_lengths(lengths)
+    if bs[0] != captions.shape[0] or len(bs) > captions.shape[1]:
+        raise CapnetError("packed_targets: lengths do not match captions %s" % (tuple(captions.shape),))
+    out = torch.empty(sum(bs), dtype=torch.int64, device=captions.device)
+    check(_lib.lib().capnet_packed_targets(ptr(captions), captions.shape[1], len(bs), int_array(bs),
+                                           ptr(out), current_stream()), "capnet_packed_targets")
+    return out
+
+
+def pack_tensors(tensors, flat, unpack=False, scale=1.0):
+    """Gather `tensors` into `flat` (or scatter back, scaled)."""
+    n = len(tensors)
+    if n == 0:
+        return
+    _need_cuda(flat, *tensors)
+    numel = (C.c_long * n)(*[t.numel() for t in tensors])
+    if sum(t.numel() for t in tensors) > flat.numel():
+        raise CapnetError("pack_tensors: flat buffer too small")
+    for t in tensors:
+        if not t.is_contiguous():
+            raise CapnetError("pack_tensors: tensors must be contiguous")
+    check(_lib.lib().capnet_pack_tensors(n, ptr_array(tensors), numel, ptr(flat), int(unpack),
+                                         float(scale), current_stream()), "capnet_pack_tensors")
+
+
 def pack_conv_weight(w_oihw, row_stride):
     _need_cuda(w_oihw)
     w = _c(w_oihw)

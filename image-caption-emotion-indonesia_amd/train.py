@@ -1,0 +1,104 @@
+"""The training loop of the reference on the MI355X kernels.
+
+  train_step     one iteration of the bodies of train_factual / train_emotion
+                 (stylenet/train_multitask.py:373-389, 527-537; nic/train_transfer_fac.py:252-296)
+  train_factual  stylenet/train_multitask.py:364-408
+  train_emotion  stylenet/train_multitask.py:511-557
+Same order of operations: targets -> encoder -> decoder -> CrossEntropyLoss -> zero_grad ->
+backward -> clip_gradient -> optimizer.step. The loss stays on the device; `.item()` is taken
+once per log interval instead of every step (the reference syncs every step, :393,396).
+"""
+import random
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .utils import AverageMeter, clip_gradient
+
+
+class CrossEntropyLoss(nn.Module):
+    """nn.CrossEntropyLoss() (mean reduction) on the fused HIP softmax+NLL kernels."""
+
+    def forward(self, outputs, targets):
+        return ops.cross_entropy(outputs, targets)
+
+
+def train_step(encoder, decoder, optimizer, criterion, images, captions, lengths, grad_clip,
+               mode=None, zero_encoder_grad=True, teacher_forcing_ratio=0.8, tf_mask=None,
+               loss_scale=None):
+    """One optimisation step; returns the (device) loss tensor of this batch.
+
+    mode=None: factual step (decoder called without `mode`, both modules zero_grad'ed).
+    mode='happy'|...: emotion step; the reference leaves encoder.zero_grad() commented out
+    there (train_multitask.py:534) -> pass zero_encoder_grad=False to reproduce that.
+    loss_scale: data-parallel weight N_rank/N_global applied to the back-propagated loss.
+    """
+    targets = ops.packed_targets(captions, lengths)
+    features = encoder(images)
+    kw = {}
+    if mode is not None:
+        kw["mode"] = mode
+    if tf_mask is not None:
+        kw["tf_mask"] = tf_mask
+    outputs = decoder(captions, lengths, features, teacher_forcing_ratio=teacher_forcing_ratio, **kw)
+    loss = criterion(outputs, targets)
+    decoder.zero_grad()
+    if zero_encoder_grad:
+        encoder.zero_grad()
+    (loss if loss_scale is None else loss * loss_scale).backward()
+    clip_gradient(optimizer, grad_clip)
+    optimizer.step()
+    return loss.detach()
+
+
+def _drain(pending, meter):
+    for loss, n in pending:
+        meter.update(loss.item(), n)
+    del pending[:]
+
+
+def train_factual(encoder, decoder, optimizer, criterion, data_loader, log_step, grad_clip,
+                  device=None):
+    decoder.train()
+    encoder.train()
+    losses = AverageMeter()
+    pending = []
+    device = device or next(decoder.parameters()).device
+    for i, (images, captions, lengths, all_captions) in enumerate(data_loader):
+        images = images.to(device, non_blocking=True)
+        captions = captions.to(device, non_blocking=True)
+        loss = train_step(encoder, decoder, optimizer, criterion, images, captions, lengths,
+                          grad_clip)
+        pending.append((loss, sum(lengths)))
+        if i % log_step == 0:
+            _drain(pending, losses)
+            ops.check_device_errors()
+            print("""Step [{}/{}], [FAC], Loss: {:.4f}""".format(i, len(data_loader), losses.val))
+    _drain(pending, losses)
+    ops.check_device_errors()
+    return losses.avg
+
+
+def train_emotion(encoder, decoder, optimizer, criterion, data_loaders, tags, log_step,
+                  grad_clip, device=None):
+    decoder.train()
+    encoder.train()
+    losses = [AverageMeter() for _ in range(len(tags))]
+    device = device or next(decoder.parameters()).device
+    for j in random.sample([i for i in range(len(tags))], len(tags)):
+        pending = []
+        for i, (images, captions, lengths, all_captions) in enumerate(data_loaders[j]):
+            images = images.to(device, non_blocking=True)
+            captions = captions.to(device, non_blocking=True)
+            loss = train_step(encoder, decoder, optimizer, criterion, images, captions, lengths,
+                              grad_clip, mode=tags[j], zero_encoder_grad=False)
+            pending.append((loss, sum(lengths)))
+            if i % log_step == 0:
+                _drain(pending, losses[j])
+                ops.check_device_errors()
+                print("""Step [{}/{}], [{}], Loss: {:.4f}""".format(
+                    i, len(data_loaders[j]), tags[j][:3].upper(), losses[j].val))
+        _drain(pending, losses[j])
+    ops.check_device_errors()
+    return [l.avg for l in losses]

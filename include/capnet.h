@@ -78,6 +78,12 @@ int capnet_trunk_forward(const capnet_trunk_t* t, const float* images_nchw,
                          float* const* bn_running_var, int train, float momentum, float eps,
                          void* workspace, float* out_pooled, float* out_map,
                          capnet_stream_t stream);
+/* Per-convolution hipEvent timing for bench.py's roofline: while enabled, every conv kernel
+ * launched by capnet_trunk_forward is bracketed by two events on the launch stream;
+ * collect synchronises on them and returns the totals since the previous collect. */
+int capnet_trunk_set_timing(capnet_trunk_t* t, int enable);
+int capnet_trunk_collect_timing(capnet_trunk_t* t, double* conv_ms, long* conv_launches,
+                                double* conv_flops);
 /* OIHW (torch Conv2d.weight) -> packed rows */
 int capnet_pack_conv_weight(const float* w_oihw, float* out, int Cout, int Cin, int KH, int KW,
                             int row_stride, capnet_stream_t stream);
@@ -178,6 +184,17 @@ int capnet_clamp_adam(int n, float* const* params, float* const* grads, float* c
                       float* const* exp_avg_sq, const long* numel, const int* step, float lr,
                       float beta1, float beta2, float eps, float clip, int write_grad,
                       capnet_stream_t stream);
+
+/* targets = pack_padded_sequence(captions, lengths, batch_first=True)[0]
+ * (stylenet/train_multitask.py:377-379); batch_sizes is a host array. out: [sum(batch_sizes)]. */
+int capnet_packed_targets(const long long* captions, int T, int steps, const int* batch_sizes,
+                          long long* out, capnet_stream_t stream);
+
+/* Data-parallel plumbing (no reference counterpart: the reference is single-device): gather
+ * n gradient tensors into one flat buffer (direction 0) for ONE RCCL all-reduce, and scatter
+ * it back multiplied by `scale` (direction 1). Host arrays of device pointers / sizes. */
+int capnet_pack_tensors(int n, float* const* tensors, const long* numel, float* flat,
+                        int direction, float scale, capnet_stream_t stream);
 
 /* x[i] = min(max(x[i], lo), hi): utils.clip_gradient alone (stylenet/utils.py:57-60). */
 int capnet_clamp(float* x, long n, float lo, float hi, capnet_stream_t stream);
