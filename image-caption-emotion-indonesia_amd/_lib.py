@@ -38,6 +38,10 @@ SIGNATURES = {
     "capnet_adaptive_pool_replicate": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "capnet_conv2d_fwd": (_i, [_vp, _l, _l, _l, _l, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _i,
                                _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "capnet_trunk_conv_kmajor": (_i, [_vp, _i]),
+    "capnet_pack_conv_weight_kmajor": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "capnet_conv2d_fwd_kmajor": (_i, [_vp, _l, _l, _l, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _i,
+                                      _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "capnet_conv_tiles_m": (_i, [_i, _i, _i]),
     "capnet_bn_finalize": (_i, [_vp, _vp, _i, _i, _l, _vp, _vp, _vp, _vp, C.c_float, C.c_float,
                                 _vp, _vp, _vp]),

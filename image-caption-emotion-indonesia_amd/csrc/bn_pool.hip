@@ -273,4 +273,34 @@ int pack_conv_weight(const float* w_oihw, float* out, int Cout, int Cin, int KH,
   return kOk;
 }
 
+// OIHW -> K-major [Kw][Cout] (k = (r*KW + s)*Cin + ci), the LDS-DMA friendly image of conv v2
+__global__ void pack_weight_kmajor_kernel(const float* __restrict__ w, float* __restrict__ out,
+                                          int Cout, int Cin, int KH, int KW, int Kw) {
+  const long total = (long)Kw * Cout;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int co = (int)(i % Cout);
+    const int k = (int)(i / Cout);
+    float v = 0.f;
+    if (k < KH * KW * Cin) {
+      const int ci = k % Cin;
+      const int tap = k / Cin;
+      const int s = tap % KW, r = tap / KW;
+      v = w[(((long)co * Cin + ci) * KH + r) * KW + s];
+    }
+    out[i] = v;
+  }
+}
+
+int pack_conv_weight_kmajor(const float* w_oihw, float* out, int Cout, int Cin, int KH, int KW,
+                            int Kw, hipStream_t stream) {
+  CAPNET_REQUIRE(w_oihw && out && Kw >= KH * KW * Cin, "pack_conv_weight_kmajor: bad argument");
+  const long total = (long)Cout * Kw;
+  const int blocks = (int)(total / 256 < 1 ? 1 : (total / 256 > 4096 ? 4096 : total / 256));
+  hipLaunchKernelGGL(pack_weight_kmajor_kernel, dim3(blocks), dim3(256), 0, stream, w_oihw, out,
+                     Cout, Cin, KH, KW, Kw);
+  CAPNET_LAUNCH_CHECK();
+  return kOk;
+}
+
 }  // namespace capnet

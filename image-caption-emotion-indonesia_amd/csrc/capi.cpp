@@ -70,6 +70,21 @@ int capnet_trunk_forward(const capnet_trunk_t* t, const float* images_nchw,
                        bn_bias, bn_running_mean, bn_running_var, train, momentum, eps,
                        reinterpret_cast<float*>(workspace), out_pooled, out_map, S(stream));
 }
+int capnet_trunk_conv_kmajor(const capnet_trunk_t* t, int i) {
+  return trunk_conv_kmajor(reinterpret_cast<const Trunk*>(t), i);
+}
+int capnet_pack_conv_weight_kmajor(const float* w_oihw, float* out, int Cout, int Cin, int KH,
+                                   int KW, int k_rows, capnet_stream_t stream) {
+  return pack_conv_weight_kmajor(w_oihw, out, Cout, Cin, KH, KW, k_rows, S(stream));
+}
+int capnet_conv2d_fwd_kmajor(const float* x, long sxb, long sxh, long sxw, const float* w_kmajor,
+                             int k_rows, float* y, const float* in_scale, const float* in_shift,
+                             int relu_in, float* part_sum, float* part_sq, int B, int H, int W,
+                             int Cin, int Cout, int KH, int KW, int stride, int pad, int tile,
+                             capnet_stream_t stream) {
+  return conv2d_fwd_v2(x, sxb, sxh, sxw, w_kmajor, k_rows, y, in_scale, in_shift, relu_in, part_sum,
+                       part_sq, B, H, W, Cin, Cout, KH, KW, stride, pad, tile, S(stream));
+}
 int capnet_pack_conv_weight(const float* w_oihw, float* out, int Cout, int Cin, int KH, int KW,
                             int row_stride, capnet_stream_t stream) {
   return pack_conv_weight(w_oihw, out, Cout, Cin, KH, KW, row_stride, S(stream));

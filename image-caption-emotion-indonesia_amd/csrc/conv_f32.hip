@@ -31,73 +31,72 @@ struct ConvArgs {
   int tiles_m, tiles_n;
 };
 
-// A-operand loader, channel-contiguous fast path: Cin % BK == 0, sxc == 1, 16-B aligned rows.
+// A-operand loader, channel-contiguous fast path: Cin % BK == 0, sxc == 1, 16-B aligned rows,
+// input addressed with 32-bit element offsets. Loads are unconditional (tap coordinates are
+// clamped into the image, the result is zeroed in store() when the tap is padding), so no
+// wait for memory is ever placed ahead of the MFMAs.
 template <int BR, int BK, int LD>
 struct ConvLoaderFast {
   static constexpr int TPR = BK / 4;
   static constexpr int RPP = kGemmThreads / TPR;
   static constexpr int PASSES = BR / RPP;
-  ConvArgs g;  // by-value copy: uniform fields stay in SGPRs (no kernarg address taken)
-  long boff[PASSES];
+  const float* x;
+  const float* in_scale;
+  const float* in_shift;
+  int H, W, Cin, KW, sxh, sxw, relu;
+  int boff[PASSES];
   int ih0[PASSES], iw0[PASSES];
   float4 v[PASSES];
   float4 sc, sh;
   unsigned ok;  // bit ps: tap in bounds for pass ps
 
-  __device__ __forceinline__ void init(const ConvArgs& g_, int m0) {
-    g = g_;
+  __device__ __forceinline__ void init(const ConvArgs& g, int m0) {
+    x = g.x; in_scale = g.in_scale; in_shift = g.in_shift;
+    H = g.H; W = g.W; Cin = g.Cin; KW = g.KW; sxh = (int)g.sxh; sxw = (int)g.sxw;
+    relu = g.relu_in;
     const int rl = threadIdx.x / TPR;
     const int ohw = g.OH * g.OW;
 #pragma unroll
     for (int ps = 0; ps < PASSES; ++ps) {
       const int m = m0 + rl + ps * RPP;
-      if (m < g.M) {
-        const int b = m / ohw;
-        const int rem = m - b * ohw;
-        const int oh = rem / g.OW;
-        const int ow = rem - oh * g.OW;
-        ih0[ps] = oh * g.stride - g.pad;
-        iw0[ps] = ow * g.stride - g.pad;
-        boff[ps] = (long)b * g.sxb;
-      } else {
-        ih0[ps] = -(1 << 28);  // never in bounds
-        iw0[ps] = 0;
-        boff[ps] = 0;
-      }
+      const int mc = m < g.M ? m : g.M - 1;
+      const int b = mc / ohw;
+      const int rem = mc - b * ohw;
+      const int oh = rem / g.OW;
+      const int ow = rem - oh * g.OW;
+      // rows past M get a coordinate that is out of the image for every tap
+      ih0[ps] = m < g.M ? oh * g.stride - g.pad : -(1 << 20);
+      iw0[ps] = ow * g.stride - g.pad;
+      boff[ps] = b * (int)g.sxb;
     }
   }
   __device__ __forceinline__ void load(int k0) {
     const int kc = threadIdx.x % TPR;
-    const int tap = k0 / g.Cin;
-    const int c = k0 - tap * g.Cin + 4 * kc;
-    const int r = tap / g.KW;
-    const int s = tap - r * g.KW;
+    const int tap = k0 / Cin;
+    const int c = k0 - tap * Cin + 4 * kc;
+    const int r = tap / KW;
+    const int s = tap - r * KW;
     ok = 0;
 #pragma unroll
     for (int ps = 0; ps < PASSES; ++ps) {
       const int ih = ih0[ps] + r, iw = iw0[ps] + s;
-      const bool inb = (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W &&
-                       k0 < g.K;
-      v[ps] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (inb) {
-        v[ps] = *reinterpret_cast<const float4*>(g.x + boff[ps] + (long)ih * g.sxh +
-                                                 (long)iw * g.sxw + c);
-        ok |= 1u << ps;
-      }
+      const bool inb = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+      const int ihc = min(max(ih, 0), H - 1), iwc = min(max(iw, 0), W - 1);
+      v[ps] = *reinterpret_cast<const float4*>(x + (boff[ps] + ihc * sxh + iwc * sxw + c));
+      ok |= (inb ? 1u : 0u) << ps;
     }
-    if (g.in_scale && k0 < g.K) {
-      sc = *reinterpret_cast<const float4*>(g.in_scale + c);
-      sh = *reinterpret_cast<const float4*>(g.in_shift + c);
+    if (in_scale) {
+      sc = *reinterpret_cast<const float4*>(in_scale + c);
+      sh = *reinterpret_cast<const float4*>(in_shift + c);
     }
   }
   __device__ __forceinline__ void store(float* lds) const {
     const int kc = threadIdx.x % TPR, rl = threadIdx.x / TPR;
-    const bool pre = g.in_scale != nullptr;
-    const bool relu = g.relu_in != 0;
+    const bool pre = in_scale != nullptr;
 #pragma unroll
     for (int ps = 0; ps < PASSES; ++ps) {
       float4 t = v[ps];
-      if (pre && ((ok >> ps) & 1u)) {
+      if (pre) {
         t.x = fmaf(t.x, sc.x, sh.x);
         t.y = fmaf(t.y, sc.y, sh.y);
         t.z = fmaf(t.z, sc.z, sh.z);
@@ -109,6 +108,7 @@ struct ConvLoaderFast {
           t.w = fmaxf(t.w, 0.f);
         }
       }
+      t = mask4(t, ((ok >> ps) & 1u) ? 4 : 0);
       float* d = lds + (4 * kc) * LD + rl + ps * RPP;
       d[0 * LD] = t.x;
       d[1 * LD] = t.y;
@@ -278,7 +278,7 @@ int conv2d_fwd(const float* x, long sxb, long sxh, long sxw, long sxc, const flo
   CAPNET_REQUIRE((part_sum == nullptr) == (part_sq == nullptr), "conv2d_fwd: stats pair");
   g.relu_in = relu_in;
   const bool fast = (Cin % 16 == 0) && sxc == 1 && (sxw % 4 == 0) && (sxh % 4 == 0) &&
-                    (sxb % 4 == 0) && aligned16(x) &&
+                    (sxb % 4 == 0) && aligned16(x) && ((long)Bn * sxb < (1L << 31)) &&
                     (!in_scale || (aligned16(in_scale) && aligned16(in_shift)));
   if (tile == 0) tile = conv_auto_tile(g.M, Cout);
   if (tile == 128) launch_conv<128, 128>(g, fast, stream);

@@ -1,0 +1,354 @@
+// Implicit-GEMM convolution, second generation: built around one measured fact about gfx950 --
+// v_mfma_f32_32x32x2_f32 runs on the SAME pipe as the f32 VALU (a co-resident wave's VALU work
+// adds to MFMA time instead of hiding under it; tools/native/coexec.hip measures 2.31 ms MFMA
+// + 0.88 ms VALU = 3.01 ms together). So the k-loop is written to issue almost no VALU:
+//   * weights are pre-packed K-MAJOR ([Kw][Cout]) and streamed straight into LDS by LDS-DMA
+//     (global_load_lds_dwordx4): no VGPRs, no ds_write, no address arithmetic in the loop;
+//   * activations are fetched with buffer_load_dwordx4 whose per-lane byte offset is constant
+//     for a whole filter tap and whose k advance is a scalar soffset;
+//   * the previous layer's BatchNorm+ReLU and the zero padding are 2 v_pk_fma + 4 v_med3 per
+//     float4 (v_med3(x, 0, hi) with hi = +inf / 0 is ReLU and the padding mask in one op);
+//   * every LDS address is one per-thread base + an immediate (k-loop unrolled over the two
+//     LDS stages), fragments for k-step j+1 are read while the MFMAs of step j run.
+// Same contract as conv_f32.hip (raw NHWC output + per-workgroup column sums for the batch
+// statistics); requires Cin % 16 == 0, channel-contiguous input and Cout % BN == 0.
+#include "common.h"
+#include "mfma_core.h"
+#include "kernels.h"
+
+namespace capnet {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct ConvArgs2 {
+  const float* x;
+  const float* wk;  // [Kw][Cout]
+  float* y;
+  const float* in_scale;
+  const float* in_shift;
+  float* part_sum;
+  float* part_sq;
+  int H, W, Cin, OH, OW, Cout, KW, stride, pad;
+  int sxb, sxh, sxw;
+  int M, Kw;
+  int relu_in;
+  int tiles_m, tiles_n;
+  unsigned x_bytes, ss_bytes;
+};
+
+// LDS-DMA of 16 B per lane: LDS[m0_base + 16*lane] = *(sbase + voff). Inline asm on purpose:
+// with the builtin, hipcc cannot tell the DMA's LDS destination from the stage being read and
+// puts s_waitcnt vmcnt(0) in front of every ds_read of the k-loop (measured: the wait sat
+// right before the MFMAs). An asm DMA is invisible to its bookkeeping; it is ordered by hand:
+// it is issued BEFORE the tile's buffer loads, vmcnt retires in issue order, so once store()
+// has consumed those loads the DMA has landed, and the __syncthreads() that follows publishes
+// it to the other waves.
+__device__ __forceinline__ void glds16(const float* sbase, int voff_bytes, unsigned lds_byte_addr) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %3\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff_bytes), "s"(lds_byte_addr), "s"(sbase)
+      : "memory");
+}
+
+// 16-B global load, address = uniform 64-bit base (SGPR pair) + per-lane 32-bit byte offset.
+// Inline asm for the same reason as glds16: hipcc's own loads in this loop got 64-bit VALU
+// address arithmetic and an s_waitcnt vmcnt(0) that drained the LDS-DMA before they issued.
+// The result is NOT valid until wait_loads() (vmcnt is counted by hand).
+__device__ __forceinline__ void gload16(f32x4& dst, const float* sbase, unsigned voff_bytes) {
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff_bytes), "s"(sbase) : "memory");
+}
+
+template <int BM, int BN>
+__global__ __launch_bounds__(kGemmThreads) void conv_f32_v2_kernel(ConvArgs2 g) {
+  constexpr int BK = 16;
+  constexpr int LDA = BM + 4;
+  constexpr int A_ST = BK * LDA;  // floats per A stage (k-major, padded: transposing writes)
+  constexpr int B_ST = BK * BN;   // floats per B stage (k-major, unpadded: filled by LDS-DMA)
+  constexpr int MT = BM / 64, NT = BN / 64;
+  constexpr int PASSES = BM / 64;  // A rows per thread (4 threads per row)
+  constexpr int LPR = BN / 4;      // lanes per k-row of the B tile
+  constexpr int RPI = 64 / LPR;    // k-rows per DMA instruction
+  constexpr int NI = BK / RPI / 4; // DMA instructions per wave and tile
+  static_assert(NI >= 1, "B tile too small for 4 waves");
+  __shared__ __attribute__((aligned(16))) float lds[2 * A_ST + 2 * B_ST];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+  const int nwg = g.tiles_m * g.tiles_n;
+  const int id = xcd_remap(blockIdx.x, nwg);
+  const int tm = id / g.tiles_n, tn = id - tm * g.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  // ---- A staging geometry (fixed per thread) ----
+  const int kc = tid & 3, rl = tid >> 2;
+  int boff[PASSES], ih0[PASSES], iw0[PASSES];
+  {
+    const int ohw = g.OH * g.OW;
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+      const int m = m0 + rl + ps * 64;
+      const int mc = m < g.M ? m : g.M - 1;
+      const int b = mc / ohw;
+      const int rem = mc - b * ohw;
+      const int oh = rem / g.OW;
+      const int ow = rem - oh * g.OW;
+      ih0[ps] = m < g.M ? oh * g.stride - g.pad : -(1 << 20);  // rows past M: never in the image
+      iw0[ps] = ow * g.stride - g.pad;
+      boff[ps] = b * g.sxb + 4 * kc;
+    }
+  }
+  const bool pre = g.in_scale != nullptr;
+  const float inf = __builtin_inff();
+  const float lo = g.relu_in ? 0.f : -inf;  // v_med3(x, lo, hi): relu iff lo == 0
+
+  // need_mask: some staged element must become 0 (padding taps; rows past M in a ragged last
+  // M tile). Otherwise store() issues no VALU at all besides the prologue's fma.
+  const bool need_mask = pre || g.pad > 0 || (g.M % BM) != 0;
+  unsigned voff[PASSES];         // byte offset of this thread's float4 for the current tap
+  float hi[PASSES], lw[PASSES];  // v_med3(x, lw, hi): (lo, +inf) inside the image, (0, 0) outside
+  int tap = 0, c0 = 0;
+  auto set_tap = [&](int t) {
+    const int r = t / g.KW, s = t - r * g.KW;
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+      const int ih = ih0[ps] + r, iw = iw0[ps] + s;
+      const bool inb = (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
+      const int ihc = min(max(ih, 0), g.H - 1), iwc = min(max(iw, 0), g.W - 1);
+      voff[ps] = (unsigned)(boff[ps] + ihc * g.sxh + iwc * g.sxw) * 4u;
+      hi[ps] = inb ? inf : 0.f;
+      lw[ps] = inb ? lo : 0.f;
+    }
+  };
+  set_tap(0);
+
+  // ---- B DMA geometry ----
+  int bsrc[NI];  // byte offset of this lane's 16 B inside the [Kw][Cout] matrix, tile k0 = 0
+#pragma unroll
+  for (int q = 0; q < NI; ++q) {
+    const int krow = (wave * NI + q) * RPI + lane / LPR;
+    bsrc[q] = (krow * g.Cout + n0 + 4 * (lane % LPR)) * 4;   // bytes
+  }
+  const float* wk = g.wk;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const unsigned lds_b0 = __builtin_amdgcn_readfirstlane(
+      (unsigned)(size_t)(__attribute__((address_space(3))) float*)(lds + 2 * A_ST));
+
+  f32x4 av[PASSES];
+  f32x4 scv, shv;
+  auto issue = [&](int stage, int kt) {
+    // B first: an LDS-DMA issued while VGPR-destination loads are outstanding makes hipcc drain them
+    const unsigned bdst = lds_b0 + (unsigned)(stage * B_ST + wave_u * NI * RPI * BN) * 4u;
+    const float* bs = wk + (long)kt * BK * g.Cout;   // uniform: stays in SGPRs
+#pragma unroll
+    for (int q = 0; q < NI; ++q) glds16(bs, bsrc[q], bdst + (unsigned)(q * RPI * BN) * 4u);
+    // uniform base (SGPR pair, advanced by scalar adds) + per-lane 32-bit offset that only
+    // changes with the filter tap: global_load_dwordx4 v, v_off, s[base] -- no VALU per tile
+    const float* xb = g.x + c0;
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) gload16(av[ps], xb, voff[ps]);
+    if (pre) {
+      gload16(scv, g.in_scale + c0, (unsigned)(16 * kc));
+      gload16(shv, g.in_shift + c0, (unsigned)(16 * kc));
+    }
+    // advance (tap, c0) for the next call
+    c0 += BK;
+    if (c0 >= g.Cin) {
+      c0 = 0;
+      ++tap;
+      set_tap(tap);
+    }
+  };
+  // hi/ok of the tile that was LOADED (set_tap above may already have moved on): keep a copy
+  float hi_ld[PASSES], lw_ld[PASSES];
+  auto snapshot = [&]() {
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+      hi_ld[ps] = hi[ps];
+      lw_ld[ps] = lw[ps];
+    }
+  };
+  const int awr = (4 * kc) * LDA + rl;  // A store index inside a stage
+  auto store = [&](int stage) {
+    // every load and DMA of this tile has landed after this wait (vmcnt retires in order); the
+    // "+v" operands make the loaded registers defined HERE for the compiler
+    if (PASSES == 2)
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(av[0]), "+v"(av[PASSES - 1]), "+v"(scv), "+v"(shv)::"memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(av[0]), "+v"(scv), "+v"(shv)::"memory");
+    float* d0 = lds + stage * A_ST + awr;
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+      float x0 = av[ps].x, x1 = av[ps].y, x2 = av[ps].z, x3 = av[ps].w;
+      if (pre) {
+        x0 = fmaf(x0, scv.x, shv.x);
+        x1 = fmaf(x1, scv.y, shv.y);
+        x2 = fmaf(x2, scv.z, shv.z);
+        x3 = fmaf(x3, scv.w, shv.w);
+      }
+      // relu (lw = 0, hi = inf), identity (lw = -inf, hi = inf) or forced zero for padding and
+      // rows past M (lw = hi = 0): one v_med3 per element
+      if (need_mask) {
+        const float h = hi_ld[ps], l = lw_ld[ps];
+        x0 = __builtin_amdgcn_fmed3f(x0, l, h);
+        x1 = __builtin_amdgcn_fmed3f(x1, l, h);
+        x2 = __builtin_amdgcn_fmed3f(x2, l, h);
+        x3 = __builtin_amdgcn_fmed3f(x3, l, h);
+      }
+      float* d = d0 + ps * 64;
+      d[0 * LDA] = x0;
+      d[1 * LDA] = x1;
+      d[2 * LDA] = x2;
+      d[3 * LDA] = x3;
+    }
+  };
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+  const int ard = lh * LDA + wm * (BM / 2) + li;               // A fragment index inside a stage
+  const int brd = 2 * A_ST + lh * BN + wn * (BN / 2) + li;     // B fragment index (stage 0)
+  auto compute = [&](int stage) {
+    const float* As = lds + stage * A_ST + ard;
+    const float* Bs = lds + stage * B_ST + brd;
+    float a0[MT], b0[NT], a1[MT], b1[NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) a0[mt] = As[mt * 32];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) b0[nt] = Bs[nt * 32];
+#pragma unroll
+    for (int j = 0; j < BK / 2; j += 2) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) a1[mt] = As[(2 * j + 2) * LDA + mt * 32];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) b1[nt] = Bs[(2 * j + 2) * BN + nt * 32];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[mt], b0[nt], acc[mt][nt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (j + 2 < BK / 2) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a0[mt] = As[(2 * j + 4) * LDA + mt * 32];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) b0[nt] = Bs[(2 * j + 4) * BN + nt * 32];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[mt], b1[nt], acc[mt][nt], 0, 0, 0);
+    }
+  };
+
+  const int nk = g.Kw / BK;
+  snapshot();
+  issue(0, 0);
+  store(0);
+  __syncthreads();
+  int kt = 0;
+  for (; kt + 2 <= nk; kt += 2) {
+    // tile kt is in stage 0; tile kt+1 is fetched into stage 1 while stage 0 is consumed
+    snapshot();
+    issue(1, kt + 1);
+    compute(0);
+    store(1);
+    __syncthreads();
+    const bool more = kt + 2 < nk;
+    if (more) {
+      snapshot();
+      issue(0, kt + 2);
+    }
+    compute(1);
+    if (more) store(0);
+    __syncthreads();
+  }
+  if (kt < nk) compute(0);  // odd number of k tiles
+
+  // ---- epilogue: raw output + batch-statistics partials ----
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int n = n0 + wn * (BN / 2) + nt * 32 + li;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * (BM / 2) + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m < g.M) g.y[(long)m * g.Cout + n] = acc[mt][nt][r];
+      }
+    }
+  }
+  if (g.part_sum) {
+    using T = TileCfg<BM, BN, BK>;
+    block_col_stats<T>(acc, lds, g.part_sum + (long)tm * g.Cout, g.part_sq + (long)tm * g.Cout,
+                       n0, g.Cout);
+  }
+}
+
+template <int BM, int BN>
+static void launch_v2(ConvArgs2& g, hipStream_t stream) {
+  g.tiles_m = cdiv(g.M, BM);
+  g.tiles_n = g.Cout / BN;
+  hipLaunchKernelGGL((conv_f32_v2_kernel<BM, BN>), dim3(g.tiles_m * g.tiles_n), dim3(kGemmThreads),
+                     0, stream, g);
+}
+
+bool conv_v2_eligible(const float* x, long sxb, long sxh, long sxw, long sxc, int Bn, int Cin,
+                      int Cout, const float* in_scale, const float* in_shift) {
+  return (Cin % 16 == 0) && sxc == 1 && (sxw % 4 == 0) && (sxh % 4 == 0) && (sxb % 4 == 0) &&
+         aligned16(x) && ((long)Bn * sxb * 4 < (1L << 31)) && (Cout % 64 == 0) &&
+         (!in_scale || (aligned16(in_scale) && aligned16(in_shift)));
+}
+
+// wk: weights packed [Kw][Cout] (pack_conv_weight_kmajor). tile: 0 auto, 128, 64, 12864.
+int conv2d_fwd_v2(const float* x, long sxb, long sxh, long sxw, const float* wk, int Kw, float* y,
+                  const float* in_scale, const float* in_shift, int relu_in, float* part_sum,
+                  float* part_sq, int Bn, int H, int W, int Cin, int Cout, int KH, int KW,
+                  int stride, int pad, int tile, hipStream_t stream) {
+  CAPNET_REQUIRE(x && wk && y, "conv2d_fwd_v2: null pointer");
+  CAPNET_REQUIRE(conv_v2_eligible(x, sxb, sxh, sxw, 1, Bn, Cin, Cout, in_scale, in_shift),
+                 "conv2d_fwd_v2: shape/alignment not supported (Cin=%d Cout=%d)", Cin, Cout);
+  CAPNET_REQUIRE(Kw == KH * KW * Cin && aligned16(wk), "conv2d_fwd_v2: packed weight stride");
+  CAPNET_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv2d_fwd_v2: scale/shift pair");
+  CAPNET_REQUIRE((part_sum == nullptr) == (part_sq == nullptr), "conv2d_fwd_v2: stats pair");
+  CAPNET_REQUIRE(in_scale || !relu_in, "conv2d_fwd_v2: relu_in needs a scale/shift prologue");
+  ConvArgs2 g;
+  g.x = x; g.wk = wk; g.y = y;
+  g.in_scale = in_scale; g.in_shift = in_shift;
+  g.part_sum = part_sum; g.part_sq = part_sq;
+  g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.KW = KW; g.stride = stride; g.pad = pad;
+  g.OH = (H + 2 * pad - KH) / stride + 1;
+  g.OW = (W + 2 * pad - KW) / stride + 1;
+  g.sxb = (int)sxb; g.sxh = (int)sxh; g.sxw = (int)sxw;
+  const long M = (long)Bn * g.OH * g.OW;
+  CAPNET_REQUIRE(M < (1L << 31), "conv2d_fwd_v2: too many output pixels");
+  g.M = (int)M;
+  g.Kw = Kw;
+  g.relu_in = relu_in;
+  g.x_bytes = (unsigned)((long)Bn * sxb * 4);
+  g.ss_bytes = (unsigned)(Cin * 4);
+  if (tile == 0) tile = conv_auto_tile(g.M, Cout);
+  if (Cout % 128 != 0 && tile == 128) tile = 12864;
+  if (tile == 128) launch_v2<128, 128>(g, stream);
+  else if (tile == 64) launch_v2<64, 64>(g, stream);
+  else if (tile == 12864) launch_v2<128, 64>(g, stream);
+  else CAPNET_REQUIRE(false, "conv2d_fwd_v2: unknown tile %d", tile);
+  CAPNET_LAUNCH_CHECK();
+  return kOk;
+}
+
+}  // namespace capnet

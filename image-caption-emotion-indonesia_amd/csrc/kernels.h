@@ -16,6 +16,13 @@ int conv2d_fwd(const float* x, long sxb, long sxh, long sxw, long sxc, const flo
                float* part_sum, float* part_sq, int Bn, int H, int W, int Cin, int Cout, int KH,
                int KW, int stride, int pad, int tile, hipStream_t stream);
 int conv_auto_tile(int M, int Cout);
+// conv_f32_v2.hip (weights packed K-major [Kw][Cout])
+bool conv_v2_eligible(const float* x, long sxb, long sxh, long sxw, long sxc, int Bn, int Cin,
+                      int Cout, const float* in_scale, const float* in_shift);
+int conv2d_fwd_v2(const float* x, long sxb, long sxh, long sxw, const float* wk, int Kw, float* y,
+                  const float* in_scale, const float* in_shift, int relu_in, float* part_sum,
+                  float* part_sq, int Bn, int H, int W, int Cin, int Cout, int KH, int KW,
+                  int stride, int pad, int tile, hipStream_t stream);
 int conv_tiles_m(int M, int tile);
 
 // bn_pool.hip
@@ -32,6 +39,8 @@ int bn_relu_maxpool(const float* y, const float* scale, const float* shift, floa
 int global_avgpool(const float* x, float* out, int Bn, int HW, int C, hipStream_t stream);
 int adaptive_pool_replicate(const float* x, float* out, int Bn, int S, int OUT, int C,
                             hipStream_t stream);
+int pack_conv_weight_kmajor(const float* w_oihw, float* out, int Cout, int Cin, int KH, int KW,
+                            int Kw, hipStream_t stream);
 int pack_conv_weight(const float* w_oihw, float* out, int Cout, int Cin, int KH, int KW, int Kw,
                      hipStream_t stream);
 
@@ -43,6 +52,7 @@ size_t trunk_workspace_bytes(const Trunk* t);
 int trunk_num_convs(const Trunk* t);
 int trunk_final_side(const Trunk* t);
 int trunk_conv_shape(const Trunk* t, int i, int* cout, int* cin, int* k, int* stride, int* kw);
+int trunk_conv_kmajor(const Trunk* t, int i);
 double trunk_flops(const Trunk* t);
 int trunk_set_timing(Trunk* t, int enable);
 int trunk_collect_timing(Trunk* t, double* conv_ms, long* conv_launches, double* conv_flops);

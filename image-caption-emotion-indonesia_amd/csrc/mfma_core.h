@@ -34,29 +34,36 @@ struct TileCfg {
   static constexpr int MT = BM / 64;  // 32x32 MFMA tiles per wave along M
   static constexpr int NT = BN / 64;
   static_assert(BM % 64 == 0 && BN % 64 == 0, "wave grid is 2x2 of 32-multiples");
-  static_assert(BK % 8 == 0, "BK");
+  static_assert(BK % 8 == 0, "BK");  // the k loop is unrolled two MFMA k-steps (4 k) at a time
 };
-
-// ---- guarded 4-wide load -------------------------------------------------------------
-// nvalid in [0,4]: number of in-bounds elements starting at p. VEC promises 16-B alignment.
-template <bool VEC>
-__device__ __forceinline__ float4 load4_guard(const float* __restrict__ p, int nvalid) {
-  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (VEC) {
-    if (nvalid >= 4) {
-      v = *reinterpret_cast<const float4*>(p);
-      return v;
-    }
-  }
-  if (nvalid > 0) v.x = p[0];
-  if (nvalid > 1) v.y = p[1];
-  if (nvalid > 2) v.z = p[2];
-  if (nvalid > 3) v.w = p[3];
-  return v;
-}
 
 // ---- operand loaders -----------------------------------------------------------------
 // Logical operand X[R][K]; tile rows [r0, r0+BR), k in [k0, k0+BK).
+//
+// load() only ISSUES global loads (into registers) and records what is valid; store() masks,
+// transforms and writes the LDS image. Nothing in load() may depend on a loaded value: the
+// mainloop calls load(t+1) BEFORE the MFMAs of tile t and store() after them, so any use of
+// the data in load() would put an s_waitcnt vmcnt(0) in front of the matrix work.
+// VEC = true: 16-B aligned rows (ld % 4 == 0, base % 16 == 0); loads are unconditional
+// float4 from a clamped (always in-bounds) address, out-of-range elements are zeroed in
+// store(). VEC = false: element-wise guarded loads (rare: odd leading dimensions).
+
+__device__ __forceinline__ float4 mask4(float4 v, int n) {
+  v.x = n > 0 ? v.x : 0.f;
+  v.y = n > 1 ? v.y : 0.f;
+  v.z = n > 2 ? v.z : 0.f;
+  v.w = n > 3 ? v.w : 0.f;
+  return v;
+}
+
+__device__ __forceinline__ float4 load4_scalar(const float* __restrict__ p, int n) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (n > 0) v.x = p[0];
+  if (n > 1) v.y = p[1];
+  if (n > 2) v.z = p[2];
+  if (n > 3) v.w = p[3];
+  return v;
+}
 
 // K-contiguous storage: X[r][k] = p[r*ld + k]. BK/4 threads cover one row.
 template <int BR, int BK, int LD, bool VEC>
@@ -69,30 +76,36 @@ struct LoaderKContig {
   long ld;
   int R, K, r0;
   float4 v[PASSES];
+  int nv[PASSES];
   __device__ __forceinline__ void init(const float* p_, long ld_, int R_, int K_, int r0_) {
     p = p_; ld = ld_; R = R_; K = K_; r0 = r0_;
   }
   __device__ __forceinline__ void load(int k0) {
     const int kc = threadIdx.x % TPR, rl = threadIdx.x / TPR;
     const int k = k0 + 4 * kc;
+    int kn = K - k;
+    kn = kn < 0 ? 0 : (kn > 4 ? 4 : kn);
+    const int kk = kn > 0 ? k : 0;
 #pragma unroll
     for (int ps = 0; ps < PASSES; ++ps) {
       const int r = r0 + rl + ps * RPP;
-      int nv = K - k;
-      nv = nv < 0 ? 0 : (nv > 4 ? 4 : nv);
-      if (r >= R) nv = 0;
-      v[ps] = load4_guard<VEC>(p + (long)r * ld + k, nv);
+      const bool rv = r < R;
+      const int rr = rv ? r : R - 1;
+      nv[ps] = rv ? kn : 0;
+      if (VEC) v[ps] = *reinterpret_cast<const float4*>(p + (long)rr * ld + kk);
+      else v[ps] = load4_scalar(p + (long)rr * ld + kk, nv[ps]);
     }
   }
   __device__ __forceinline__ void store(float* lds) const {
     const int kc = threadIdx.x % TPR, rl = threadIdx.x / TPR;
 #pragma unroll
     for (int ps = 0; ps < PASSES; ++ps) {
+      const float4 t = mask4(v[ps], nv[ps]);
       float* d = lds + (4 * kc) * LD + rl + ps * RPP;
-      d[0 * LD] = v[ps].x;
-      d[1 * LD] = v[ps].y;
-      d[2 * LD] = v[ps].z;
-      d[3 * LD] = v[ps].w;
+      d[0 * LD] = t.x;
+      d[1 * LD] = t.y;
+      d[2 * LD] = t.z;
+      d[3 * LD] = t.w;
     }
   }
 };
@@ -108,20 +121,25 @@ struct LoaderRContig {
   long ld;
   int R, K, r0;
   float4 v[PASSES];
+  int nv[PASSES];
   __device__ __forceinline__ void init(const float* p_, long ld_, int R_, int K_, int r0_) {
     p = p_; ld = ld_; R = R_; K = K_; r0 = r0_;
   }
   __device__ __forceinline__ void load(int k0) {
     const int rc = threadIdx.x % TPK, kl = threadIdx.x / TPK;
     const int r = r0 + 4 * rc;
+    int rn = R - r;
+    rn = rn < 0 ? 0 : (rn > 4 ? 4 : rn);
+    const int rr = rn > 0 ? r : 0;
 #pragma unroll
     for (int ps = 0; ps < PASSES; ++ps) {
       const int kk = kl + ps * KPP;
       const int k = k0 + kk;
-      int nv = R - r;
-      nv = nv < 0 ? 0 : (nv > 4 ? 4 : nv);
-      if (k >= K || kk >= BK) nv = 0;
-      v[ps] = load4_guard<VEC>(p + (long)k * ld + r, nv);
+      const bool kv = k < K && kk < BK;
+      const int kc = k < K ? k : K - 1;
+      nv[ps] = kv ? rn : 0;
+      if (VEC) v[ps] = *reinterpret_cast<const float4*>(p + (long)kc * ld + rr);
+      else v[ps] = load4_scalar(p + (long)kc * ld + rr, nv[ps]);
     }
   }
   __device__ __forceinline__ void store(float* lds) const {
@@ -129,7 +147,7 @@ struct LoaderRContig {
 #pragma unroll
     for (int ps = 0; ps < PASSES; ++ps) {
       const int kk = kl + ps * KPP;
-      if (kk < BK) *reinterpret_cast<float4*>(lds + kk * LD + 4 * rc) = v[ps];
+      if (kk < BK) *reinterpret_cast<float4*>(lds + kk * LD + 4 * rc) = mask4(v[ps], nv[ps]);
     }
   }
 };
@@ -165,18 +183,38 @@ __device__ __forceinline__ void gemm_block_mainloop(AL& al, BL& bl, int K, float
     }
     const float* As = cur + lh * T::LDA + wm * (T::BM / 2) + li;
     const float* Bs = cur + T::A_ELEMS + lh * T::LDB + wn * (T::BN / 2) + li;
+    // fragments of k-step j+1 are read from LDS while the MFMAs of step j run (two named
+    // register sets, static indexing), so a wave never idles the matrix pipe on LDS latency
+    float a0[T::MT], b0[T::NT], a1[T::MT], b1[T::NT];
 #pragma unroll
-    for (int j = 0; j < T::BK / 2; ++j) {
-      float a[T::MT], b[T::NT];
+    for (int mt = 0; mt < T::MT; ++mt) a0[mt] = As[mt * 32];
 #pragma unroll
-      for (int mt = 0; mt < T::MT; ++mt) a[mt] = As[(2 * j) * T::LDA + mt * 32];
+    for (int nt = 0; nt < T::NT; ++nt) b0[nt] = Bs[nt * 32];
 #pragma unroll
-      for (int nt = 0; nt < T::NT; ++nt) b[nt] = Bs[(2 * j) * T::LDB + nt * 32];
+    for (int j = 0; j < T::BK / 2; j += 2) {
+#pragma unroll
+      for (int mt = 0; mt < T::MT; ++mt) a1[mt] = As[(2 * j + 2) * T::LDA + mt * 32];
+#pragma unroll
+      for (int nt = 0; nt < T::NT; ++nt) b1[nt] = Bs[(2 * j + 2) * T::LDB + nt * 32];
+      __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the MFMAs (hipcc sinks it)
 #pragma unroll
       for (int mt = 0; mt < T::MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < T::NT; ++nt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[mt], b0[nt], acc[mt][nt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (j + 2 < T::BK / 2) {
+#pragma unroll
+        for (int mt = 0; mt < T::MT; ++mt) a0[mt] = As[(2 * j + 4) * T::LDA + mt * 32];
+#pragma unroll
+        for (int nt = 0; nt < T::NT; ++nt) b0[nt] = Bs[(2 * j + 4) * T::LDB + nt * 32];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int mt = 0; mt < T::MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < T::NT; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[mt], b1[nt], acc[mt][nt], 0, 0, 0);
     }
     if (more) {
       al.store(nxt);

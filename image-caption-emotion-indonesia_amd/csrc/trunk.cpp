@@ -23,7 +23,8 @@ struct TrunkConv {
   int Cin, Cout, k, stride, pad;
   int H, W;    // input spatial size
   int OH, OW;  // output spatial size
-  int Kw;      // packed weight row stride
+  int Kw;      // packed K extent (rows of the K-major image / row stride of the row-major one)
+  bool kmajor; // weights packed [Kw][Cout] for conv_f32_v2 (else [Cout][Kw] for conv_f32)
 };
 
 struct Trunk {
@@ -54,6 +55,7 @@ int trunk_create(int B, int H, int W, Trunk** out) {
     c.OH = (h + 2 * pad - k) / stride + 1;
     c.OW = (w + 2 * pad - k) / stride + 1;
     c.Kw = round_up(k * k * cin, 16);
+    c.kmajor = (cin % 16 == 0) && (cout % 64 == 0);
     t->convs.push_back(c);
     return c;
   };
@@ -150,6 +152,10 @@ int trunk_conv_shape(const Trunk* t, int i, int* cout, int* cin, int* k, int* st
   return kOk;
 }
 
+int trunk_conv_kmajor(const Trunk* t, int i) {
+  return (i >= 0 && i < (int)t->convs.size() && t->convs[i].kmajor) ? 1 : 0;
+}
+
 double trunk_flops(const Trunk* t) {
   double f = 0;
   for (auto& c : t->convs)
@@ -187,9 +193,18 @@ int conv_bn(const Ctx& c, int i, const float* x, long sxb, long sxh, long sxw, l
     CAPNET_HIP_CHECK(hipEventCreate(&e1));
     CAPNET_HIP_CHECK(hipEventRecord(e0, c.s));
   }
-  int rc = conv2d_fwd(x, sxb, sxh, sxw, sxc, c.w[i], d.Kw, y, in_scale, in_shift, relu_in,
-                      c.train ? psum : nullptr, c.train ? psq : nullptr, c.t->B, d.H, d.W, d.Cin,
-                      d.Cout, d.k, d.k, d.stride, d.pad, tile, c.s);
+  int rc;
+  if (d.kmajor) {
+    CAPNET_REQUIRE(conv_v2_eligible(x, sxb, sxh, sxw, sxc, c.t->B, d.Cin, d.Cout, in_scale, in_shift),
+                   "trunk: conv %d planned for the K-major kernel but its operands are not eligible", i);
+    rc = conv2d_fwd_v2(x, sxb, sxh, sxw, c.w[i], d.Kw, y, in_scale, in_shift, relu_in,
+                       c.train ? psum : nullptr, c.train ? psq : nullptr, c.t->B, d.H, d.W, d.Cin,
+                       d.Cout, d.k, d.k, d.stride, d.pad, tile, c.s);
+  } else {
+    rc = conv2d_fwd(x, sxb, sxh, sxw, sxc, c.w[i], d.Kw, y, in_scale, in_shift, relu_in,
+                    c.train ? psum : nullptr, c.train ? psq : nullptr, c.t->B, d.H, d.W, d.Cin,
+                    d.Cout, d.k, d.k, d.stride, d.pad, tile, c.s);
+  }
   if (c.t->timing) {
     CAPNET_HIP_CHECK(hipEventRecord(e1, c.s));
     c.t->ev.push_back(e0);

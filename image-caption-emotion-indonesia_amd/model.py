@@ -168,7 +168,8 @@ class _TrunkRunner:
                 if tuple(c.weight.shape) != (cout, cin, k, k) or c.stride != stride:
                     raise CapnetError("conv %d: module shape %s does not match the plan" %
                                       (i, tuple(c.weight.shape)))
-                packed.append(ops.pack_conv_weight(c.weight.detach(), kw))
+                kmajor = bool(L.capnet_trunk_conv_kmajor(plan["handle"], i))
+                packed.append(ops.pack_conv_weight(c.weight.detach(), kw, kmajor=kmajor))
             self.packed, self.packed_key = packed, key
         return self.packed
 

@@ -154,10 +154,16 @@ def pack_tensors(tensors, flat, unpack=False, scale=1.0):
                                          float(scale), current_stream()), "capnet_pack_tensors")
 
 
-def pack_conv_weight(w_oihw, row_stride):
+def pack_conv_weight(w_oihw, row_stride, kmajor=False):
+    """OIHW -> [Cout][row_stride] rows, or (kmajor) the K-major [row_stride][Cout] image."""
     _need_cuda(w_oihw)
     w = _c(w_oihw)
     co, ci, kh, kw = w.shape
+    if kmajor:
+        out = torch.empty((row_stride, co), dtype=torch.float32, device=w.device)
+        check(_lib.lib().capnet_pack_conv_weight_kmajor(ptr(w), ptr(out), co, ci, kh, kw, row_stride,
+                                                        current_stream()), "capnet_pack_conv_weight_kmajor")
+        return out
     out = torch.empty((co, row_stride), dtype=torch.float32, device=w.device)
     check(_lib.lib().capnet_pack_conv_weight(ptr(w), ptr(out), co, ci, kh, kw, row_stride,
                                              current_stream()), "capnet_pack_conv_weight")

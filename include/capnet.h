@@ -84,6 +84,11 @@ int capnet_trunk_forward(const capnet_trunk_t* t, const float* images_nchw,
 int capnet_trunk_set_timing(capnet_trunk_t* t, int enable);
 int capnet_trunk_collect_timing(capnet_trunk_t* t, double* conv_ms, long* conv_launches,
                                 double* conv_flops);
+/* Weight image convolution i expects: 0 = rows [Cout][row_stride] (capnet_pack_conv_weight),
+ * 1 = K-major [row_stride][Cout] (capnet_pack_conv_weight_kmajor; streamed to LDS by LDS-DMA). */
+int capnet_trunk_conv_kmajor(const capnet_trunk_t* t, int i);
+int capnet_pack_conv_weight_kmajor(const float* w_oihw, float* out, int Cout, int Cin, int KH,
+                                   int KW, int k_rows, capnet_stream_t stream);
 /* OIHW (torch Conv2d.weight) -> packed rows */
 int capnet_pack_conv_weight(const float* w_oihw, float* out, int Cout, int Cin, int KH, int KW,
                             int row_stride, capnet_stream_t stream);
@@ -98,6 +103,13 @@ int capnet_conv2d_fwd(const float* x, long sxb, long sxh, long sxw, long sxc,
                       const float* in_shift, int relu_in, float* part_sum, float* part_sq, int B,
                       int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
                       int tile, capnet_stream_t stream);
+/* the low-VALU kernel used for every trunk convolution with Cin % 16 == 0 and Cout % 64 == 0:
+ * NHWC channel-contiguous input, K-major weights, k_rows == KH*KW*Cin */
+int capnet_conv2d_fwd_kmajor(const float* x, long sxb, long sxh, long sxw, const float* w_kmajor,
+                             int k_rows, float* y, const float* in_scale, const float* in_shift,
+                             int relu_in, float* part_sum, float* part_sq, int B, int H, int W,
+                             int Cin, int Cout, int KH, int KW, int stride, int pad, int tile,
+                             capnet_stream_t stream);
 int capnet_conv_tiles_m(int M, int Cout, int tile);
 int capnet_bn_finalize(const float* part_sum, const float* part_sq, int tiles, int C, long count,
                        const float* gamma, const float* beta, float* running_mean,

@@ -95,6 +95,44 @@ def test_conv_fast_path(dev, tile, B, H, W, Cin, Cout, k, stride, pad, pre):
     assert rel_err(psq.sum(0), (ref_nhwc ** 2).sum(0)) < 1e-5
 
 
+@pytest.mark.parametrize("tile", [0, 64, 128, 12864])
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,stride,pad,pre", [
+    (2, 14, 14, 64, 64, 3, 1, 1, True),
+    (3, 9, 11, 32, 128, 3, 2, 1, True),
+    (2, 8, 8, 128, 256, 1, 1, 0, False),      # no prologue, M = 128
+    (3, 7, 7, 128, 128, 1, 1, 0, False),      # no prologue, ragged last M tile (147 rows)
+    (2, 8, 8, 128, 64, 1, 2, 0, True),
+    (2, 6, 6, 48, 192, 3, 1, 1, True),        # 3 k-tiles per tap, odd tile count (27)
+])
+def test_conv_kmajor_lds_dma_path(dev, tile, B, H, W, Cin, Cout, k, stride, pad, pre):
+    """conv_f32_v2: K-major weights by LDS-DMA, saddr loads, med3 mask -- the kernel every trunk
+    convolution except the stem runs on."""
+    g = torch.Generator().manual_seed(B + H + Cin + Cout + k + 1)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) * 0.1
+    scale = torch.rand(Cin, generator=g) - 0.3 if pre else None      # some negative scales
+    shift = torch.randn(Cin, generator=g) if pre else None
+    ref = _conv_ref(x, w, stride, pad, scale, shift, relu=pre)
+    OH, OW = ref.shape[2], ref.shape[3]
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    Kw = k * k * Cin
+    wk = ops.pack_conv_weight(w.to(dev), Kw, kmajor=True)
+    M = B * OH * OW
+    y = torch.full((M, Cout), float("nan"), device=dev)
+    tiles = lib().capnet_conv_tiles_m(M, Cout, tile)
+    psum = torch.zeros(tiles, Cout, device=dev)
+    psq = torch.zeros(tiles, Cout, device=dev)
+    sd = scale.to(dev) if pre else None
+    hd = shift.to(dev) if pre else None
+    check(lib().capnet_conv2d_fwd_kmajor(ptr(xd), H * W * Cin, W * Cin, Cin, ptr(wk), Kw, ptr(y),
+                                         ptr(sd), ptr(hd), int(pre), ptr(psum), ptr(psq), B, H, W,
+                                         Cin, Cout, k, k, stride, pad, tile, current_stream()))
+    ref_nhwc = ref.permute(0, 2, 3, 1).reshape(M, Cout)
+    assert rel_err(y, ref_nhwc) < 3e-6
+    assert rel_err(psum.sum(0), ref_nhwc.sum(0)) < 1e-5
+    assert rel_err(psq.sum(0), (ref_nhwc ** 2).sum(0)) < 1e-5
+
+
 def test_conv_stem_generic_nchw(dev):
     B, H, W = 2, 64, 64
     g = torch.Generator().manual_seed(11)
