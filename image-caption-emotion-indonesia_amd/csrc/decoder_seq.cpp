@@ -123,11 +123,13 @@ int input_chain(const SeqDims& d, const Layout& L, float* sv, int r0, int r1, hi
 size_t seq_saved_floats(const SeqDims& d) { return make_layout(d).total; }
 size_t seq_saved_ints(const SeqDims& d) { return make_layout(d).itotal; }
 
-size_t seq_fwd_scratch_floats(const SeqDims& d) { return (size_t)d.B * d.V + 64; }
+constexpr size_t kSplitKFloats = 32ull * 64 * 2048;  // slabs for the per-step skinny GEMMs (16 MB)
+
+size_t seq_fwd_scratch_floats(const SeqDims& d) { return (size_t)d.B * d.V + 64 + kSplitKFloats; }
 
 size_t seq_bwd_scratch_floats(const SeqDims& d) {
   const size_t N = d.N;
-  size_t n = N * 4 * d.H + N * d.H + 2 * (size_t)d.B * d.H + N * d.E + 256;
+  size_t n = N * 4 * d.H + N * d.H + 2 * (size_t)d.B * d.H + N * d.E + 256 + kSplitKFloats;
   if (d.cell == kCellFactored) n += 2 * N * 4 * d.F;
   return n;
 }
@@ -188,6 +190,7 @@ int seq_forward(const SeqDims& d, const int* batch_sizes, const unsigned char* t
   RC(input_chain(d, L, sv, 0, N, s));
 
   // ---- recurrence
+  float* skws = scratch + (size_t)d.B * d.V + 64;
   for (int t = 0; t < d.steps; ++t) {
     const int b = batch_sizes[t], r0 = off[t];
     if (t > 0) {
@@ -202,8 +205,8 @@ int seq_forward(const SeqDims& d, const int* batch_sizes, const unsigned char* t
         RC(input_chain(d, L, sv, r0, r0 + b, s));
       }
       // G[rows] += h_{t-1} . Wcat^T
-      RC(sgemm(false, true, b, 4 * H, H, h_prev, H, sv + L.Wcat, H, sv + L.G + (size_t)r0 * 4 * H,
-               4 * H, nullptr, 1, 1, 0, 0, 0, 0, 0, s));
+      RC(sgemm_splitk(false, true, b, 4 * H, H, h_prev, H, sv + L.Wcat, H,
+                      sv + L.G + (size_t)r0 * 4 * H, 4 * H, nullptr, 1, skws, kSplitKFloats, s));
     }
     RC(lstm_pointwise_fwd(sv + L.G + (size_t)r0 * 4 * H,
                           t > 0 ? sv + L.Cst + (size_t)off[t - 1] * H : nullptr,
@@ -238,6 +241,7 @@ int seq_backward(const SeqDims& d, const int* batch_sizes, const float* dH, cons
     dA2 = scratch + take((size_t)N * 4 * F);
     dA1 = scratch + take((size_t)N * 4 * F);
   }
+  float* skws = scratch + take(kSplitKFloats);
   const float* sv = saved;
   CAPNET_HIP_CHECK(hipMemsetAsync(dh_rec, 0, (size_t)d.B * H * sizeof(float), s));
   CAPNET_HIP_CHECK(hipMemsetAsync(dc, 0, (size_t)d.B * H * sizeof(float), s));
@@ -251,8 +255,8 @@ int seq_backward(const SeqDims& d, const int* batch_sizes, const float* dH, cons
                           go.gi, go.gf, go.go, go.gg, go.tanh_out, s));
     if (t > 0) {
       // dh_{t-1}[0:b] = dPre_t . Wcat     (rows b..b_{t-1} of step t-1 have no successor)
-      RC(sgemm(false, false, b, H, 4 * H, dPre + (size_t)r0 * 4 * H, 4 * H, sv + L.Wcat, H, dh_rec,
-               H, nullptr, 0, 1, 0, 0, 0, 0, 0, s));
+      RC(sgemm_splitk(false, false, b, H, 4 * H, dPre + (size_t)r0 * 4 * H, 4 * H, sv + L.Wcat, H,
+                      dh_rec, H, nullptr, 0, skws, kSplitKFloats, s));
     }
   }
   // recurrent weight gradient over all steps at once: dWcat = dPre^T . h_{t-1}

@@ -21,6 +21,7 @@ struct GemmArgs {
   long sA, sB, sC, sBias;  // batch strides (elements)
   int accumulate;
   int tiles_m, tiles_n;
+  int splitk, kchunk;  // splitk > 1: blockIdx.y = z*splitk + ks; slice ks writes slab C + ks*M*ldc
 };
 
 template <int BM, int BN, int BK, bool TA, bool TB, bool VEC>
@@ -32,10 +33,12 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_f32_kernel(GemmArgs g) {
   const int id = xcd_remap(blockIdx.x, nwg);
   const int tm = id / g.tiles_n, tn = id - tm * g.tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
-  const int z = blockIdx.y;
-  const float* A = g.A + (long)z * g.sA;
-  const float* B = g.B + (long)z * g.sB;
-  float* C = g.C + (long)z * g.sC;
+  const int z = blockIdx.y / g.splitk, ks = blockIdx.y - z * g.splitk;
+  const int kb = ks * g.kchunk;
+  const int Kloc = min(g.kchunk, g.K - kb);
+  const float* A = g.A + (long)z * g.sA + (TA ? (long)kb * g.lda : (long)kb);
+  const float* B = g.B + (long)z * g.sB + (TB ? (long)kb : (long)kb * g.ldb);
+  float* C = g.C + (long)z * g.sC + (long)ks * g.M * g.ldc;
   const float* bias = g.bias ? g.bias + (long)z * g.sBias : nullptr;
 
   using ALoad = typename std::conditional<TA, LoaderRContig<BM, BK, T::LDA, VEC>,
@@ -44,11 +47,11 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_f32_kernel(GemmArgs g) {
                                           LoaderRContig<BN, BK, T::LDB, VEC>>::type;
   ALoad al;
   BLoad bl;
-  al.init(A, g.lda, g.M, g.K, m0);
-  bl.init(B, g.ldb, g.N, g.K, n0);
+  al.init(A, g.lda, g.M, Kloc, m0);
+  bl.init(B, g.ldb, g.N, Kloc, n0);
 
   f32x16 acc[T::MT][T::NT];
-  gemm_block_mainloop<T>(al, bl, g.K, lds, acc);
+  gemm_block_mainloop<T>(al, bl, Kloc, lds, acc);
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -76,7 +79,7 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_f32_kernel(GemmArgs g) {
 
 template <int BM, int BN, int BK, bool TA, bool TB, bool VEC>
 static void launch_gemm(const GemmArgs& g, int batch, hipStream_t stream) {
-  dim3 grid(g.tiles_m * g.tiles_n, batch);
+  dim3 grid(g.tiles_m * g.tiles_n, batch * g.splitk);
   hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, TA, TB, VEC>), grid, dim3(kGemmThreads), 0,
                      stream, g);
 }
@@ -97,6 +100,24 @@ static void dispatch_layout(const GemmArgs& g, int batch, bool ta, bool tb, bool
 #undef CAPNET_GEMM_CASE
 }
 
+// out[m][n] = sum_ks slab[ks][m][n] + bias[n] (+ out[m][n]); fixed summation order
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab,
+                                                            int splitk, int M, int N,
+                                                            float* __restrict__ out, long ldc,
+                                                            const float* __restrict__ bias,
+                                                            int accumulate) {
+  const long total = (long)M * N;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int m = (int)(i / N), n = (int)(i - (long)m * N);
+    float s = 0.f;
+    for (int k = 0; k < splitk; ++k) s += slab[(long)k * total + i];
+    if (bias) s += bias[n];
+    float* o = out + (long)m * ldc + n;
+    *o = accumulate ? *o + s : s;
+  }
+}
+
 // Tile choice: the chip has 256 CUs and this kernel keeps ~3-4 workgroups per CU resident;
 // prefer the 128x128 tile (best operand reuse) once it alone fills the chip, else 64x64.
 int sgemm(bool ta, bool tb, int M, int N, int K, const float* A, long lda, const float* B,
@@ -115,6 +136,8 @@ int sgemm(bool ta, bool tb, int M, int N, int K, const float* A, long lda, const
   g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.sA = sA; g.sB = sB; g.sC = sC; g.sBias = sBias;
   g.accumulate = accumulate;
+  g.splitk = 1;
+  g.kchunk = K;
   const bool vec = aligned16(A) && aligned16(B) && (lda % 4 == 0) && (ldb % 4 == 0) &&
                    (sA % 4 == 0) && (sB % 4 == 0);
   const long t128 = (long)cdiv(M, 128) * cdiv(N, 128) * batch;
@@ -129,6 +152,48 @@ int sgemm(bool ta, bool tb, int M, int N, int K, const float* A, long lda, const
   } else {
     CAPNET_REQUIRE(false, "sgemm: unknown tile %d", tile);
   }
+  CAPNET_LAUNCH_CHECK();
+  return kOk;
+}
+
+}  // namespace capnet
+
+namespace capnet {
+
+// Skinny products of the recurrence (M <= 64 rows per time step): too few output tiles to fill
+// 256 CUs, so K is split across workgroups into slabs in `ws` and summed in a fixed order.
+// Falls back to sgemm when there are enough tiles or no workspace.
+int sgemm_splitk(bool ta, bool tb, int M, int N, int K, const float* A, long lda, const float* B,
+                 long ldb, float* C, long ldc, const float* bias, int accumulate, float* ws,
+                 size_t ws_floats, hipStream_t stream) {
+  if (M == 0 || N == 0) return kOk;
+  const long tiles = (long)cdiv(M, 64) * cdiv(N, 64);
+  int splitk = 1;
+  if (tiles < 96 && K >= 256) {
+    splitk = (int)(192 / tiles);
+    if (splitk > K / 64) splitk = K / 64;
+    if (splitk > 32) splitk = 32;
+  }
+  while (splitk > 1 && (size_t)splitk * M * N > ws_floats) --splitk;
+  if (splitk <= 1 || !ws)
+    return sgemm(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, 1, 0, 0, 0, 0, 0, stream);
+  CAPNET_REQUIRE(A && B && C, "sgemm_splitk: null operand");
+  GemmArgs g;
+  g.A = A; g.B = B; g.C = ws; g.bias = nullptr;
+  g.M = M; g.N = N; g.K = K;
+  g.lda = lda; g.ldb = ldb; g.ldc = N;
+  g.sA = g.sB = g.sC = g.sBias = 0;
+  g.accumulate = 0;
+  g.splitk = splitk;
+  g.kchunk = cdiv(cdiv(K, splitk), 16) * 16;
+  g.splitk = cdiv(K, g.kchunk);
+  g.tiles_m = cdiv(M, 64);
+  g.tiles_n = cdiv(N, 64);
+  const bool vec = aligned16(A) && aligned16(B) && (lda % 4 == 0) && (ldb % 4 == 0);
+  dispatch_layout<64, 64, 16>(g, 1, ta, tb, vec, stream);
+  const long total = (long)M * N;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)(cdiv(total, 256) > 1024 ? 1024 : cdiv(total, 256))),
+                     dim3(256), 0, stream, ws, g.splitk, M, N, C, ldc, bias, accumulate);
   CAPNET_LAUNCH_CHECK();
   return kOk;
 }

@@ -10,6 +10,10 @@ int sgemm(bool ta, bool tb, int M, int N, int K, const float* A, long lda, const
           long ldb, float* C, long ldc, const float* bias, int accumulate, int batch, long sA,
           long sB, long sC, long sBias, int force_tile, hipStream_t stream);
 
+int sgemm_splitk(bool ta, bool tb, int M, int N, int K, const float* A, long lda, const float* B,
+                 long ldb, float* C, long ldc, const float* bias, int accumulate, float* ws,
+                 size_t ws_floats, hipStream_t stream);
+
 // conv_f32.hip
 int conv2d_fwd(const float* x, long sxb, long sxh, long sxw, long sxc, const float* w_packed,
                int Kw, float* y, const float* in_scale, const float* in_shift, int relu_in,
