@@ -81,9 +81,12 @@ int capnet_conv2d_fwd_kmajor(const float* x, long sxb, long sxh, long sxw, const
                              int k_rows, float* y, const float* in_scale, const float* in_shift,
                              int relu_in, float* part_sum, float* part_sq, int B, int H, int W,
                              int Cin, int Cout, int KH, int KW, int stride, int pad, int tile,
-                             capnet_stream_t stream) {
+                             float* slabs, capnet_stream_t stream) {
   return conv2d_fwd_v2(x, sxb, sxh, sxw, w_kmajor, k_rows, y, in_scale, in_shift, relu_in, part_sum,
-                       part_sq, B, H, W, Cin, Cout, KH, KW, stride, pad, tile, S(stream));
+                       part_sq, B, H, W, Cin, Cout, KH, KW, stride, pad, tile, slabs, S(stream));
+}
+size_t capnet_conv_kmajor_slab_floats(int M, int Cout, int k_rows, int tile) {
+  return conv_v2_slab_floats(M, Cout, k_rows, tile);
 }
 int capnet_pack_conv_weight(const float* w_oihw, float* out, int Cout, int Cin, int KH, int KW,
                             int row_stride, capnet_stream_t stream) {
@@ -104,6 +107,13 @@ int capnet_conv2d_fwd(const float* x, long sxb, long sxh, long sxw, long sxc,
 }
 int capnet_conv_tiles_m(int M, int Cout, int tile) {
   if (tile == 0) tile = conv_auto_tile(M, Cout);
+  return conv_tiles_m(M, tile);
+}
+void capnet_conv_kmajor_plan(int M, int Cout, int k_rows, int tile, int* out5) {
+  conv_v2_plan(M, Cout, k_rows, tile, out5);
+}
+int capnet_conv_kmajor_tiles_m(int M, int Cout, int k_rows, int tile) {
+  if (tile == 0) tile = conv_v2_auto_tile(M, Cout, k_rows);
   return conv_tiles_m(M, tile);
 }
 int capnet_bn_finalize(const float* part_sum, const float* part_sq, int tiles, int C, long count,

@@ -12,6 +12,7 @@
 //     LDS stages), fragments for k-step j+1 are read while the MFMAs of step j run.
 // Same contract as conv_f32.hip (raw NHWC output + per-workgroup column sums for the batch
 // statistics); requires Cin % 16 == 0, channel-contiguous input and Cout % BN == 0.
+#include <algorithm>
 #include "common.h"
 #include "mfma_core.h"
 #include "kernels.h"
@@ -34,6 +35,11 @@ struct ConvArgs2 {
   int relu_in;
   int tiles_m, tiles_n;
   unsigned x_bytes, ss_bytes;
+  // tail balancing: workgroups [0, full_tiles) compute whole tiles; the remaining `tiles -
+  // full_tiles` tiles are each cut into `split` K-slices of `kps` k-tiles that write fp32 partial
+  // slabs ([rem_tile][slice][BM*BN]) summed by conv_tail_fixup_kernel
+  int full_tiles, split, kps;
+  float* slabs;
 };
 
 // LDS-DMA of 16 B per lane: LDS[m0_base + 16*lane] = *(sbase + voff). Inline asm on purpose:
@@ -81,8 +87,18 @@ __global__ __launch_bounds__(kGemmThreads) void conv_f32_v2_kernel(ConvArgs2 g) 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 31, lh = lane >> 5;
-  const int nwg = g.tiles_m * g.tiles_n;
-  const int id = xcd_remap(blockIdx.x, nwg);
+  const int nk = g.Kw / BK;
+  int id, kt0 = 0, kt1 = nk, slice = 0;
+  const bool partial = (int)blockIdx.x >= g.full_tiles;
+  if (!partial) {
+    id = xcd_remap(blockIdx.x, g.full_tiles);
+  } else {
+    const int u = blockIdx.x - g.full_tiles;
+    id = g.full_tiles + u / g.split;
+    slice = u - (u / g.split) * g.split;
+    kt0 = slice * g.kps;
+    kt1 = min(nk, kt0 + g.kps);
+  }
   const int tm = id / g.tiles_n, tn = id - tm * g.tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
 
@@ -113,7 +129,7 @@ __global__ __launch_bounds__(kGemmThreads) void conv_f32_v2_kernel(ConvArgs2 g) 
   const bool need_mask = pre || g.pad > 0 || (g.M % BM) != 0;
   unsigned voff[PASSES];         // byte offset of this thread's float4 for the current tap
   float hi[PASSES], lw[PASSES];  // v_med3(x, lw, hi): (lo, +inf) inside the image, (0, 0) outside
-  int tap = 0, c0 = 0;
+  int tap = (kt0 * BK) / g.Cin, c0 = kt0 * BK - tap * g.Cin;
   auto set_tap = [&](int t) {
     const int r = t / g.KW, s = t - r * g.KW;
 #pragma unroll
@@ -126,7 +142,7 @@ __global__ __launch_bounds__(kGemmThreads) void conv_f32_v2_kernel(ConvArgs2 g) 
       lw[ps] = inb ? lo : 0.f;
     }
   };
-  set_tap(0);
+  set_tap(tap);
 
   // ---- B DMA geometry ----
   int bsrc[NI];  // byte offset of this lane's 16 B inside the [Kw][Cout] matrix, tile k0 = 0
@@ -255,20 +271,19 @@ __global__ __launch_bounds__(kGemmThreads) void conv_f32_v2_kernel(ConvArgs2 g) 
     }
   };
 
-  const int nk = g.Kw / BK;
   snapshot();
-  issue(0, 0);
+  issue(0, kt0);
   store(0);
   __syncthreads();
-  int kt = 0;
-  for (; kt + 2 <= nk; kt += 2) {
+  int kt = kt0;
+  for (; kt + 2 <= kt1; kt += 2) {
     // tile kt is in stage 0; tile kt+1 is fetched into stage 1 while stage 0 is consumed
     snapshot();
     issue(1, kt + 1);
     compute(0);
     store(1);
     __syncthreads();
-    const bool more = kt + 2 < nk;
+    const bool more = kt + 2 < kt1;
     if (more) {
       snapshot();
       issue(0, kt + 2);
@@ -277,7 +292,22 @@ __global__ __launch_bounds__(kGemmThreads) void conv_f32_v2_kernel(ConvArgs2 g) 
     if (more) store(0);
     __syncthreads();
   }
-  if (kt < nk) compute(0);  // odd number of k tiles
+  if (kt < kt1) compute(0);  // odd number of k tiles
+
+  if (partial) {
+    // K-slice of a tail tile: dense fp32 slab, summed (with the statistics) by the fixup kernel
+    float* slab = g.slabs + ((size_t)(id - g.full_tiles) * g.split + slice) * (BM * BN);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ml = wm * (BM / 2) + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          slab[ml * BN + wn * (BN / 2) + nt * 32 + li] = acc[mt][nt][r];
+        }
+    return;
+  }
 
   // ---- epilogue: raw output + batch-statistics partials ----
 #pragma unroll
@@ -299,12 +329,155 @@ __global__ __launch_bounds__(kGemmThreads) void conv_f32_v2_kernel(ConvArgs2 g) 
   }
 }
 
+// One 1024-thread workgroup per tail tile: y = sum of its K-slice slabs (fixed order), plus that
+// tile's column sums / sums of squares for the batch statistics. The slab loads of one output
+// element are independent and issued together (the kernel is pure latency otherwise).
+template <int BM, int BN>
+__global__ __launch_bounds__(1024) void conv_tail_fixup_kernel(ConvArgs2 g) {
+  constexpr int RL = 1024 / BN;  // row lanes
+  __shared__ float s_sum[RL][BN], s_sq[RL][BN];
+  const int id = g.full_tiles + blockIdx.x;
+  const int tm = id / g.tiles_n, tn = id - tm * g.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int c = threadIdx.x % BN, rl = threadIdx.x / BN;
+  const float* slab = g.slabs + (size_t)blockIdx.x * g.split * (BM * BN);
+  const int sp = g.split;
+  float cs = 0.f, cq = 0.f;
+  for (int ml = rl; ml < BM; ml += RL) {
+    float p[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) p[k] = slab[(size_t)(k < sp ? k : sp - 1) * (BM * BN) + ml * BN + c];
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v += k < sp ? p[k] : 0.f;
+    const int m = m0 + ml;
+    if (m < g.M) {
+      g.y[(long)m * g.Cout + n0 + c] = v;
+      cs += v;
+      cq = fmaf(v, v, cq);
+    }
+  }
+  if (g.part_sum) {
+    s_sum[rl][c] = cs;
+    s_sq[rl][c] = cq;
+    __syncthreads();
+    if (rl == 0) {
+      for (int r = 1; r < RL; ++r) { cs += s_sum[r][c]; cq += s_sq[r][c]; }
+      g.part_sum[(long)tm * g.Cout + n0 + c] = cs;
+      g.part_sq[(long)tm * g.Cout + n0 + c] = cq;
+    }
+  }
+}
+
+// Tail plan for T tiles (BM x BN, nk k-tiles each) on 256 CUs, in units of one tile's time.
+// Unsplit, the tiles past the last full round of 256 cost a whole extra tile time; cut into
+// `split` K-slices they cost ceil(R*split/256)/split of it, plus the slab round trip through
+// HBM (priced at 4 TB/s against ~0.45 TFLOP/s per CU). Returns the estimated time; *split = 1
+// means "leave it alone".
+static double plan_tail(int T, int nk, int BM, int BN, int* full_tiles, int* split, int* kps) {
+  const int full = (T / 256) * 256;
+  const int R = T - full;
+  *full_tiles = T;
+  *split = 1;
+  *kps = nk;
+  const double unsplit = (double)(full / 256) + (R > 0 ? 1.0 : 0.0);
+  // Below two full rounds the CUs are latency-bound, not MFMA-bound (one 64x64 tile alone on a
+  // CU takes 66 us, two take 91 us): an extra tile is cheap there and slicing it does not pay.
+  if (R == 0 || full < 512) return unsplit;
+  const double tile_s = 2.0 * BM * BN * nk * 16 / 0.45e12;
+  double best = unsplit;
+  int best_slices = 1, best_per = nk;
+  for (int sp = 2; sp <= 16; ++sp) {
+    const int per = cdiv(nk, sp);
+    if (per < 4) break;  // keep >= 4 k-tiles per slice
+    const int slices = cdiv(nk, per);
+    const double slab_s = 2.0 * R * slices * BM * BN * 4 / 4e12 + 4e-6;  // + the fix-up launch
+    const double t = (double)(full / 256) + (double)cdiv((long)R * slices, 256) * per / nk +
+                     slab_s / tile_s;
+    if (t < best) {
+      best = t;
+      best_slices = slices;
+      best_per = per;
+    }
+  }
+  if (best_slices > 1 && best < 0.96 * unsplit) {
+    *full_tiles = full;
+    *split = best_slices;
+    *kps = best_per;
+    return best;
+  }
+  return unsplit;
+}
+
+static void tile_dims(int tile, int* BM, int* BN) {
+  *BM = tile == 64 ? 64 : 128;
+  *BN = tile == 128 ? 128 : 64;
+}
+
+// Tile choice for the K-major kernel. Measured model (tools/conv_bench.py, B sweep): with n
+// tiles per CU a k-tile step costs max(n * c / 0.8, c / 0.47) cycles, c = MFMA cycles of one
+// tile's k-tile per SIMD (512 / 1024 / 2048 for 64x64 / 128x64 / 128x128): a lone workgroup per
+// CU is latency-bound at ~47 % of the matrix pipe, several share it at ~80 %. n comes from the
+// tail plan (fractional once the tail is K-sliced).
+int conv_v2_auto_tile(int M, int Cout, int Kw) {
+  const int cands[3] = {128, 12864, 64};
+  int best = 64;
+  double best_t = 1e30;
+  for (int tile : cands) {
+    int BM, BN;
+    tile_dims(tile, &BM, &BN);
+    if (Cout % BN != 0) continue;
+    const int T = cdiv(M, BM) * (Cout / BN);
+    int full, sp, kps;
+    const double n = plan_tail(T, Kw / 16, BM, BN, &full, &sp, &kps);
+    const double c = (double)BM * BN / 8.0;
+    double t = std::max(n * c / 0.8, c / 0.47);
+    if (tile != 128) t *= 1.02;  // smaller tiles re-read more operand bytes through L2
+    if (t < best_t) { best_t = t; best = tile; }
+  }
+  return best;
+}
+
+// out = {tile, tiles, full_tiles, split, k-tiles per slice}
+void conv_v2_plan(int M, int Cout, int Kw, int tile, int* out) {
+  if (tile == 0) tile = conv_v2_auto_tile(M, Cout, Kw);
+  int BM, BN;
+  tile_dims(tile, &BM, &BN);
+  const int T = cdiv(M, BM) * (Cout / BN);
+  int full, sp, kps;
+  plan_tail(T, Kw / 16, BM, BN, &full, &sp, &kps);
+  out[0] = tile; out[1] = T; out[2] = full; out[3] = sp; out[4] = kps;
+}
+
+size_t conv_v2_slab_floats(int M, int Cout, int Kw, int tile) {
+  if (tile == 0) tile = conv_v2_auto_tile(M, Cout, Kw);
+  int BM, BN;
+  tile_dims(tile, &BM, &BN);
+  if (Cout % BN != 0) return 0;
+  const int T = cdiv(M, BM) * (Cout / BN);
+  int full, sp, kps;
+  plan_tail(T, Kw / 16, BM, BN, &full, &sp, &kps);
+  return sp > 1 ? (size_t)(T - full) * sp * BM * BN : 0;
+}
+
 template <int BM, int BN>
 static void launch_v2(ConvArgs2& g, hipStream_t stream) {
   g.tiles_m = cdiv(g.M, BM);
   g.tiles_n = g.Cout / BN;
-  hipLaunchKernelGGL((conv_f32_v2_kernel<BM, BN>), dim3(g.tiles_m * g.tiles_n), dim3(kGemmThreads),
-                     0, stream, g);
+  const int T = g.tiles_m * g.tiles_n;
+  g.full_tiles = T;
+  g.split = 1;
+  g.kps = g.Kw / 16;
+  if (g.slabs) {
+    int full, sp, kps;
+    plan_tail(T, g.Kw / 16, BM, BN, &full, &sp, &kps);
+    if (sp > 1) { g.full_tiles = full; g.split = sp; g.kps = kps; }
+  }
+  const int rem = T - g.full_tiles;
+  hipLaunchKernelGGL((conv_f32_v2_kernel<BM, BN>), dim3(g.full_tiles + rem * g.split),
+                     dim3(kGemmThreads), 0, stream, g);
+  if (rem > 0)
+    hipLaunchKernelGGL((conv_tail_fixup_kernel<BM, BN>), dim3(rem), dim3(1024), 0, stream, g);
 }
 
 bool conv_v2_eligible(const float* x, long sxb, long sxh, long sxw, long sxc, int Bn, int Cin,
@@ -318,7 +491,7 @@ bool conv_v2_eligible(const float* x, long sxb, long sxh, long sxw, long sxc, in
 int conv2d_fwd_v2(const float* x, long sxb, long sxh, long sxw, const float* wk, int Kw, float* y,
                   const float* in_scale, const float* in_shift, int relu_in, float* part_sum,
                   float* part_sq, int Bn, int H, int W, int Cin, int Cout, int KH, int KW,
-                  int stride, int pad, int tile, hipStream_t stream) {
+                  int stride, int pad, int tile, float* slabs, hipStream_t stream) {
   CAPNET_REQUIRE(x && wk && y, "conv2d_fwd_v2: null pointer");
   CAPNET_REQUIRE(conv_v2_eligible(x, sxb, sxh, sxw, 1, Bn, Cin, Cout, in_scale, in_shift),
                  "conv2d_fwd_v2: shape/alignment not supported (Cin=%d Cout=%d)", Cin, Cout);
@@ -339,9 +512,10 @@ int conv2d_fwd_v2(const float* x, long sxb, long sxh, long sxw, const float* wk,
   g.M = (int)M;
   g.Kw = Kw;
   g.relu_in = relu_in;
+  g.slabs = slabs;
   g.x_bytes = (unsigned)((long)Bn * sxb * 4);
   g.ss_bytes = (unsigned)(Cin * 4);
-  if (tile == 0) tile = conv_auto_tile(g.M, Cout);
+  if (tile == 0) tile = conv_v2_auto_tile(g.M, Cout, Kw);
   if (Cout % 128 != 0 && tile == 128) tile = 12864;
   if (tile == 128) launch_v2<128, 128>(g, stream);
   else if (tile == 64) launch_v2<64, 64>(g, stream);

@@ -26,7 +26,10 @@ bool conv_v2_eligible(const float* x, long sxb, long sxh, long sxw, long sxc, in
 int conv2d_fwd_v2(const float* x, long sxb, long sxh, long sxw, const float* wk, int Kw, float* y,
                   const float* in_scale, const float* in_shift, int relu_in, float* part_sum,
                   float* part_sq, int Bn, int H, int W, int Cin, int Cout, int KH, int KW,
-                  int stride, int pad, int tile, hipStream_t stream);
+                  int stride, int pad, int tile, float* slabs, hipStream_t stream);
+size_t conv_v2_slab_floats(int M, int Cout, int Kw, int tile);
+int conv_v2_auto_tile(int M, int Cout, int Kw);
+void conv_v2_plan(int M, int Cout, int Kw, int tile, int* out);
 int conv_tiles_m(int M, int tile);
 
 // bn_pool.hip

@@ -31,7 +31,7 @@ struct Trunk {
   int B, H, W;
   std::vector<TrunkConv> convs;  // torchvision parameter order
   // workspace layout (float offsets)
-  size_t off_x[2], off_y1, off_y2, off_y3, off_d, off_part, off_ss, total_floats;
+  size_t off_x[2], off_y1, off_y2, off_y3, off_d, off_part, off_slab, off_ss, total_floats;
   std::vector<size_t> ss_off;  // per conv: offset of [scale | shift] (2*Cout floats)
   int final_side;
   // optional per-convolution hipEvent timing (bench.py roofline): pairs recorded on the launch
@@ -99,10 +99,14 @@ int trunk_create(int B, int H, int W, Trunk** out) {
   size_t max_part = 0;
   for (auto& c : t->convs) {
     const long M = (long)B * c.OH * c.OW;
-    const int tile = conv_auto_tile((int)M, c.Cout);
+    const int tile = c.kmajor ? conv_v2_auto_tile((int)M, c.Cout, c.Kw) : conv_auto_tile((int)M, c.Cout);
     max_part = std::max(max_part, (size_t)conv_tiles_m((int)M, tile) * c.Cout);
   }
   t->off_part = take(2 * max_part);
+  size_t max_slab = 0;
+  for (auto& c : t->convs)
+    if (c.kmajor) max_slab = std::max(max_slab, conv_v2_slab_floats(B * c.OH * c.OW, c.Cout, c.Kw, 0));
+  t->off_slab = take(max_slab + 64);
   t->off_ss = off;
   for (auto& c : t->convs) t->ss_off.push_back(take(2 * (size_t)c.Cout));
   t->total_floats = off;
@@ -184,7 +188,7 @@ int conv_bn(const Ctx& c, int i, const float* x, long sxb, long sxh, long sxw, l
             const float* in_scale, const float* in_shift, int relu_in, float* y) {
   const TrunkConv& d = c.t->convs[i];
   const long M = (long)c.t->B * d.OH * d.OW;
-  const int tile = conv_auto_tile((int)M, d.Cout);
+  const int tile = d.kmajor ? conv_v2_auto_tile((int)M, d.Cout, d.Kw) : conv_auto_tile((int)M, d.Cout);
   float* psum = c.ws + c.t->off_part;
   float* psq = psum + (size_t)conv_tiles_m((int)M, tile) * d.Cout;
   hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -199,7 +203,7 @@ int conv_bn(const Ctx& c, int i, const float* x, long sxb, long sxh, long sxw, l
                    "trunk: conv %d planned for the K-major kernel but its operands are not eligible", i);
     rc = conv2d_fwd_v2(x, sxb, sxh, sxw, c.w[i], d.Kw, y, in_scale, in_shift, relu_in,
                        c.train ? psum : nullptr, c.train ? psq : nullptr, c.t->B, d.H, d.W, d.Cin,
-                       d.Cout, d.k, d.k, d.stride, d.pad, tile, c.s);
+                       d.Cout, d.k, d.k, d.stride, d.pad, tile, c.ws + c.t->off_slab, c.s);
   } else {
     rc = conv2d_fwd(x, sxb, sxh, sxw, sxc, c.w[i], d.Kw, y, in_scale, in_shift, relu_in,
                     c.train ? psum : nullptr, c.train ? psq : nullptr, c.t->B, d.H, d.W, d.Cin,

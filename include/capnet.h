@@ -109,7 +109,17 @@ int capnet_conv2d_fwd_kmajor(const float* x, long sxb, long sxh, long sxw, const
                              int k_rows, float* y, const float* in_scale, const float* in_shift,
                              int relu_in, float* part_sum, float* part_sq, int B, int H, int W,
                              int Cin, int Cout, int KH, int KW, int stride, int pad, int tile,
-                             capnet_stream_t stream);
+                             float* slabs, capnet_stream_t stream);
+/* `slabs` (may be NULL = no tail balancing): scratch of capnet_conv_kmajor_slab_floats floats.
+ * When the tile count is not a multiple of the 256 CUs, the tiles past the last full round are
+ * cut into K-slices (fp32 partial slabs, summed in a fixed order by a fix-up launch) so that
+ * every CU ends at the same time. */
+size_t capnet_conv_kmajor_slab_floats(int M, int Cout, int k_rows, int tile);
+/* the launch plan of that call: out5 = {tile, tiles, whole tiles, K-slices per tail tile,
+ * k-tiles per slice} (diagnostics / tests) */
+void capnet_conv_kmajor_plan(int M, int Cout, int k_rows, int tile, int* out5);
+/* rows of the part_sum / part_sq arrays that call writes (tile = 0: its own choice) */
+int capnet_conv_kmajor_tiles_m(int M, int Cout, int k_rows, int tile);
 int capnet_conv_tiles_m(int M, int Cout, int tile);
 int capnet_bn_finalize(const float* part_sum, const float* part_sq, int tiles, int C, long count,
                        const float* gamma, const float* beta, float* running_mean,

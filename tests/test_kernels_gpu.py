@@ -103,6 +103,8 @@ def test_conv_fast_path(dev, tile, B, H, W, Cin, Cout, k, stride, pad, pre):
     (3, 7, 7, 128, 128, 1, 1, 0, False),      # no prologue, ragged last M tile (147 rows)
     (2, 8, 8, 128, 64, 1, 2, 0, True),
     (2, 6, 6, 48, 192, 3, 1, 1, True),        # 3 k-tiles per tap, odd tile count (27)
+    (23, 14, 14, 64, 256, 3, 1, 1, True),     # 4508 rows: tiles past a multiple of 256 -> K-sliced tail
+    (5, 28, 28, 64, 128, 1, 1, 0, False),     # 3920 rows, tail tiles without prologue
 ])
 def test_conv_kmajor_lds_dma_path(dev, tile, B, H, W, Cin, Cout, k, stride, pad, pre):
     """conv_f32_v2: K-major weights by LDS-DMA, saddr loads, med3 mask -- the kernel every trunk
@@ -119,14 +121,16 @@ def test_conv_kmajor_lds_dma_path(dev, tile, B, H, W, Cin, Cout, k, stride, pad,
     wk = ops.pack_conv_weight(w.to(dev), Kw, kmajor=True)
     M = B * OH * OW
     y = torch.full((M, Cout), float("nan"), device=dev)
-    tiles = lib().capnet_conv_tiles_m(M, Cout, tile)
+    tiles = lib().capnet_conv_kmajor_tiles_m(M, Cout, Kw, tile)
     psum = torch.zeros(tiles, Cout, device=dev)
     psq = torch.zeros(tiles, Cout, device=dev)
     sd = scale.to(dev) if pre else None
     hd = shift.to(dev) if pre else None
+    slabs = torch.empty(max(1, lib().capnet_conv_kmajor_slab_floats(M, Cout, Kw, tile)), device=dev)
     check(lib().capnet_conv2d_fwd_kmajor(ptr(xd), H * W * Cin, W * Cin, Cin, ptr(wk), Kw, ptr(y),
                                          ptr(sd), ptr(hd), int(pre), ptr(psum), ptr(psq), B, H, W,
-                                         Cin, Cout, k, k, stride, pad, tile, current_stream()))
+                                         Cin, Cout, k, k, stride, pad, tile, ptr(slabs),
+                                         current_stream()))
     ref_nhwc = ref.permute(0, 2, 3, 1).reshape(M, Cout)
     assert rel_err(y, ref_nhwc) < 3e-6
     assert rel_err(psum.sum(0), ref_nhwc.sum(0)) < 1e-5

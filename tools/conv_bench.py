@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--shapes", default=",".join(SHAPES))
     ap.add_argument("--no-pre", action="store_true")
+    ap.add_argument("--no-tail", action="store_true", help="disable the K-sliced tail balancing")
     ap.add_argument("--v1", action="store_true", help="row-major-weight kernel (conv_f32.hip)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -42,7 +43,9 @@ def main():
         Kw = (k * k * Cin + 15) // 16 * 16
         wp = ops.pack_conv_weight(w, Kw, kmajor=not args.v1)
         y = torch.empty(M, Cout, device=dev)
-        tiles = lib().capnet_conv_tiles_m(M, Cout, args.tile)
+        tiles = max(lib().capnet_conv_tiles_m(M, Cout, args.tile),
+                    lib().capnet_conv_kmajor_tiles_m(M, Cout, Kw, args.tile))
+        slabs = torch.empty(max(1, lib().capnet_conv_kmajor_slab_floats(M, Cout, Kw, args.tile)), device=dev)
         ps = torch.empty(tiles, Cout, device=dev)
         pq = torch.empty(tiles, Cout, device=dev)
         sc = torch.rand(Cin, device=dev) + 0.5
@@ -53,7 +56,8 @@ def main():
                 check(lib().capnet_conv2d_fwd_kmajor(ptr(x), H * H * Cin, H * Cin, Cin, ptr(wp), Kw, ptr(y),
                                                      None if args.no_pre else ptr(sc), None if args.no_pre else ptr(sh),
                                                      0 if args.no_pre else 1, ptr(ps), ptr(pq), B, H, H, Cin, Cout,
-                                                     k, k, stride, pad, args.tile, current_stream()))
+                                                     k, k, stride, pad, args.tile,
+                                                     None if args.no_tail else ptr(slabs), current_stream()))
                 return
             check(lib().capnet_conv2d_fwd(ptr(x), H * H * Cin, H * Cin, Cin, 1, ptr(wp), Kw, ptr(y),
                                           None if args.no_pre else ptr(sc), None if args.no_pre else ptr(sh),
