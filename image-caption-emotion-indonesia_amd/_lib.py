@@ -63,6 +63,15 @@ SIGNATURES = {
                                 _vp]),
     "capnet_seq_backward": (_i, [_ip, _ip, _vp, _vp, _vp, _vp, _vp, C.POINTER(_vp), C.c_float,
                                  C.c_ulonglong, _i, _vp]),
+    "capnet_att_saved_floats": (_sz, [_ip]),
+    "capnet_att_saved_ints": (_sz, [_ip]),
+    "capnet_att_fwd_scratch_floats": (_sz, [_ip]),
+    "capnet_att_bwd_scratch_floats": (_sz, [_ip]),
+    "capnet_att_seq_forward": (_i, [_ip, _ip, C.POINTER(C.c_ubyte), _vp, _vp, _vp, C.POINTER(_vp),
+                                    _vp, _vp, C.c_float, C.c_ulonglong, _i, _vp, _vp, _vp, _vp, _vp,
+                                    _vp, _vp]),
+    "capnet_att_seq_backward": (_i, [_ip, _ip, _vp, _vp, _vp, _vp, C.POINTER(_vp), _vp, _vp, _vp,
+                                     C.POINTER(_vp), C.c_float, C.c_ulonglong, _i, _vp]),
     "capnet_embedding_fwd": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _vp]),
     "capnet_lstm_pointwise_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "capnet_xent_fwd": (_i, [_vp, _l, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),

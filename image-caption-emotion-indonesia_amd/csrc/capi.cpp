@@ -157,9 +157,9 @@ int capnet_lstm_pointwise_fwd(float* pre, const float* c_prev, float* c_out, flo
                               int H, int cell, capnet_stream_t stream) {
   CAPNET_REQUIRE(pre && c_out && h_out && b >= 0 && H > 0, "lstm_pointwise_fwd: bad argument");
   if (cell == kCellFactored)
-    return lstm_pointwise_fwd(pre, c_prev, c_out, h_out, b, H, 0, 1, 2, 3, 0, S(stream));
+    return lstm_pointwise_fwd(pre, 4L * H, c_prev, c_out, h_out, b, H, 0, 1, 2, 3, 0, S(stream));
   CAPNET_REQUIRE(cell == kCellLSTM, "lstm_pointwise_fwd: unknown cell %d", cell);
-  return lstm_pointwise_fwd(pre, c_prev, c_out, h_out, b, H, 0, 1, 3, 2, 1, S(stream));
+  return lstm_pointwise_fwd(pre, 4L * H, c_prev, c_out, h_out, b, H, 0, 1, 3, 2, 1, S(stream));
 }
 
 size_t capnet_seq_saved_floats(const int* dims) { return seq_saved_floats(to_dims(dims)); }
@@ -202,6 +202,64 @@ int capnet_seq_backward(const int* dims, const int* batch_sizes, const float* d_
   g.dbUW = grads[5]; g.dWcat = grads[6]; g.dEmb = grads[7]; g.dFeat = grads[8];
   return seq_backward(to_dims(dims), batch_sizes, d_hiddens, hiddens, saved, saved_i, scratch, g,
                       dropout_p, seed, training, S(stream));
+}
+
+static AttDims to_adims(const int* d) {
+  AttDims r;
+  r.B = d[0]; r.T = d[1]; r.steps = d[2]; r.N = d[3]; r.E = d[4]; r.F = d[5]; r.H = d[6];
+  r.V = d[7]; r.A = d[8]; r.P = d[9]; r.C = d[10];
+  return r;
+}
+static int to_aweights(const float* const* p, AttWeights* w) {
+  CAPNET_REQUIRE(p != nullptr, "att decoder: null weight table");
+  for (int i = 0; i < 44; ++i) CAPNET_REQUIRE(p[i] != nullptr, "att decoder: weight %d is null", i);
+  for (int g = 0; g < 4; ++g) {
+    w->Vw[g] = p[0 + g];  w->Vb[g] = p[4 + g];
+    w->Sw[g] = p[8 + g];  w->Sb[g] = p[12 + g];
+    w->Uw[g] = p[16 + g]; w->Ub[g] = p[20 + g];
+    w->Ww[g] = p[24 + g]; w->Wb[g] = p[28 + g];
+  }
+  w->init_h_w = p[32]; w->init_h_b = p[33]; w->init_c_w = p[34]; w->init_c_b = p[35];
+  w->enc_att_w = p[36]; w->enc_att_b = p[37]; w->dec_att_w = p[38]; w->dec_att_b = p[39];
+  w->full_att_w = p[40]; w->full_att_b = p[41]; w->f_beta_w = p[42]; w->f_beta_b = p[43];
+  return kOk;
+}
+size_t capnet_att_saved_floats(const int* dims) { return att_saved_floats(to_adims(dims)); }
+size_t capnet_att_saved_ints(const int* dims) { return att_saved_ints(to_adims(dims)); }
+size_t capnet_att_fwd_scratch_floats(const int* dims) { return att_fwd_scratch_floats(to_adims(dims)); }
+size_t capnet_att_bwd_scratch_floats(const int* dims) { return att_bwd_scratch_floats(to_adims(dims)); }
+
+int capnet_att_seq_forward(const int* dims, const int* batch_sizes, const unsigned char* tf_mask,
+                           const long long* captions, const float* features, const float* emb,
+                           const float* const* weights, const float* Cw, const float* Cb,
+                           float dropout_p, unsigned long long seed, int training, float* saved,
+                           int* saved_i, float* scratch, float* hiddens, float* alphas,
+                           int* err_flag, capnet_stream_t stream) {
+  CAPNET_REQUIRE(dims != nullptr, "att_seq_forward: null dims");
+  AttWeights w;
+  int rc = to_aweights(weights, &w);
+  if (rc) return rc;
+  return att_seq_forward(to_adims(dims), batch_sizes, tf_mask, captions, features, emb, w, Cw, Cb,
+                         dropout_p, seed, training, saved, saved_i, scratch, hiddens, alphas,
+                         err_flag, S(stream));
+}
+
+int capnet_att_seq_backward(const int* dims, const int* batch_sizes, const float* d_hiddens,
+                            const float* d_alphas, const float* hiddens, const float* features,
+                            const float* const* weights, const float* saved, const int* saved_i,
+                            float* scratch, float* const* grads, float dropout_p,
+                            unsigned long long seed, int training, capnet_stream_t stream) {
+  CAPNET_REQUIRE(dims && grads, "att_seq_backward: null dims/grads");
+  AttWeights w;
+  int rc = to_aweights(weights, &w);
+  if (rc) return rc;
+  AttGrads g;
+  g.dVcat = grads[0]; g.dbV = grads[1]; g.dScat = grads[2]; g.dbS = grads[3]; g.dUcat = grads[4];
+  g.dWz = grads[5]; g.dbz = grads[6]; g.dWe = grads[7]; g.dbe = grads[8]; g.dwf = grads[9];
+  g.dbf = grads[10]; g.dWih = grads[11]; g.dbih = grads[12]; g.dWic = grads[13]; g.dbic = grads[14];
+  g.dEmb = grads[15];
+  return att_seq_backward(to_adims(dims), batch_sizes, d_hiddens, d_alphas, hiddens, features, w,
+                          saved, saved_i, scratch, g, dropout_p, seed, training, S(stream));
 }
 
 int capnet_xent_fwd(const float* logits, long ld, int N, int V, const long long* targets,

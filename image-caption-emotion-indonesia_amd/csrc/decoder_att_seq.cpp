@@ -1,0 +1,278 @@
+// Sequence driver of the attention decoder: DecoderFactoredLSTMAtt.forward
+// (stylenet/model_att.py:238-305) and its BPTT, one C call each.
+//
+// Per step t (rows = batch_sizes[t], previous state h, c -- the initial state is
+// init_h/init_c(mean over pixels of the feature map), :185-194,260):
+//   alpha, awe = attention(features, h)          (:279-280, Attention.forward :51-70)
+//   gate = sigmoid(f_beta(h)); awe = gate * awe  (:283-284)
+//   x = teacher forced ? dropout(B(w_t)) : B(argmax(C h))   (:285-288)
+//   h, c = factored_lstm_step(cat[x, awe], h, c)             (:290-293, forward_step :196-236)
+//   alphas[:rows, t] = alpha                                 (:296)
+// MI355X mapping. Every product with h_{t-1} is ONE skinny GEMM per step against the stacked
+// weight Wz = [W_i; W_f; W_o; W_c; decoder_att; f_beta] ([4H+A+C] x H): the forward writes
+// Z = [gate pre-acts | att2 | f_beta(h)] rows, the backward reads dZ rows and gets dh in one
+// product; the weight gradients of all six matrices are one TN GEMM over all packed rows after
+// the loop. encoder_att(features) is hoisted out of the time loop (the reference recomputes it
+// every step) and its weight gradient is accumulated per sample and reduced by one GEMM.
+#include <vector>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace capnet {
+
+namespace {
+
+struct ALayout {
+  size_t XA, Zf, A1, A2, Cst, alpha, awe, att1, mean, h0, c0, Vcat, Scat, Ucat, Wz, bV, bS, bz, total;
+  size_t row_sample, row_col, row_token, prev_row, itotal;
+  int ZW, XW;
+};
+
+ALayout make_alayout(const AttDims& d) {
+  ALayout L;
+  L.ZW = 4 * d.H + d.A + d.C;
+  L.XW = d.E + d.C;
+  size_t o = 0;
+  auto take = [&](size_t n) { size_t r = o; o += (n + 3) / 4 * 4; return r; };
+  const size_t N = d.N, F = d.F, H = d.H;
+  L.XA = take(N * L.XW);
+  L.Zf = take(N * L.ZW);
+  L.A1 = take(N * 4 * F);
+  L.A2 = take(N * 4 * F);
+  L.Cst = take(N * H);
+  L.alpha = take(N * d.P);
+  L.awe = take(N * d.C);
+  L.att1 = take((size_t)d.B * d.P * d.A);
+  L.mean = take((size_t)d.B * d.C);
+  L.h0 = take((size_t)d.B * H);
+  L.c0 = take((size_t)d.B * H);
+  L.Vcat = take(4 * F * L.XW);
+  L.Scat = take(4 * F * F);
+  L.Ucat = take(4 * H * F);
+  L.Wz = take((size_t)L.ZW * H);
+  L.bV = take(4 * F);
+  L.bS = take(4 * F);
+  L.bz = take(L.ZW);
+  L.total = o;
+  size_t io = 0;
+  auto itake = [&](size_t n) { size_t r = io; io += (n + 3) / 4 * 4; return r; };
+  L.row_sample = itake(N);
+  L.row_col = itake(N);
+  L.row_token = itake(N);
+  L.prev_row = itake(N);
+  L.itotal = io;
+  return L;
+}
+
+constexpr size_t kAttSplitKFloats = 32ull * 64 * 4608;
+
+int check(const AttDims& d, const int* bs) {
+  CAPNET_REQUIRE(d.B > 0 && d.T > 0 && d.steps > 0 && d.N > 0 && d.E > 0 && d.F > 0 && d.H > 0 &&
+                     d.V > 0 && d.A > 0 && d.P > 0 && d.C > 0,
+                 "att decoder: bad dims");
+  CAPNET_REQUIRE(d.E % 4 == 0 && d.H % 4 == 0 && d.A % 4 == 0 && d.C % 512 == 0 && d.F % 4 == 0,
+                 "att decoder: E, H, A, F must be multiples of 4 and the feature size of 512 "
+                 "(E=%d H=%d A=%d F=%d C=%d)", d.E, d.H, d.A, d.F, d.C);
+  CAPNET_REQUIRE(bs != nullptr && d.steps <= kMaxSteps && d.steps <= d.T, "att decoder: steps");
+  long n = 0;
+  int prev = d.B;
+  CAPNET_REQUIRE(bs[0] == d.B, "att decoder: batch_sizes[0] must equal the batch");
+  for (int t = 0; t < d.steps; ++t) {
+    CAPNET_REQUIRE(bs[t] > 0 && bs[t] <= prev, "att decoder: batch_sizes must be non-increasing");
+    prev = bs[t];
+    n += bs[t];
+  }
+  CAPNET_REQUIRE(n == d.N, "att decoder: sum(batch_sizes) != N");
+  return kOk;
+}
+
+#define RC(x) do { int _rc = (x); if (_rc) return _rc; } while (0)
+
+int cpy(float* dst, const float* src, size_t n, hipStream_t s) {
+  CAPNET_HIP_CHECK(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+  return kOk;
+}
+
+}  // namespace
+
+size_t att_saved_floats(const AttDims& d) { return make_alayout(d).total; }
+size_t att_saved_ints(const AttDims& d) { return make_alayout(d).itotal; }
+size_t att_fwd_scratch_floats(const AttDims& d) { return (size_t)d.B * d.V + 64 + kAttSplitKFloats; }
+size_t att_bwd_scratch_floats(const AttDims& d) {
+  const ALayout L = make_alayout(d);
+  const size_t N = d.N;
+  return N * L.ZW + 2 * N * 4 * d.F + N * L.XW + N * d.H + 2 * (size_t)d.B * d.H +
+         (size_t)d.B * (d.C / 512) * d.P + (size_t)d.B * d.P * d.A + N * d.A + N + 4096 +
+         kAttSplitKFloats;
+}
+
+int att_seq_forward(const AttDims& d, const int* bs, const unsigned char* tf,
+                    const long long* captions, const float* feat, const float* emb,
+                    const AttWeights& w, const float* Cw, const float* Cb, float dropout_p,
+                    unsigned long long seed, int training, float* saved, int* saved_i,
+                    float* scratch, float* hiddens, float* alphas_bt, int* err_flag,
+                    hipStream_t s) {
+  RC(check(d, bs));
+  CAPNET_REQUIRE(tf && captions && feat && emb && Cw && Cb && saved && saved_i && scratch &&
+                     hiddens && alphas_bt && err_flag,
+                 "att_seq_forward: null argument");
+  CAPNET_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "att_seq_forward: dropout p");
+  const ALayout L = make_alayout(d);
+  const int E = d.E, F = d.F, H = d.H, N = d.N, A = d.A, P = d.P, C = d.C, ZW = L.ZW, XW = L.XW;
+  float* sv = saved;
+  std::vector<int> off(d.steps + 1, 0);
+  for (int t = 0; t < d.steps; ++t) off[t + 1] = off[t] + bs[t];
+  {
+    SeqMeta m;
+    m.N = N; m.steps = d.steps; m.has_features = 0;
+    for (int t = 0; t <= d.steps; ++t) m.off[t] = off[t];
+    for (int t = 0; t < d.steps; ++t) m.tf[t] = tf[t] ? 1 : 0;
+    RC(build_rows(m, saved_i + L.row_sample, saved_i + L.row_col, saved_i + L.row_token,
+                  saved_i + L.prev_row, s));
+  }
+  // ---- pack weights
+  for (int g = 0; g < 4; ++g) {
+    RC(cpy(sv + L.Vcat + (size_t)g * F * XW, w.Vw[g], (size_t)F * XW, s));
+    RC(cpy(sv + L.Scat + (size_t)g * F * F, w.Sw[g], (size_t)F * F, s));
+    RC(cpy(sv + L.Ucat + (size_t)g * H * F, w.Uw[g], (size_t)H * F, s));
+    RC(cpy(sv + L.Wz + (size_t)g * H * H, w.Ww[g], (size_t)H * H, s));
+    RC(cpy(sv + L.bV + (size_t)g * F, w.Vb[g], F, s));
+    RC(cpy(sv + L.bS + (size_t)g * F, w.Sb[g], F, s));
+    RC(vec_add(w.Ub[g], w.Wb[g], sv + L.bz + (size_t)g * H, H, s));
+  }
+  RC(cpy(sv + L.Wz + (size_t)4 * H * H, w.dec_att_w, (size_t)A * H, s));
+  RC(cpy(sv + L.Wz + (size_t)(4 * H + A) * H, w.f_beta_w, (size_t)C * H, s));
+  RC(cpy(sv + L.bz + 4 * H, w.dec_att_b, A, s));
+  RC(cpy(sv + L.bz + 4 * H + A, w.f_beta_b, C, s));
+
+  // ---- time-invariant parts
+  RC(global_avgpool(feat, sv + L.mean, d.B, P, C, s));
+  RC(sgemm(false, true, d.B, H, C, sv + L.mean, C, w.init_h_w, C, sv + L.h0, H, w.init_h_b, 0, 1, 0,
+           0, 0, 0, 0, s));
+  RC(sgemm(false, true, d.B, H, C, sv + L.mean, C, w.init_c_w, C, sv + L.c0, H, w.init_c_b, 0, 1, 0,
+           0, 0, 0, 0, s));
+  RC(sgemm(false, true, d.B * P, A, C, feat, C, w.enc_att_w, C, sv + L.att1, A, w.enc_att_b, 0, 1,
+           0, 0, 0, 0, 0, s));
+  CAPNET_HIP_CHECK(hipMemsetAsync(sv + L.XA, 0, (size_t)N * XW * sizeof(float), s));
+  CAPNET_HIP_CHECK(hipMemsetAsync(alphas_bt, 0, (size_t)d.B * d.steps * P * sizeof(float), s));
+  RC(gather_inputs(captions, d.T, nullptr, emb, E, d.V, saved_i + L.row_sample, saved_i + L.row_col,
+                   saved_i + L.row_token, sv + L.XA, XW, 0, N, dropout_p, seed,
+                   training && dropout_p > 0.f, 0, err_flag, s));
+
+  float* skws = scratch + (size_t)d.B * d.V + 64;
+  for (int t = 0; t < d.steps; ++t) {
+    const int b = bs[t], r0 = off[t];
+    const float* hprev = t > 0 ? hiddens + (size_t)off[t - 1] * H : sv + L.h0;
+    const float* cprev = t > 0 ? sv + L.Cst + (size_t)off[t - 1] * H : sv + L.c0;
+    float* Z = sv + L.Zf + (size_t)r0 * ZW;
+    // Z = h . Wz^T + bz  ->  [recurrent gate pre-acts | att2 | f_beta(h)]
+    RC(sgemm_splitk(false, true, b, ZW, H, hprev, H, sv + L.Wz, H, Z, ZW, sv + L.bz, 0, skws,
+                    kAttSplitKFloats, s));
+    RC(att_step_fwd(sv + L.att1, feat, Z + 4 * H, Z + 4 * H + A, ZW, w.full_att_w, w.full_att_b, b, P,
+                    A, C, sv + L.alpha + (size_t)r0 * P, alphas_bt, d.steps, t,
+                    sv + L.awe + (size_t)r0 * C, sv + L.XA + (size_t)r0 * XW + E, XW, s));
+    if (t > 0 && !tf[t]) {
+      RC(sgemm(false, true, b, d.V, H, hprev, H, Cw, H, scratch, d.V, Cb, 0, 1, 0, 0, 0, 0, 0, s));
+      RC(argmax_rows(scratch, b, d.V, d.V, saved_i + L.row_token + r0, s));
+      RC(gather_inputs(captions, d.T, nullptr, emb, E, d.V, saved_i + L.row_sample,
+                       saved_i + L.row_col, saved_i + L.row_token, sv + L.XA, XW, r0, r0 + b,
+                       dropout_p, seed, 0, 1, err_flag, s));
+    }
+    // factored chain on [x | gated context]
+    RC(sgemm_splitk(false, true, b, 4 * F, XW, sv + L.XA + (size_t)r0 * XW, XW, sv + L.Vcat, XW,
+                    sv + L.A1 + (size_t)r0 * 4 * F, 4 * F, sv + L.bV, 0, skws, kAttSplitKFloats, s));
+    RC(sgemm(false, true, b, F, F, sv + L.A1 + (size_t)r0 * 4 * F, 4 * F, sv + L.Scat, F,
+             sv + L.A2 + (size_t)r0 * 4 * F, 4 * F, sv + L.bS, 0, 4, F, (long)F * F, F, F, 0, s));
+    RC(sgemm(false, true, b, H, F, sv + L.A2 + (size_t)r0 * 4 * F, 4 * F, sv + L.Ucat, F, Z, ZW,
+             nullptr, 1, 4, F, (long)H * F, H, 0, 0, s));
+    RC(lstm_pointwise_fwd(Z, ZW, cprev, sv + L.Cst + (size_t)r0 * H, hiddens + (size_t)r0 * H, b, H,
+                          0, 1, 2, 3, 0, s));
+  }
+  return kOk;
+}
+
+int att_seq_backward(const AttDims& d, const int* bs, const float* dH, const float* dalphas_bt,
+                     const float* hiddens, const float* feat, const AttWeights& w,
+                     const float* saved, const int* saved_i, float* scratch, const AttGrads& g,
+                     float dropout_p, unsigned long long seed, int training, hipStream_t s) {
+  RC(check(d, bs));
+  CAPNET_REQUIRE(dH && hiddens && feat && saved && saved_i && scratch, "att_seq_backward: null argument");
+  CAPNET_REQUIRE(g.dVcat && g.dbV && g.dScat && g.dbS && g.dUcat && g.dWz && g.dbz && g.dWe && g.dbe &&
+                     g.dwf && g.dbf && g.dWih && g.dbih && g.dWic && g.dbic && g.dEmb,
+                 "att_seq_backward: null gradient buffer");
+  const ALayout L = make_alayout(d);
+  const int E = d.E, F = d.F, H = d.H, N = d.N, A = d.A, P = d.P, C = d.C, ZW = L.ZW, XW = L.XW;
+  const float* sv = saved;
+  std::vector<int> off(d.steps + 1, 0);
+  for (int t = 0; t < d.steps; ++t) off[t + 1] = off[t] + bs[t];
+  size_t o = 0;
+  auto take = [&](size_t n) { size_t r = o; o += (n + 3) / 4 * 4; return r; };
+  float* Zb = scratch + take((size_t)N * ZW);
+  float* dA2 = scratch + take((size_t)N * 4 * F);
+  float* dA1 = scratch + take((size_t)N * 4 * F);
+  float* dXA = scratch + take((size_t)N * XW);
+  float* Hprev = scratch + take((size_t)N * H);
+  float* dh_rec = scratch + take((size_t)d.B * H);
+  float* dc = scratch + take((size_t)d.B * H);
+  float* dalpha_part = scratch + take((size_t)d.B * (C / 512) * P);
+  float* datt1 = scratch + take((size_t)d.B * P * A);
+  float* dwf_rows = scratch + take((size_t)N * A);
+  float* dbf_rows = scratch + take((size_t)N);
+  float* skws = scratch + take(kAttSplitKFloats);
+  CAPNET_HIP_CHECK(hipMemsetAsync(dh_rec, 0, (size_t)d.B * H * sizeof(float), s));
+  CAPNET_HIP_CHECK(hipMemsetAsync(dc, 0, (size_t)d.B * H * sizeof(float), s));
+  CAPNET_HIP_CHECK(hipMemsetAsync(datt1, 0, (size_t)d.B * P * A * sizeof(float), s));
+
+  for (int t = d.steps - 1; t >= 0; --t) {
+    const int b = bs[t], r0 = off[t];
+    const int b_next = (t + 1 < d.steps) ? bs[t + 1] : 0;
+    const float* cprev = t > 0 ? sv + L.Cst + (size_t)off[t - 1] * H : sv + L.c0;
+    const float* Zf = sv + L.Zf + (size_t)r0 * ZW;
+    float* Z = Zb + (size_t)r0 * ZW;
+    RC(lstm_pointwise_bwd(Zf, ZW, sv + L.Cst + (size_t)r0 * H, cprev, dH + (size_t)r0 * H, dh_rec, dc,
+                          Z, ZW, b, b_next, H, 0, 1, 2, 3, 0, s));
+    RC(sgemm(false, false, b, F, H, Z, ZW, sv + L.Ucat, F, dA2 + (size_t)r0 * 4 * F, 4 * F, nullptr,
+             0, 4, H, (long)H * F, F, 0, 0, s));
+    RC(sgemm(false, false, b, F, F, dA2 + (size_t)r0 * 4 * F, 4 * F, sv + L.Scat, F,
+             dA1 + (size_t)r0 * 4 * F, 4 * F, nullptr, 0, 4, F, (long)F * F, F, 0, 0, s));
+    RC(sgemm_splitk(false, false, b, XW, 4 * F, dA1 + (size_t)r0 * 4 * F, 4 * F, sv + L.Vcat, XW,
+                    dXA + (size_t)r0 * XW, XW, nullptr, 0, skws, kAttSplitKFloats, s));
+    RC(att_step_bwd(sv + L.att1, feat, Zf + 4 * H, ZW, Zf + 4 * H + A, ZW, sv + L.awe + (size_t)r0 * C,
+                    sv + L.alpha + (size_t)r0 * P, w.full_att_w, dXA + (size_t)r0 * XW + E, XW,
+                    dalphas_bt, d.steps, t, b, P, A, C, dalpha_part, Z + 4 * H + A, Z + 4 * H, ZW,
+                    datt1, dwf_rows + (size_t)r0 * A, dbf_rows + r0, s));
+    // dh_{t-1} (or dh0) = dZ . Wz
+    RC(sgemm_splitk(false, false, b, H, ZW, Z, ZW, sv + L.Wz, H, dh_rec, H, nullptr, 0, skws,
+                    kAttSplitKFloats, s));
+  }
+  // ---- weight gradients over all rows at once
+  RC(gather_prev_rows(hiddens, saved_i + L.prev_row, sv + L.h0, saved_i + L.row_sample, Hprev, N, H, s));
+  RC(sgemm(true, false, ZW, H, N, Zb, ZW, Hprev, H, g.dWz, H, nullptr, 0, 1, 0, 0, 0, 0, 0, s));
+  RC(colsum(Zb, ZW, N, ZW, g.dbz, 0, s));
+  RC(sgemm(true, false, H, F, N, Zb, ZW, sv + L.A2, 4 * F, g.dUcat, F, nullptr, 0, 4, H, F,
+           (long)H * F, 0, 0, s));
+  RC(colsum(dA2, 4 * F, N, 4 * F, g.dbS, 0, s));
+  RC(sgemm(true, false, F, F, N, dA2, 4 * F, sv + L.A1, 4 * F, g.dScat, F, nullptr, 0, 4, F, F,
+           (long)F * F, 0, 0, s));
+  RC(colsum(dA1, 4 * F, N, 4 * F, g.dbV, 0, s));
+  RC(sgemm(true, false, 4 * F, XW, N, dA1, 4 * F, sv + L.XA, XW, g.dVcat, XW, nullptr, 0, 1, 0, 0, 0,
+           0, 0, s));
+  RC(colsum(dwf_rows, A, N, A, g.dwf, 0, s));
+  RC(colsum(dbf_rows, 1, N, 1, g.dbf, 0, s));
+  // encoder_att: d att1 was summed per sample over the steps
+  RC(sgemm(true, false, A, C, d.B * P, datt1, A, feat, C, g.dWe, C, nullptr, 0, 1, 0, 0, 0, 0, 0, s));
+  RC(colsum(datt1, A, d.B * P, A, g.dbe, 0, s));
+  // init_h / init_c: dh0 = dh_rec, dc0 = dc (all B rows are alive at t = 0)
+  RC(sgemm(true, false, H, C, d.B, dh_rec, H, sv + L.mean, C, g.dWih, C, nullptr, 0, 1, 0, 0, 0, 0, 0, s));
+  RC(colsum(dh_rec, H, d.B, H, g.dbih, 0, s));
+  RC(sgemm(true, false, H, C, d.B, dc, H, sv + L.mean, C, g.dWic, C, nullptr, 0, 1, 0, 0, 0, 0, 0, s));
+  RC(colsum(dc, H, d.B, H, g.dbic, 0, s));
+  CAPNET_HIP_CHECK(hipMemsetAsync(g.dEmb, 0, (size_t)d.V * E * sizeof(float), s));
+  RC(scatter_input_grad(dXA, XW, N, E, saved_i + L.row_sample, saved_i + L.row_col,
+                        saved_i + L.row_token, g.dEmb, nullptr, d.V, dropout_p, seed,
+                        training && dropout_p > 0.f, s));
+  return kOk;
+}
+
+}  // namespace capnet

@@ -185,7 +185,7 @@ int seq_forward(const SeqDims& d, const int* batch_sizes, const unsigned char* t
   // ---- inputs + input chain for every row whose input is known up front
   CAPNET_HIP_CHECK(hipMemsetAsync(sv + L.X, 0, (size_t)N * E * sizeof(float), s));
   RC(gather_inputs(captions, d.T, features, emb, E, d.V, saved_i + L.row_sample,
-                   saved_i + L.row_col, saved_i + L.row_token, sv + L.X, 0, N, dropout_p, seed,
+                   saved_i + L.row_col, saved_i + L.row_token, sv + L.X, E, 0, N, dropout_p, seed,
                    training && dropout_p > 0.f, 0, err_flag, s));
   RC(input_chain(d, L, sv, 0, N, s));
 
@@ -200,7 +200,7 @@ int seq_forward(const SeqDims& d, const int* batch_sizes, const unsigned char* t
         RC(sgemm(false, true, b, d.V, H, h_prev, H, Cw, H, scratch, d.V, Cb, 0, 1, 0, 0, 0, 0, 0, s));
         RC(argmax_rows(scratch, b, d.V, d.V, saved_i + L.row_token + r0, s));
         RC(gather_inputs(captions, d.T, features, emb, E, d.V, saved_i + L.row_sample,
-                         saved_i + L.row_col, saved_i + L.row_token, sv + L.X, r0, r0 + b,
+                         saved_i + L.row_col, saved_i + L.row_token, sv + L.X, E, r0, r0 + b,
                          dropout_p, seed, 0, 1, err_flag, s));
         RC(input_chain(d, L, sv, r0, r0 + b, s));
       }
@@ -208,7 +208,7 @@ int seq_forward(const SeqDims& d, const int* batch_sizes, const unsigned char* t
       RC(sgemm_splitk(false, true, b, 4 * H, H, h_prev, H, sv + L.Wcat, H,
                       sv + L.G + (size_t)r0 * 4 * H, 4 * H, nullptr, 1, skws, kSplitKFloats, s));
     }
-    RC(lstm_pointwise_fwd(sv + L.G + (size_t)r0 * 4 * H,
+    RC(lstm_pointwise_fwd(sv + L.G + (size_t)r0 * 4 * H, 4 * H,
                           t > 0 ? sv + L.Cst + (size_t)off[t - 1] * H : nullptr,
                           sv + L.Cst + (size_t)r0 * H, hiddens + (size_t)r0 * H, b, H, go.gi, go.gf,
                           go.go, go.gg, go.tanh_out, s));
@@ -249,9 +249,9 @@ int seq_backward(const SeqDims& d, const int* batch_sizes, const float* dH, cons
   for (int t = d.steps - 1; t >= 0; --t) {
     const int b = batch_sizes[t], r0 = off[t];
     const int b_next = (t + 1 < d.steps) ? batch_sizes[t + 1] : 0;
-    RC(lstm_pointwise_bwd(sv + L.G + (size_t)r0 * 4 * H, sv + L.Cst + (size_t)r0 * H,
+    RC(lstm_pointwise_bwd(sv + L.G + (size_t)r0 * 4 * H, 4 * H, sv + L.Cst + (size_t)r0 * H,
                           t > 0 ? sv + L.Cst + (size_t)off[t - 1] * H : nullptr,
-                          dH + (size_t)r0 * H, dh_rec, dc, dPre + (size_t)r0 * 4 * H, b, b_next, H,
+                          dH + (size_t)r0 * H, dh_rec, dc, dPre + (size_t)r0 * 4 * H, 4 * H, b, b_next, H,
                           go.gi, go.gf, go.go, go.gg, go.tanh_out, s));
     if (t > 0) {
       // dh_{t-1}[0:b] = dPre_t . Wcat     (rows b..b_{t-1} of step t-1 have no successor)
@@ -287,7 +287,7 @@ int seq_backward(const SeqDims& d, const int* batch_sizes, const float* dH, cons
   }
   CAPNET_HIP_CHECK(hipMemsetAsync(g.dEmb, 0, (size_t)d.V * E * sizeof(float), s));
   if (g.dFeat) CAPNET_HIP_CHECK(hipMemsetAsync(g.dFeat, 0, (size_t)d.B * E * sizeof(float), s));
-  RC(scatter_input_grad(dX, N, E, saved_i + L.row_sample, saved_i + L.row_col,
+  RC(scatter_input_grad(dX, E, N, E, saved_i + L.row_sample, saved_i + L.row_col,
                         saved_i + L.row_token, g.dEmb, g.dFeat, d.V, dropout_p, seed,
                         training && dropout_p > 0.f, s));
   return kOk;

@@ -80,25 +80,40 @@ int build_rows(const SeqMeta& m, int* row_sample, int* row_col, int* row_token, 
                hipStream_t stream);
 int gather_inputs(const long long* captions, int T, const float* features, const float* emb, int E,
                   int V, const int* row_sample, const int* row_col, int* row_token, float* X,
-                  int r0, int r1, float p, unsigned long long seed, int use_dropout, int dynamic,
-                  int* err_flag, hipStream_t stream);
+                  long ldx, int r0, int r1, float p, unsigned long long seed, int use_dropout,
+                  int dynamic, int* err_flag, hipStream_t stream);
 int embedding_fwd(const long long* idx, int n, const float* emb, int E, int V, float* out,
                   int* err_flag, hipStream_t stream);
 int packed_targets(const SeqMeta& m, const long long* captions, int T, long long* out,
                    hipStream_t stream);
 int vec_add(const float* a, const float* b, float* out, int n, hipStream_t stream);
-int lstm_pointwise_fwd(float* pre, const float* c_prev, float* c_out, float* h_out, int b, int H,
-                       int gi, int gf, int go, int gg, int tanh_out, hipStream_t stream);
-int lstm_pointwise_bwd(const float* gates, const float* c, const float* c_prev, const float* dH,
-                       const float* dh_rec, float* dc_io, float* dpre, int b, int b_next, int H,
-                       int gi, int gf, int go, int gg, int tanh_out, hipStream_t stream);
+int lstm_pointwise_fwd(float* pre, long ldp, const float* c_prev, float* c_out, float* h_out, int b,
+                       int H, int gi, int gf, int go, int gg, int tanh_out, hipStream_t stream);
+int lstm_pointwise_bwd(const float* gates, long ldg, const float* c, const float* c_prev,
+                       const float* dH, const float* dh_rec, float* dc_io, float* dpre, long ldq,
+                       int b, int b_next, int H, int gi, int gf, int go, int gg, int tanh_out,
+                       hipStream_t stream);
+int gather_prev_rows(const float* src, const int* idx, const float* first, const int* sample,
+                     float* out, int rows, int C, hipStream_t stream);
 int argmax_rows(const float* x, int rows, int ld, int V, int* out, hipStream_t stream);
 int gather_rows(const float* src, const int* idx, float* out, int rows, int C, hipStream_t stream);
 int colsum(const float* x, long ld, int rows, int C, float* out, int accumulate,
            hipStream_t stream);
-int scatter_input_grad(const float* dX, int N, int E, const int* row_sample, const int* row_col,
+int scatter_input_grad(const float* dX, long ldx, int N, int E, const int* row_sample, const int* row_col,
                        const int* row_token, float* dEmb, float* dFeat, int V, float p,
                        unsigned long long seed, int use_dropout, hipStream_t stream);
+
+// att_kernels.hip
+int att_step_fwd(const float* att1, const float* feat, const float* att2, float* gate_io, long ldz,
+                 const float* wf, const float* bf, int rows, int P, int A, int C,
+                 float* alpha_out, float* alphas_bt, int steps, int t, float* awe_out,
+                 float* xa_out, long ldx, hipStream_t stream);
+int att_step_bwd(const float* att1, const float* feat, const float* att2, long ldz2,
+                 const float* gate, long ldzg, const float* awe, const float* alpha,
+                 const float* wf, const float* dxa, long ldx, const float* dalphas_bt, int steps,
+                 int t, int rows, int P, int A, int C, float* dalpha_part, float* dgate_out,
+                 float* datt2, long ldz, float* datt1_acc, float* dwf_rows, float* dbf_rows,
+                 hipStream_t stream);
 
 // loss_optim.hip
 int xent_fwd(const float* logits, long ld, int N, int V, const long long* targets, float* lse,
@@ -151,5 +166,42 @@ int seq_forward(const SeqDims& d, const int* batch_sizes, const unsigned char* t
 int seq_backward(const SeqDims& d, const int* batch_sizes, const float* dH, const float* hiddens,
                  const float* saved, const int* saved_i, float* scratch, const SeqGrads& g,
                  float dropout_p, unsigned long long seed, int training, hipStream_t s);
+
+// decoder_att_seq.cpp -- DecoderFactoredLSTMAtt (stylenet/model_att.py:73-305)
+struct AttDims {
+  int B, T, steps, N, E, F, H, V, A, P, C;
+};
+struct AttWeights {
+  const float* Vw[4]; const float* Vb[4];   // V_g: [F][E+C]
+  const float* Sw[4]; const float* Sb[4];   // mode-selected S_g
+  const float* Uw[4]; const float* Ub[4];
+  const float* Ww[4]; const float* Wb[4];
+  const float* init_h_w; const float* init_h_b; const float* init_c_w; const float* init_c_b;
+  const float* enc_att_w; const float* enc_att_b;   // [A][C]   (mode-selected attention module)
+  const float* dec_att_w; const float* dec_att_b;   // [A][H]
+  const float* full_att_w; const float* full_att_b; // [1][A], [1]
+  const float* f_beta_w; const float* f_beta_b;     // [C][H]
+};
+// dWz [4H+A+C][H] = [dW_i; dW_f; dW_o; dW_c; d decoder_att; d f_beta]; dbz likewise
+// (dbz[0:4H] is the gradient of both the U and the W biases)
+struct AttGrads {
+  float* dVcat; float* dbV; float* dScat; float* dbS; float* dUcat; float* dWz; float* dbz;
+  float* dWe; float* dbe; float* dwf; float* dbf; float* dWih; float* dbih; float* dWic;
+  float* dbic; float* dEmb;
+};
+size_t att_saved_floats(const AttDims& d);
+size_t att_saved_ints(const AttDims& d);
+size_t att_fwd_scratch_floats(const AttDims& d);
+size_t att_bwd_scratch_floats(const AttDims& d);
+int att_seq_forward(const AttDims& d, const int* bs, const unsigned char* tf,
+                    const long long* captions, const float* feat, const float* emb,
+                    const AttWeights& w, const float* Cw, const float* Cb, float dropout_p,
+                    unsigned long long seed, int training, float* saved, int* saved_i,
+                    float* scratch, float* hiddens, float* alphas_bt, int* err_flag,
+                    hipStream_t s);
+int att_seq_backward(const AttDims& d, const int* bs, const float* dH, const float* dalphas_bt,
+                     const float* hiddens, const float* feat, const AttWeights& w,
+                     const float* saved, const int* saved_i, float* scratch, const AttGrads& g,
+                     float dropout_p, unsigned long long seed, int training, hipStream_t s);
 
 }  // namespace capnet

@@ -62,8 +62,8 @@ int build_rows(const SeqMeta& m, int* row_sample, int* row_col, int* row_token, 
 __global__ __launch_bounds__(128) void gather_inputs_kernel(
     const long long* __restrict__ captions, int T, const float* __restrict__ features,
     const float* __restrict__ emb, int E, int V, const int* __restrict__ row_sample,
-    const int* __restrict__ row_col, int* __restrict__ row_token, float* __restrict__ X, int r0,
-    int r1, float p, unsigned long long seed, int use_dropout, int dynamic,
+    const int* __restrict__ row_col, int* __restrict__ row_token, float* __restrict__ X, long ldx,
+    int r0, int r1, float p, unsigned long long seed, int use_dropout, int dynamic,
     int* __restrict__ err_flag) {
   const int r = r0 + blockIdx.x;
   if (r >= r1) return;
@@ -94,17 +94,17 @@ __global__ __launch_bounds__(128) void gather_inputs_kernel(
   for (int e = threadIdx.x; e < E; e += blockDim.x) {
     float v = src[e];
     if (drop) v *= dropout_scale(seed, sample, col, e, p, inv_keep);
-    X[(long)r * E + e] = v;
+    X[(long)r * ldx + e] = v;
   }
 }
 
 int gather_inputs(const long long* captions, int T, const float* features, const float* emb, int E,
                   int V, const int* row_sample, const int* row_col, int* row_token, float* X,
-                  int r0, int r1, float p, unsigned long long seed, int use_dropout, int dynamic,
-                  int* err_flag, hipStream_t stream) {
+                  long ldx, int r0, int r1, float p, unsigned long long seed, int use_dropout,
+                  int dynamic, int* err_flag, hipStream_t stream) {
   if (r1 <= r0) return kOk;
   hipLaunchKernelGGL(gather_inputs_kernel, dim3(r1 - r0), dim3(128), 0, stream, captions, T,
-                     features, emb, E, V, row_sample, row_col, row_token, X, r0, r1, p, seed,
+                     features, emb, E, V, row_sample, row_col, row_token, X, ldx, r0, r1, p, seed,
                      use_dropout, dynamic, err_flag);
   CAPNET_LAUNCH_CHECK();
   return kOk;
@@ -176,12 +176,12 @@ int vec_add(const float* a, const float* b, float* out, int n, hipStream_t strea
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
 __global__ __launch_bounds__(256) void lstm_pointwise_fwd_kernel(
-    float* __restrict__ pre, const float* __restrict__ c_prev, float* __restrict__ c_out,
+    float* __restrict__ pre, long ldp, const float* __restrict__ c_prev, float* __restrict__ c_out,
     float* __restrict__ h_out, int b, int H, int gi, int gf, int go, int gg, int tanh_out) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= b * H) return;
   const int row = idx / H, j = idx - row * H;
-  float* p = pre + (long)row * 4 * H;
+  float* p = pre + (long)row * ldp;
   const float i = sigmoidf_(p[gi * H + j]);
   const float f = sigmoidf_(p[gf * H + j]);
   const float o = sigmoidf_(p[go * H + j]);
@@ -196,11 +196,11 @@ __global__ __launch_bounds__(256) void lstm_pointwise_fwd_kernel(
   h_out[(long)row * H + j] = tanh_out ? o * tanhf(c) : o * c;
 }
 
-int lstm_pointwise_fwd(float* pre, const float* c_prev, float* c_out, float* h_out, int b, int H,
-                       int gi, int gf, int go, int gg, int tanh_out, hipStream_t stream) {
+int lstm_pointwise_fwd(float* pre, long ldp, const float* c_prev, float* c_out, float* h_out, int b,
+                       int H, int gi, int gf, int go, int gg, int tanh_out, hipStream_t stream) {
   if (b <= 0) return kOk;
   hipLaunchKernelGGL(lstm_pointwise_fwd_kernel, dim3(cdiv((long)b * H, 256)), dim3(256), 0, stream,
-                     pre, c_prev, c_out, h_out, b, H, gi, gf, go, gg, tanh_out);
+                     pre, ldp, c_prev, c_out, h_out, b, H, gi, gf, go, gg, tanh_out);
   CAPNET_LAUNCH_CHECK();
   return kOk;
 }
@@ -209,14 +209,14 @@ int lstm_pointwise_fwd(float* pre, const float* c_prev, float* c_out, float* h_o
 // dc_io: in = dL/dc_t from step t+1 (rows < b_next, else 0), out = dL/dc_{t-1}.
 // dpre: [b][4H] gradient wrt pre-activations.
 __global__ __launch_bounds__(256) void lstm_pointwise_bwd_kernel(
-    const float* __restrict__ gates, const float* __restrict__ c, const float* __restrict__ c_prev,
-    const float* __restrict__ dH, const float* __restrict__ dh_rec, float* __restrict__ dc_io,
-    float* __restrict__ dpre, int b, int b_next, int H, int gi, int gf, int go, int gg,
-    int tanh_out) {
+    const float* __restrict__ gates, long ldg, const float* __restrict__ c,
+    const float* __restrict__ c_prev, const float* __restrict__ dH,
+    const float* __restrict__ dh_rec, float* __restrict__ dc_io, float* __restrict__ dpre, long ldq,
+    int b, int b_next, int H, int gi, int gf, int go, int gg, int tanh_out) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= b * H) return;
   const int row = idx / H, j = idx - row * H;
-  const float* p = gates + (long)row * 4 * H;
+  const float* p = gates + (long)row * ldg;
   const float i = p[gi * H + j], f = p[gf * H + j], o = p[go * H + j], g = p[gg * H + j];
   const float ct = c[(long)row * H + j];
   const float cp = c_prev ? c_prev[(long)row * H + j] : 0.f;
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256) void lstm_pointwise_bwd_kernel(
     dc += dh * o;
   }
   const float di = dc * g, dg = dc * i, df = dc * cp;
-  float* q = dpre + (long)row * 4 * H;
+  float* q = dpre + (long)row * ldq;
   q[gi * H + j] = di * i * (1.f - i);
   q[gf * H + j] = df * f * (1.f - f);
   q[go * H + j] = d_o * o * (1.f - o);
@@ -244,13 +244,14 @@ __global__ __launch_bounds__(256) void lstm_pointwise_bwd_kernel(
   dc_io[(long)row * H + j] = dc * f;
 }
 
-int lstm_pointwise_bwd(const float* gates, const float* c, const float* c_prev, const float* dH,
-                       const float* dh_rec, float* dc_io, float* dpre, int b, int b_next, int H,
-                       int gi, int gf, int go, int gg, int tanh_out, hipStream_t stream) {
+int lstm_pointwise_bwd(const float* gates, long ldg, const float* c, const float* c_prev,
+                       const float* dH, const float* dh_rec, float* dc_io, float* dpre, long ldq,
+                       int b, int b_next, int H, int gi, int gf, int go, int gg, int tanh_out,
+                       hipStream_t stream) {
   if (b <= 0) return kOk;
   hipLaunchKernelGGL(lstm_pointwise_bwd_kernel, dim3(cdiv((long)b * H, 256)), dim3(256), 0, stream,
-                     gates, c, c_prev, dH, dh_rec, dc_io, dpre, b, b_next, H, gi, gf, go, gg,
-                     tanh_out);
+                     gates, ldg, c, c_prev, dH, dh_rec, dc_io, dpre, ldq, b, b_next, H, gi, gf, go,
+                     gg, tanh_out);
   CAPNET_LAUNCH_CHECK();
   return kOk;
 }
@@ -316,6 +317,34 @@ int gather_rows(const float* src, const int* idx, float* out, int rows, int C,
   return kOk;
 }
 
+// out[r] = idx[r] >= 0 ? src[idx[r]] : first[sample[r]]  (h_{t-1} of every packed row when the
+// initial state is not zero: attention decoders, model_att.py:260)
+__global__ __launch_bounds__(256) void gather_prev_rows_kernel(const float* __restrict__ src,
+                                                               const int* __restrict__ idx,
+                                                               const float* __restrict__ first,
+                                                               const int* __restrict__ sample,
+                                                               float* __restrict__ out, int rows,
+                                                               int C) {
+  const long total = (long)rows * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / C), c = (int)(i - (long)r * C);
+    const int s = idx[r];
+    out[i] = s >= 0 ? src[(long)s * C + c] : first[(long)sample[r] * C + c];
+  }
+}
+
+int gather_prev_rows(const float* src, const int* idx, const float* first, const int* sample,
+                     float* out, int rows, int C, hipStream_t stream) {
+  if (rows <= 0) return kOk;
+  const long total = (long)rows * C;
+  hipLaunchKernelGGL(gather_prev_rows_kernel,
+                     dim3((int)(cdiv(total, 256) > 4096 ? 4096 : cdiv(total, 256))), dim3(256), 0,
+                     stream, src, idx, first, sample, out, rows, C);
+  CAPNET_LAUNCH_CHECK();
+  return kOk;
+}
+
 // ---- column sums: out[c] (+)= sum_r x[r][c] ------------------------------------------------
 // one workgroup per 64 columns, 4 row lanes; fixed summation order (deterministic).
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, long ld, int rows,
@@ -347,7 +376,7 @@ int colsum(const float* x, long ld, int rows, int C, float* out, int accumulate,
 // ---- embedding / feature gradient scatter --------------------------------------------------
 // dX [N][E] -> dEmb[token] (atomic, tokens repeat) or dFeat[sample] (one row per sample).
 __global__ __launch_bounds__(128) void scatter_input_grad_kernel(
-    const float* __restrict__ dX, int E, const int* __restrict__ row_sample,
+    const float* __restrict__ dX, long ldx, int E, const int* __restrict__ row_sample,
     const int* __restrict__ row_col, const int* __restrict__ row_token, float* __restrict__ dEmb,
     float* __restrict__ dFeat, int V, float p, unsigned long long seed, int use_dropout) {
   const int r = blockIdx.x;
@@ -357,24 +386,24 @@ __global__ __launch_bounds__(128) void scatter_input_grad_kernel(
   if (col == -1) {
     if (dFeat)
       for (int e = threadIdx.x; e < E; e += blockDim.x)
-        dFeat[(long)sample * E + e] = dX[(long)r * E + e];
+        dFeat[(long)sample * E + e] = dX[(long)r * ldx + e];
     return;
   }
   int tok = row_token[r];
   if (tok < 0 || tok >= V) return;
   const bool drop = (col >= 0) && use_dropout;
   for (int e = threadIdx.x; e < E; e += blockDim.x) {
-    float g = dX[(long)r * E + e];
+    float g = dX[(long)r * ldx + e];
     if (drop) g *= dropout_scale(seed, sample, col, e, p, inv_keep);
     atomicAdd(dEmb + (long)tok * E + e, g);
   }
 }
 
-int scatter_input_grad(const float* dX, int N, int E, const int* row_sample, const int* row_col,
+int scatter_input_grad(const float* dX, long ldx, int N, int E, const int* row_sample, const int* row_col,
                        const int* row_token, float* dEmb, float* dFeat, int V, float p,
                        unsigned long long seed, int use_dropout, hipStream_t stream) {
   if (N <= 0) return kOk;
-  hipLaunchKernelGGL(scatter_input_grad_kernel, dim3(N), dim3(128), 0, stream, dX, E, row_sample,
+  hipLaunchKernelGGL(scatter_input_grad_kernel, dim3(N), dim3(128), 0, stream, dX, ldx, E, row_sample,
                      row_col, row_token, dEmb, dFeat, V, p, seed, use_dropout);
   CAPNET_LAUNCH_CHECK();
   return kOk;

@@ -1,15 +1,19 @@
-"""Attention-path encoder on the MI355X kernels (stylenet/model_att.py:11-29).
+"""Attention path on the MI355X kernels: EncoderCNN, Attention, DecoderFactoredLSTMAtt
+(stylenet/model_att.py).
 
 EncoderCNN(encoded_image_size=14): ResNet-152 children[:-2] under no_grad, AdaptiveAvgPool2d
 to 14x14 (an exact 2x replication of the 7x7 map), permuted to NHWC. The trunk already produces
-NHWC, so the permute costs nothing here. The attention decoder is not built yet.
+NHWC, so the permute costs nothing here.
 """
+import sys
+
 import torch
 import torch.nn as nn
 
 from . import _lib, ops
 from ._lib import CapnetError, check, current_stream, ptr
-from .model import _Marker, _TrunkRunner, _resnet152_children
+from .model import (Dropout, Embedding, Linear, _Marker, _MODES, _TrunkRunner, _dropout_seed,
+                    _resnet152_children, _resolve_tf_mask)
 
 
 class EncoderCNN(nn.Module):
@@ -41,3 +45,121 @@ class EncoderCNN(nn.Module):
                                                             2048, current_stream()),
                   "capnet_adaptive_pool_replicate")
         return out
+
+
+class Attention(nn.Module):
+    """stylenet/model_att.py:32-70 (parameter container + single-step forward)."""
+
+    def __init__(self, encoder_dim, decoder_dim, attention_dim):
+        super(Attention, self).__init__()
+        self.encoder_att = Linear(encoder_dim, attention_dim)
+        self.decoder_att = Linear(decoder_dim, attention_dim)
+        self.full_att = Linear(attention_dim, 1)
+        self.relu = _Marker()
+        self.softmax = _Marker()
+
+
+class DecoderFactoredLSTMAtt(nn.Module):
+    """stylenet/model_att.py:73-426. `num_layers` is accepted and ignored, as in the reference.
+    The image features carry no gradient (the attention encoder has no trainable parameter)."""
+
+    def __init__(self,
+                 attention_size,
+                 embed_size,
+                 hidden_size,
+                 factored_size,
+                 vocab_size,
+                 num_layers,
+                 feature_size=2048,
+                 bias=True,
+                 dropout=0.22,
+                 max_seq_length=40):
+        super(DecoderFactoredLSTMAtt, self).__init__()
+        if not bias:
+            raise CapnetError("DecoderFactoredLSTMAtt: bias=False is not supported by the HIP path")
+        self.attention_size = attention_size
+        self.feature_size = feature_size
+        self.hidden_size = hidden_size
+        self.factored_size = factored_size
+        self.embed_size = embed_size
+        self.vocab_size = vocab_size
+        self.max_seq_length = max_seq_length
+        # registration order follows stylenet/model_att.py:92-164 (state_dict order)
+        self.init_h = Linear(feature_size, hidden_size)
+        self.init_c = Linear(feature_size, hidden_size)
+        self.dropout = Dropout(dropout)
+        self.attention = Attention(feature_size, hidden_size, attention_size)
+        self.B = Embedding(vocab_size, embed_size)
+        self.f_beta = Linear(hidden_size, feature_size)
+        self.sigmoid = _Marker()
+        for g in "ifoc":
+            setattr(self, "U_" + g, Linear(factored_size, hidden_size, bias=bias))
+            setattr(self, "S_f" + g, Linear(factored_size, factored_size, bias=bias))
+            setattr(self, "V_" + g, Linear(embed_size + feature_size, factored_size, bias=bias))
+            setattr(self, "W_" + g, Linear(hidden_size, hidden_size, bias=bias))
+        for emo in ("happy", "sad", "angry"):
+            setattr(self, "attention_" + emo, Attention(feature_size, hidden_size, attention_size))
+            for g in "ifoc":
+                setattr(self, "S_%s_%s" % (emo, g), Linear(factored_size, factored_size, bias=bias))
+        self.C = Linear(hidden_size, vocab_size, bias=bias)
+        self.reset_parameters()
+        self.init_weights()
+
+    def reset_parameters(self):
+        for p in self.parameters():
+            if p.data.ndimension() >= 2:
+                nn.init.xavier_uniform_(p.data)
+            else:
+                nn.init.zeros_(p.data)
+
+    def init_weights(self):
+        self.B.weight.data.uniform_(-0.1, 0.1)
+        self.C.bias.data.fill_(0)
+        self.C.weight.data.uniform_(-0.1, 0.1)
+
+    def _mode_modules(self, mode):
+        if mode == "factual":
+            return self.attention, [getattr(self, "S_f" + g) for g in "ifoc"]
+        if mode in _MODES:
+            return (getattr(self, "attention_" + mode),
+                    [getattr(self, "S_%s_%s" % (mode, g)) for g in "ifoc"])
+        sys.stderr.write("mode name wrong!")      # the reference then fails with UnboundLocalError
+        raise ValueError("unknown mode %r (expected one of %s)" % (mode, ", ".join(_MODES)))
+
+    def _weights(self, mode):
+        att, S = self._mode_modules(mode)
+        V = [getattr(self, "V_" + g) for g in "ifoc"]
+        U = [getattr(self, "U_" + g) for g in "ifoc"]
+        W = [getattr(self, "W_" + g) for g in "ifoc"]
+        out = []
+        for grp in (V, S, U, W):
+            out += [m.weight for m in grp]
+            out += [m.bias for m in grp]
+        for m in (self.init_h, self.init_c, att.encoder_att, att.decoder_att, att.full_att, self.f_beta):
+            out += [m.weight, m.bias]
+        return out
+
+    def forward(self,
+                captions,
+                lengths,
+                features,
+                teacher_forcing_ratio=0.8,
+                mode='factual',
+                tf_mask=None):
+        """Returns (outputs [N, V], alphas [B, max(lengths), P])."""
+        batch_size = captions.size(0)
+        features = features.reshape(batch_size, -1, features.size(-1))
+        batch_sizes = ops.batch_sizes_from_lengths(lengths)
+        cfg = {
+            "batch_sizes": batch_sizes,
+            "tf_mask": _resolve_tf_mask(tf_mask, len(batch_sizes), teacher_forcing_ratio),
+            "hidden_size": self.hidden_size,
+            "factored_size": self.factored_size,
+            "attention_size": self.attention_size,
+            "dropout": self.dropout.p if self.training else 0.0,
+            "seed": _dropout_seed(self.training, self.dropout.p),
+            "training": self.training,
+        }
+        hiddens, alphas = ops.decoder_att_sequence(cfg, captions, features.detach(), self.B.weight,
+                                                   self.C.weight, self.C.bias, self._weights(mode))
+        return self.C(hiddens), alphas

@@ -420,3 +420,102 @@ class DecoderSeqFn(torch.autograd.Function):
 
 def decoder_sequence(cfg, captions, features, emb, Cw, Cb, weights):
     return DecoderSeqFn.apply(cfg, captions, features, emb, Cw, Cb, *weights)
+
+
+# ---------------------------------------------------------------------------------------
+# autograd: whole-sequence attention decoder (DecoderFactoredLSTMAtt)
+# ---------------------------------------------------------------------------------------
+class DecoderAttSeqFn(torch.autograd.Function):
+    """(hiddens [N,H], alphas [B,steps,P]) of the attention recurrence.
+
+    weights: 44 tensors in the order of capnet_att_seq_forward (V w x4, V b x4, S w x4, S b x4,
+    U w x4, U b x4, W w x4, W b x4, init_h w,b, init_c w,b, encoder_att w,b, decoder_att w,b,
+    full_att w,b, f_beta w,b). `features` gets no gradient (frozen trunk)."""
+
+    @staticmethod
+    def forward(ctx, cfg, captions, features, emb, Cw, Cb, *weights):
+        _need_cuda(captions, features, emb, Cw, Cb, *weights)
+        if len(weights) != 44:
+            raise CapnetError("attention decoder takes 44 weight tensors")
+        captions = _c(captions)
+        if captions.dtype != torch.int64:
+            raise CapnetError("captions must be int64")
+        dev = emb.device
+        bs, tf = cfg["batch_sizes"], cfg["tf_mask"]
+        B, T = captions.shape
+        V, E = emb.shape
+        H, F, A = cfg["hidden_size"], cfg["factored_size"], cfg["attention_size"]
+        features = _c(features)
+        if features.dim() != 3 or features.shape[0] != B:
+            raise CapnetError("features must be [batch, pixels, feature_size]")
+        P, Cf = features.shape[1], features.shape[2]
+        N = sum(bs)
+        if len(tf) != len(bs) or bs[0] != B:
+            raise CapnetError("attention decoder: batch_sizes / tf_mask do not match the batch")
+        dims = [B, T, len(bs), N, E, F, H, V, A, P, Cf]
+        ws = [_c(w) for w in weights]
+        emb_c, Cw_c, Cb_c = _c(emb), _c(Cw), _c(Cb)
+        cdims = int_array(dims)
+        L = _lib.lib()
+        saved = torch.empty(L.capnet_att_saved_floats(cdims), dtype=torch.float32, device=dev)
+        saved_i = torch.empty(L.capnet_att_saved_ints(cdims), dtype=torch.int32, device=dev)
+        scratch = torch.empty(L.capnet_att_fwd_scratch_floats(cdims), dtype=torch.float32, device=dev)
+        hiddens = torch.empty((N, H), dtype=torch.float32, device=dev)
+        alphas = torch.empty((B, len(bs), P), dtype=torch.float32, device=dev)
+        tfm = (C.c_ubyte * len(tf))(*[1 if x else 0 for x in tf])
+        check(L.capnet_att_seq_forward(cdims, int_array(bs), tfm, ptr(captions), ptr(features),
+                                       ptr(emb_c), ptr_array(ws), ptr(Cw_c), ptr(Cb_c),
+                                       float(cfg["dropout"]), int(cfg["seed"]), int(cfg["training"]),
+                                       ptr(saved), ptr(saved_i), ptr(scratch), ptr(hiddens),
+                                       ptr(alphas), ptr(err_flag(dev)), current_stream()),
+              "capnet_att_seq_forward")
+        ctx.cfg, ctx.dims = cfg, dims
+        ctx.save_for_backward(saved, saved_i, hiddens, features, *ws)
+        return hiddens, alphas
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, d_hiddens, d_alphas):
+        saved, saved_i, hiddens, features = ctx.saved_tensors[:4]
+        ws = list(ctx.saved_tensors[4:])
+        cfg, dims = ctx.cfg, ctx.dims
+        B, T, steps, N, E, F, H, V, A, P, Cf = dims
+        dev = saved.device
+        L = _lib.lib()
+        cdims = int_array(dims)
+        scratch = torch.empty(L.capnet_att_bwd_scratch_floats(cdims), dtype=torch.float32, device=dev)
+        d_hiddens = _c(d_hiddens)
+        d_alphas = _c(d_alphas) if d_alphas is not None else None
+
+        def new(*shape):
+            return torch.empty(shape, dtype=torch.float32, device=dev)
+
+        ZW, XW = 4 * H + A + Cf, E + Cf
+        dV, dbV, dS, dbS, dU = new(4 * F, XW), new(4 * F), new(4, F, F), new(4 * F), new(4, H, F)
+        dWz, dbz = new(ZW, H), new(ZW)
+        dWe, dbe, dwf, dbf = new(A, Cf), new(A), new(1, A), new(1)
+        dWih, dbih, dWic, dbic = new(H, Cf), new(H), new(H, Cf), new(H)
+        dEmb = new(V, E)
+        grads = [dV, dbV, dS, dbS, dU, dWz, dbz, dWe, dbe, dwf, dbf, dWih, dbih, dWic, dbic, dEmb]
+        check(L.capnet_att_seq_backward(cdims, int_array(cfg["batch_sizes"]), ptr(d_hiddens),
+                                        ptr(d_alphas), ptr(hiddens), ptr(features), ptr_array(ws),
+                                        ptr(saved), ptr(saved_i), ptr(scratch), ptr_array(grads),
+                                        float(cfg["dropout"]), int(cfg["seed"]), int(cfg["training"]),
+                                        current_stream()), "capnet_att_seq_backward")
+        wg = ([dV[g * F:(g + 1) * F] for g in range(4)] +
+              [dbV[g * F:(g + 1) * F] for g in range(4)] +
+              [dS[g] for g in range(4)] +
+              [dbS[g * F:(g + 1) * F] for g in range(4)] +
+              [dU[g] for g in range(4)] +
+              [dbz[g * H:(g + 1) * H] for g in range(4)] +
+              [dWz[g * H:(g + 1) * H] for g in range(4)] +
+              [dbz[g * H:(g + 1) * H].clone() for g in range(4)] +
+              [dWih, dbih, dWic, dbic, dWe, dbe,
+               dWz[4 * H:4 * H + A], dbz[4 * H:4 * H + A], dwf, dbf,
+               dWz[4 * H + A:], dbz[4 * H + A:]])
+        # cfg, captions, features, emb, Cw, Cb, *weights
+        return (None, None, None, dEmb, None, None) + tuple(wg)
+
+
+def decoder_att_sequence(cfg, captions, features, emb, Cw, Cb, weights):
+    return DecoderAttSeqFn.apply(cfg, captions, features, emb, Cw, Cb, *weights)

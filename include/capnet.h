@@ -181,6 +181,38 @@ int capnet_seq_backward(const int* dims, const int* batch_sizes, const float* d_
                         float* scratch, float* const* grads, float dropout_p,
                         unsigned long long seed, int training, capnet_stream_t stream);
 
+/* ---- attention decoder: DecoderFactoredLSTMAtt.forward (stylenet/model_att.py:238-305) ----
+ * dims (host int[11]) = {B, T, steps, N, E, F, H, V, A, P, C}: A attention size, P pixels
+ * (14*14), C feature size (2048; must be a multiple of 512). captions are the reference's
+ * captions[:, :-1] (T columns), batch_sizes / tf_mask as for capnet_seq_forward, features the
+ * NHWC map [B][P][C] of the attention encoder (no gradient: the trunk is frozen).
+ * weights (host array of 44 device pointers): [0..31] V/S/U/W weights and biases per gate as in
+ * capnet_seq_forward (V_g is [F][E+C]); [32,33] init_h w,b  [34,35] init_c  [36,37] the selected
+ * attention module's encoder_att  [38,39] decoder_att  [40,41] full_att  [42,43] f_beta.
+ * Outputs: hiddens [N][H]; alphas [B][steps][P] (zero where a sequence has ended, :261,296).
+ * encoder_att(features) is computed once per call, not once per step (:59,279). */
+size_t capnet_att_saved_floats(const int* dims);
+size_t capnet_att_saved_ints(const int* dims);
+size_t capnet_att_fwd_scratch_floats(const int* dims);
+size_t capnet_att_bwd_scratch_floats(const int* dims);
+int capnet_att_seq_forward(const int* dims, const int* batch_sizes, const unsigned char* tf_mask,
+                           const long long* captions, const float* features, const float* emb,
+                           const float* const* weights, const float* Cw, const float* Cb,
+                           float dropout_p, unsigned long long seed, int training, float* saved,
+                           int* saved_i, float* scratch, float* hiddens, float* alphas,
+                           int* err_flag, capnet_stream_t stream);
+/* grads (host array of 16 device pointers, all written): [0] dV [4F][E+C]  [1] dV bias [4F]
+ * [2] dS [4][F][F]  [3] dS bias  [4] dU [4][H][F]
+ * [5] dWz [4H+A+C][H] = [dW_i; dW_f; dW_o; dW_c; d decoder_att.weight; d f_beta.weight]
+ * [6] dbz [4H+A+C] (first 4H: U and W biases)  [7] d encoder_att.weight [A][C]  [8] its bias
+ * [9] d full_att.weight [A]  [10] d full_att.bias [1]  [11] d init_h.weight [H][C]  [12] bias
+ * [13] d init_c.weight  [14] bias  [15] d emb [V][E].  d_alphas may be NULL. */
+int capnet_att_seq_backward(const int* dims, const int* batch_sizes, const float* d_hiddens,
+                            const float* d_alphas, const float* hiddens, const float* features,
+                            const float* const* weights, const float* saved, const int* saved_i,
+                            float* scratch, float* const* grads, float dropout_p,
+                            unsigned long long seed, int training, capnet_stream_t stream);
+
 /* Single-step pieces used by forward_step() / sample() (no autograd):
  *   out[r] = emb[idx[r]]                      -- self.B(k_prev_words), stylenet/model.py:221
  *   gate pointwise on pre-activations [b][4H] (in place: overwritten by the activated gates),

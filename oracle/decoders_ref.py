@@ -103,3 +103,63 @@ def packed_targets(captions, lengths):
     (stylenet/train_multitask.py:377-379)."""
     bs = batch_sizes(lengths)
     return torch.cat([captions[:b, t] for t, b in enumerate(bs)], 0)
+
+
+# ---------------------------------------------------------------------------------------
+# attention decoder: DecoderFactoredLSTMAtt.forward, stylenet/model_att.py:238-305
+# ---------------------------------------------------------------------------------------
+MODE_ATT = {"factual": "attention", "happy": "attention_happy", "sad": "attention_sad",
+            "angry": "attention_angry"}
+
+
+def attention_step(p, prefix, feat, h):
+    """Attention.forward, stylenet/model_att.py:51-70."""
+    att1 = _lin(p, prefix + ".encoder_att", feat)                 # recomputed every step there
+    att2 = _lin(p, prefix + ".decoder_att", h)
+    att = _lin(p, prefix + ".full_att", torch.relu(att1 + att2.unsqueeze(1))).squeeze(2)
+    alpha = torch.softmax(att, dim=1)
+    return (feat * alpha.unsqueeze(2)).sum(dim=1), alpha
+
+
+def factored_att_forward(p, captions, lengths, features, tf_mask, mode="factual", drop_mask=None):
+    """Returns (packed logits [N, V], alphas [B, max(lengths), P]). `captions` / `lengths` are what
+    the training loop passes: captions[:, :-1] and lengths - 1 (train_multitask_att.py:402-408)."""
+    B = captions.size(0)
+    feat = features.reshape(B, -1, features.size(-1))
+    P = feat.size(1)
+    emb_w = p["B.weight"]
+    embeddings = emb_w[captions]
+    if drop_mask is not None:
+        embeddings = embeddings * drop_mask
+    bs = batch_sizes(lengths)
+    mean = feat.mean(dim=1)
+    h = _lin(p, "init_h", mean)
+    c = _lin(p, "init_c", mean)
+    alphas = torch.zeros(B, max(lengths), P, dtype=emb_w.dtype)
+    hiddens, alpha_list = [], []
+    predicted = captions[:, 0:1]
+    att = MODE_ATT[mode]
+    for i, b in enumerate(bs):
+        awe, alpha = attention_step(p, att, feat[:b], h[:b])
+        gate = torch.sigmoid(_lin(p, "f_beta", h[:b]))
+        awe = gate * awe
+        if tf_mask[i]:
+            x = embeddings[:b, i, :]
+        else:
+            x = emb_w[predicted][:b, 0, :]
+        h, c = factored_step(p, torch.cat([x, awe], dim=1), h[:b], c[:b], mode)
+        hiddens.append(h)
+        alpha_list.append((b, i, alpha))
+        predicted = Fn.linear(h, p["C.weight"], p["C.bias"]).max(1)[1].unsqueeze(1)
+    # alphas[:b, i, :] = alpha without in-place writes (keeps autograd simple)
+    cols = []
+    for b, i, alpha in alpha_list:
+        cols.append(torch.cat([alpha, torch.zeros(B - b, P, dtype=alpha.dtype)], 0).unsqueeze(1))
+    alphas = torch.cat(cols, 1)
+    return Fn.linear(torch.cat(hiddens, 0), p["C.weight"], p["C.bias"]), alphas
+
+
+def att_loss(logits, alphas, targets, alpha_c=1.0):
+    """criterion(outputs, targets) + alpha_c * ((1 - alphas.sum(dim=1))**2).mean()
+    (stylenet/train_multitask_att.py:409-411)."""
+    return Fn.cross_entropy(logits, targets) + alpha_c * ((1.0 - alphas.sum(dim=1)) ** 2).mean()

@@ -110,3 +110,29 @@ def test_trunk_oracle_fp32_against_fp64_fixture():
         y = net(imgs).reshape(int(z["B"]), -1)
     e = rel_err(y, z["pooled_train"])
     assert 1e-6 < e < 2e-3, e
+
+
+@pytest.mark.parametrize("cname", ["tf1_factual", "tf0_happy", "tfmix_factual", "tfmix_sad"])
+def test_attention_decoder_matches_reference(cname):
+    """oracle factored_att_forward vs DecoderFactoredLSTMAtt run verbatim (fixture)."""
+    z = load_golden("decoder_att_tiny.npz")
+    c = golden_case(z, cname)
+    p = {k: v.clone().requires_grad_(True) for k, v in golden_params(z).items()}
+    captions, lengths, feats = t(z["captions"]), z["lengths"].tolist(), t(z["features"])
+    lens = [l - 1 for l in lengths]
+    tf = [bool(x) for x in c["tf_mask"]]
+    logits, alphas = D.factored_att_forward(p, captions[:, :-1], lens, feats, tf, mode=str(c["mode"]))
+    loss = D.att_loss(logits, alphas, D.packed_targets(captions[:, 1:], lens))
+    loss.backward()
+    assert rel_err(logits, c["logits"]) < TOL
+    assert rel_err(alphas, c["alphas"]) < TOL
+    assert abs(loss.item() - float(c["loss"])) < 2e-6
+    n = 0
+    for k, v in p.items():
+        key = "grad." + k
+        if key in c:
+            assert rel_err(v.grad, c[key]) < 2e-5, k
+            n += 1
+        else:
+            assert v.grad is None or float(v.grad.abs().max()) == 0.0, k
+    assert n > 30

@@ -266,6 +266,49 @@ def gen_trunk():
     save("trunk_b3.npz", arrays)
 
 
+def gen_att_tiny():
+    """DecoderFactoredLSTMAtt (stylenet/model_att.py) on the training-loop call pattern of
+    stylenet/train_multitask_att.py:402-411: captions[:, :-1], lengths-1, loss + alpha penalty."""
+    ref = load_ref("stylenet", "model_att")
+    A, E, H, F, V, Cf, P = 16, 12, 16, 16, 37, 512, 4
+    dec = ref.DecoderFactoredLSTMAtt(A, E, H, F, V, 1, feature_size=Cf, dropout=0.0)
+    dec.train()
+    state = synthetic.decoder_state(dec.state_dict(), seed=11, bias_range=0.1)
+    dec.load_state_dict(state)
+    captions, lengths, _ = tiny_inputs(V, E, 23)
+    g = torch.Generator().manual_seed(24)
+    features = torch.randn(4, 2, 2, Cf, generator=g)          # NHWC map, P = 4 pixels
+    arrays = {"captions": captions.numpy(), "lengths": np.array(lengths), "features": features.numpy(),
+              "dims": np.array([A, E, H, F, V, Cf, P])}
+    for k, v in state.items():
+        arrays["param." + k] = v.numpy()
+    names = []
+    for cname, mode, seed, ratio in [("tf1_factual", "factual", 100, 1.0), ("tf0_happy", "happy", 101, 0.0),
+                                     ("tfmix_factual", "factual", 3, 0.6), ("tfmix_sad", "sad", 5, 0.6)]:
+        dec.zero_grad()
+        lens = [l - 1 for l in lengths]
+        targets = pack_padded_sequence(captions[:, 1:], lens, batch_first=True)[0]
+        random.seed(seed)
+        outputs, alphas = dec(captions[:, :-1], lens, features, teacher_forcing_ratio=ratio, mode=mode)
+        ce = nn.CrossEntropyLoss()(outputs, targets)
+        loss = ce + 1. * ((1. - alphas.sum(dim=1)) ** 2).mean()
+        loss.backward()
+        names.append(cname)
+        pre = "case.%s." % cname
+        arrays[pre + "mode"] = np.array(mode)
+        arrays[pre + "logits"] = outputs.detach().numpy()
+        arrays[pre + "alphas"] = alphas.detach().numpy()
+        arrays[pre + "loss"] = loss.detach().numpy()
+        arrays[pre + "ce"] = ce.detach().numpy()
+        arrays[pre + "tf_mask"] = np.array(tf_draws(seed, max(lens), ratio), dtype=np.uint8)
+        for k, prm in dec.named_parameters():
+            if prm.grad is not None:
+                arrays[pre + "grad." + k] = prm.grad.detach().numpy().copy()
+        print("att", cname, "tf", arrays[pre + "tf_mask"].tolist(), "loss", float(loss), "ce", float(ce))
+    arrays["cases"] = np.array(names)
+    save("decoder_att_tiny.npz", arrays)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     which = sys.argv[1:] or ["factored_tiny", "nic_tiny", "factored_full"]
@@ -277,3 +320,5 @@ if __name__ == "__main__":
         gen_factored_full()
     if "trunk" in which:
         gen_trunk()
+    if "att_tiny" in which:
+        gen_att_tiny()
