@@ -34,7 +34,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="images per GPU")
     ap.add_argument("--vocab", type=int, default=8192)
-    ap.add_argument("--decoder", default="factored", choices=["factored", "nic"])
+    ap.add_argument("--decoder", default="factored", choices=["factored", "nic", "att"],
+                    help="factored = BASELINE configs[1] (the headline); nic = config 0's decoder; "
+                         "att = config 3's attention decoder (secondary workloads)")
     ap.add_argument("--dropout", type=float, default=0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-conv-events", action="store_true",
@@ -137,20 +139,27 @@ def main():
     from capnet.model import DecoderFactoredLSTM, EncoderCNN
     from capnet.nic_model import DecoderRNN
     from capnet.parallel import DataParallelAdam
-    from capnet.train import CrossEntropyLoss, train_step
+    from capnet.train import CrossEntropyLoss, train_step, train_step_att
+    from capnet import model_att
 
     B, V = args.batch, args.vocab
     torch.manual_seed(1234)
-    encoder = EncoderCNN(300)
+    encoder = EncoderCNN(300) if args.decoder != "att" else model_att.EncoderCNN(14)
     if args.decoder == "factored":
         decoder = DecoderFactoredLSTM(300, 512, 512, V, 1, dropout=args.dropout)
+    elif args.decoder == "att":
+        decoder = model_att.DecoderFactoredLSTMAtt(512, 300, 512, 512, V, 1, dropout=args.dropout)
     else:
         decoder = DecoderRNN(300, 512, V, 1, dropout=args.dropout)
     decoder.load_state_dict(synthetic.decoder_state(decoder.state_dict(), seed=1234))
     encoder.to(dev).train()
     decoder.to(dev).train()
-    params = list(decoder.parameters()) + list(encoder.linear.parameters()) + list(encoder.bn.parameters())
-    optimizer = DataParallelAdam(params, lr=2e-4, overlap=True).attach(encoder)
+    params = list(decoder.parameters())
+    if args.decoder != "att":
+        params += list(encoder.linear.parameters()) + list(encoder.bn.parameters())
+    optimizer = DataParallelAdam(params, lr=2e-4, overlap=True)
+    if args.decoder != "att":
+        optimizer.attach(encoder)
     criterion = CrossEntropyLoss()
 
     # every rank can rebuild every rank's lengths (seeded), so token weights and the global
@@ -166,6 +175,10 @@ def main():
 
     def step():
         tf = [random.random() < 0.8 for _ in range(global_steps)]
+        if args.decoder == "att":
+            optimizer.wait_for_update()   # no trainable encoder head to hang the wait on
+            return train_step_att(encoder, decoder, optimizer, criterion, images, captions, lengths,
+                                  0.5, tf_mask=tf, loss_scale=loss_scale)
         return train_step(encoder, decoder, optimizer, criterion, images, captions, lengths, 0.5,
                           tf_mask=tf, loss_scale=loss_scale)
 
@@ -238,7 +251,10 @@ def main():
             "loss_last": round(float(last.item()), 5),
             "roofline": roofline,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if args.decoder != "factored":
+            out["config"]["workload"] = out["config"]["workload"].replace(
+                "configs[1]: StyleNet FactoredLSTM", "secondary (--decoder %s): " % args.decoder)
+        if world == 1 and not args.no_cpu_baseline and args.decoder == "factored":
             out["cpu_baseline"] = cpu_baseline(args, args.cpu_steps)
         else:
             out["cpu_baseline"] = None

@@ -52,6 +52,33 @@ def train_step(encoder, decoder, optimizer, criterion, images, captions, lengths
     return loss.detach()
 
 
+def train_step_att(encoder, decoder, optimizer, criterion, images, captions, lengths, grad_clip,
+                   mode=None, zero_encoder_grad=True, teacher_forcing_ratio=0.8, tf_mask=None,
+                   alpha_c=1.0, loss_scale=None):
+    """One step of the attention loops (stylenet/train_multitask_att.py:398-417): inputs
+    captions[:, :-1], targets captions[:, 1:], lengths-1, loss += alpha_c*((1-sum_t alpha)^2).mean().
+    `lengths` are the loader's lengths (the -1 is applied here, as the reference does at :402)."""
+    lengths = [l - 1 for l in lengths]
+    targets = ops.packed_targets(captions[:, 1:].contiguous(), lengths)
+    features = encoder(images)
+    kw = {}
+    if mode is not None:
+        kw["mode"] = mode
+    if tf_mask is not None:
+        kw["tf_mask"] = tf_mask
+    outputs, alphas = decoder(captions[:, :-1].contiguous(), lengths, features,
+                              teacher_forcing_ratio=teacher_forcing_ratio, **kw)
+    loss = criterion(outputs, targets)
+    loss = loss + alpha_c * ((1. - alphas.sum(dim=1)) ** 2).mean()
+    decoder.zero_grad()
+    if zero_encoder_grad:
+        encoder.zero_grad()
+    (loss if loss_scale is None else loss * loss_scale).backward()
+    clip_gradient(optimizer, grad_clip)
+    optimizer.step()
+    return loss.detach()
+
+
 def _drain(pending, meter):
     for loss, n in pending:
         meter.update(loss.item(), n)
