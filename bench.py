@@ -227,6 +227,55 @@ def main():
                         "launches": n.value, "avg_launch_us": round(ms.value * 1e3 / n.value, 2),
                         "flops_per_launch": fl.value / n.value}
 
+    # secondary roofline: the recurrent LSTM step (5.77 MB of algorithmic HBM
+    # traffic per step at b=64, H=512), timed with events on the launch stream
+    lstm = None
+    if rank == 0:
+        Hh, bb = 512, 64
+        hp = torch.randn(bb, Hh, device=dev) * 0.1
+        wc = torch.randn(4 * Hh, Hh, device=dev) * 0.05
+        wfrag = torch.empty(lib.capnet_lstm_wfrag_floats(Hh), device=dev)
+        capnet._lib.check(lib.capnet_lstm_pack_wfrag(wc.data_ptr(), wfrag.data_ptr(), Hh, 0,
+                                                     capnet._lib.current_stream()))
+        gts0 = torch.randn(bb, 4 * Hh, device=dev)
+        cp = torch.randn(bb, Hh, device=dev) * 0.1
+        co, ho, gts = torch.empty_like(cp), torch.empty_like(cp), gts0.clone()
+        st = capnet._lib.current_stream()
+
+        def lstm_step():
+            capnet._lib.check(lib.capnet_lstm_step_fused(hp.data_ptr(), wfrag.data_ptr(), gts.data_ptr(),
+                                                         4 * Hh, cp.data_ptr(), co.data_ptr(),
+                                                         ho.data_ptr(), bb, Hh, 0, st))
+        for _ in range(5):
+            lstm_step()
+        torch.cuda.synchronize()
+        # 24 dependent steps (one caption's worth) captured in a hipGraph, so that the host's
+        # ctypes/launch cost (~8 us per call) is not what gets timed
+        n_steps, n_rep = 24, 20
+        side = torch.cuda.Stream()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            st = capnet._lib.current_stream()
+            with torch.cuda.graph(graph, stream=side):
+                st = capnet._lib.current_stream()
+                for _ in range(n_steps):
+                    lstm_step()
+        st = capnet._lib.current_stream()
+        graph.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n_rep):
+            graph.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / (n_rep * n_steps)
+        step_bytes = 4 * Hh * Hh * 4 + bb * 4 * Hh * 4 + bb * Hh * 4 * 4 + bb * 4 * Hh * 4
+        lstm = {"bound": "hbm", "kernel": "lstm_step_fused_kernel (b=64, H=512; 24 dependent steps replayed from a hipGraph)",
+                "achieved": round(step_bytes / us / 1e3, 1), "peak": 8000.0, "unit": "GB/s",
+                "frac": round(step_bytes / us / 1e3 / 8000.0, 4), "traffic": None,
+                "bytes_per_step": step_bytes, "us_per_step": round(us, 2)}
+
     if rank == 0:
         total_images = B * world * args.steps
         out = {
@@ -250,6 +299,7 @@ def main():
             "loss_first": round(float(first.item()), 5) if first is not None else None,
             "loss_last": round(float(last.item()), 5),
             "roofline": roofline,
+            "roofline_lstm_step": lstm,
         }
         if args.decoder != "factored":
             out["config"]["workload"] = out["config"]["workload"].replace(

@@ -74,6 +74,11 @@ SIGNATURES = {
                                      C.POINTER(_vp), C.c_float, C.c_ulonglong, _i, _vp]),
     "capnet_embedding_fwd": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _vp]),
     "capnet_lstm_pointwise_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "capnet_lstm_wfrag_floats": (_sz, [_i]),
+    "capnet_lstm_pack_wfrag": (_i, [_vp, _vp, _i, _i, _vp]),
+    "capnet_lstm_step_fused": (_i, [_vp, _vp, _vp, _l, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "capnet_lstm_step_fused_stamped": (_i, [_vp, _vp, _vp, _l, _vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "capnet_lstm_step_fused_supported": (_i, [_i, _i]),
     "capnet_xent_fwd": (_i, [_vp, _l, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "capnet_xent_bwd": (_i, [_vp, _l, _i, _i, _vp, _vp, _vp, _vp, _l, _vp]),
     "capnet_clamp_adam": (_i, [_i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp),

@@ -162,6 +162,28 @@ int capnet_lstm_pointwise_fwd(float* pre, const float* c_prev, float* c_out, flo
   return lstm_pointwise_fwd(pre, 4L * H, c_prev, c_out, h_out, b, H, 0, 1, 3, 2, 1, S(stream));
 }
 
+size_t capnet_lstm_wfrag_floats(int H) { return lstm_wfrag_floats(H); }
+int capnet_lstm_pack_wfrag(const float* w_cat, float* w_frag, int H, int cell, capnet_stream_t stream) {
+  CAPNET_REQUIRE(cell == kCellFactored || cell == kCellLSTM, "lstm_pack_wfrag: unknown cell %d", cell);
+  return cell == kCellFactored ? lstm_pack_wfrag(w_cat, w_frag, H, 0, 1, 2, 3, S(stream))
+                               : lstm_pack_wfrag(w_cat, w_frag, H, 0, 1, 3, 2, S(stream));
+}
+int capnet_lstm_step_fused(const float* h_prev, const float* w_cat, float* gates, long ldg,
+                           const float* c_prev, float* c_out, float* h_out, int b, int H, int cell,
+                           capnet_stream_t stream) {
+  CAPNET_REQUIRE(cell == kCellFactored || cell == kCellLSTM, "lstm_step_fused: unknown cell %d", cell);
+  if (cell == kCellFactored)
+    return lstm_step_fused(h_prev, w_cat, gates, ldg, c_prev, c_out, h_out, b, H, 0, 1, 2, 3, 0, S(stream));
+  return lstm_step_fused(h_prev, w_cat, gates, ldg, c_prev, c_out, h_out, b, H, 0, 1, 3, 2, 1, S(stream));
+}
+int capnet_lstm_step_fused_stamped(const float* h_prev, const float* w_frag, float* gates, long ldg,
+                                   const float* c_prev, float* c_out, float* h_out, int b, int H,
+                                   unsigned long long* stamps, capnet_stream_t stream) {
+  return lstm_step_fused(h_prev, w_frag, gates, ldg, c_prev, c_out, h_out, b, H, 0, 1, 2, 3, 0,
+                         S(stream), stamps);
+}
+int capnet_lstm_step_fused_supported(int b, int H) { return lstm_step_fused_supported(b, H) ? 1 : 0; }
+
 size_t capnet_seq_saved_floats(const int* dims) { return seq_saved_floats(to_dims(dims)); }
 size_t capnet_seq_saved_ints(const int* dims) { return seq_saved_ints(to_dims(dims)); }
 size_t capnet_seq_fwd_scratch_floats(const int* dims) { return seq_fwd_scratch_floats(to_dims(dims)); }

@@ -23,7 +23,7 @@ namespace {
 
 struct Layout {
   // saved float buffer
-  size_t X, A1, A2, G, Cst, Vcat, Scat, Ucat, Wcat, bV, bS, bUW, total;
+  size_t X, A1, A2, G, Cst, Vcat, Scat, Ucat, Wcat, Wfrag, bV, bS, bUW, total;
   // int buffer
   size_t row_sample, row_col, row_token, prev_row, itotal;
 };
@@ -37,6 +37,7 @@ Layout make_layout(const SeqDims& d) {
   L.G = take(N * 4 * H);
   L.Cst = take(N * H);
   L.Wcat = take(4 * H * H);
+  L.Wfrag = take(H % 16 == 0 ? lstm_wfrag_floats((int)H) : 4);
   L.bUW = take(4 * H);
   if (d.cell == kCellFactored) {
     L.A1 = take(N * 4 * F);
@@ -182,6 +183,9 @@ int seq_forward(const SeqDims& d, const int* batch_sizes, const unsigned char* t
     RC(vec_add(w.Vb[0], w.Wb[0], sv + L.bUW, 4 * H, s));
   }
 
+  bool fused_step = H % 16 == 0 && lstm_step_fused_supported(batch_sizes[0], H);
+  if (fused_step) RC(lstm_pack_wfrag(sv + L.Wcat, sv + L.Wfrag, H, go.gi, go.gf, go.go, go.gg, s));
+
   // ---- inputs + input chain for every row whose input is known up front
   CAPNET_HIP_CHECK(hipMemsetAsync(sv + L.X, 0, (size_t)N * E * sizeof(float), s));
   RC(gather_inputs(captions, d.T, features, emb, E, d.V, saved_i + L.row_sample,
@@ -203,6 +207,13 @@ int seq_forward(const SeqDims& d, const int* batch_sizes, const unsigned char* t
                          saved_i + L.row_col, saved_i + L.row_token, sv + L.X, E, r0, r0 + b,
                          dropout_p, seed, 0, 1, err_flag, s));
         RC(input_chain(d, L, sv, r0, r0 + b, s));
+      }
+      if (fused_step) {
+        // gates += h_{t-1} . Wcat^T, activations and the c/h update in one launch
+        RC(lstm_step_fused(h_prev, sv + L.Wfrag, sv + L.G + (size_t)r0 * 4 * H, 4 * H,
+                           sv + L.Cst + (size_t)off[t - 1] * H, sv + L.Cst + (size_t)r0 * H,
+                           hiddens + (size_t)r0 * H, b, H, go.gi, go.gf, go.go, go.gg, go.tanh_out, s));
+        continue;
       }
       // G[rows] += h_{t-1} . Wcat^T
       RC(sgemm_splitk(false, true, b, 4 * H, H, h_prev, H, sv + L.Wcat, H,

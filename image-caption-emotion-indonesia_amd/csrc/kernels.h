@@ -103,6 +103,15 @@ int scatter_input_grad(const float* dX, long ldx, int N, int E, const int* row_s
                        const int* row_token, float* dEmb, float* dFeat, int V, float p,
                        unsigned long long seed, int use_dropout, hipStream_t stream);
 
+// lstm_step.hip
+bool lstm_step_fused_supported(int b, int H);
+size_t lstm_wfrag_floats(int H);
+int lstm_pack_wfrag(const float* Wcat, float* Wfrag, int H, int gi, int gf, int go, int gg,
+                    hipStream_t stream);
+int lstm_step_fused(const float* hprev, const float* Wfrag, float* G, long ldg, const float* cprev,
+                    float* c_out, float* h_out, int b, int H, int gi, int gf, int go, int gg,
+                    int tanh_out, hipStream_t stream, unsigned long long* stamps = nullptr);
+
 // att_kernels.hip
 int att_step_fwd(const float* att1, const float* feat, const float* att2, float* gate_io, long ldz,
                  const float* wf, const float* bf, int rows, int P, int A, int C,

@@ -222,6 +222,27 @@ int capnet_embedding_fwd(const long long* idx, int n, const float* emb, int E, i
 int capnet_lstm_pointwise_fwd(float* pre, const float* c_prev, float* c_out, float* h_out, int b,
                               int H, int cell, capnet_stream_t stream);
 
+/* One recurrent step in one launch (used inside capnet_seq_forward for t > 0):
+ *   gates[b][4H] (in: U(S(V x)) + biases, ld ldg) += h_prev[b][H] . W[4H][H]^T (W given as the
+ *   capnet_lstm_pack_wfrag image), then the gate
+ *   non-linearities, c = f*c_prev + i*g, h = o*c (cell 0) / o*tanh(c) (cell 1); gates are
+ *   overwritten by the activated values. Each wave keeps its slice of w_cat in registers for
+ *   the launch. b <= 64, H in {16,32,64,96,128,256,512} (capnet_lstm_step_fused_supported). */
+size_t capnet_lstm_wfrag_floats(int H);
+/* w_cat [4H][H] (gate blocks in the cell's storage order) -> the fragment-major image the step
+ * kernel streams with fully coalesced 1-KB reads (one per 4 MFMA k-steps and wave) */
+int capnet_lstm_pack_wfrag(const float* w_cat, float* w_frag, int H, int cell,
+                           capnet_stream_t stream);
+int capnet_lstm_step_fused(const float* h_prev, const float* w_frag, float* gates, long ldg,
+                           const float* c_prev, float* c_out, float* h_out, int b, int H, int cell,
+                           capnet_stream_t stream);
+/* diagnostic variant (cell 0): also writes 5 s_memtime readings per workgroup to `stamps`
+ * ([H/8][5] uint64: start, operands staged, MFMAs done, K-reduced, end) */
+int capnet_lstm_step_fused_stamped(const float* h_prev, const float* w_frag, float* gates, long ldg,
+                                   const float* c_prev, float* c_out, float* h_out, int b, int H,
+                                   unsigned long long* stamps, capnet_stream_t stream);
+int capnet_lstm_step_fused_supported(int b, int H);
+
 /* ---- loss: nn.CrossEntropyLoss() (mean) -- stylenet/train_multitask.py:134,383 ---------- */
 int capnet_xent_fwd(const float* logits, long ld, int N, int V, const long long* targets,
                     float* lse, float* row_loss, float* loss, int* err_flag,
