@@ -4,7 +4,7 @@ import capnet
 from capnet._lib import lib, check, current_stream
 L = lib()
 dev = torch.device('cuda:0')
-for H, b in [(16, 4), (16, 64), (16, 32), (32, 4), (32, 64), (64, 3)]:
+for H, b in [(16, 4), (16, 64), (16, 32), (32, 4), (32, 64), (64, 3), (96, 40), (96, 17), (128, 33), (256, 64), (512, 64), (512, 9)]:
     g = torch.Generator().manual_seed(H + b)
     hp = torch.randn(b, H, generator=g); W = torch.randn(4 * H, H, generator=g) * 0.2
     G0 = torch.randn(b, 4 * H, generator=g); cp = torch.randn(b, H, generator=g)

@@ -10,7 +10,7 @@ G = torch.randn(b, 4 * H, device=dev); cp = torch.randn(b, H, device=dev)
 wf = torch.empty(L.capnet_lstm_wfrag_floats(H), device=dev)
 check(L.capnet_lstm_pack_wfrag(W.data_ptr(), wf.data_ptr(), H, 0, current_stream()))
 co, ho = torch.empty(b, H, device=dev), torch.empty(b, H, device=dev)
-st = torch.zeros(H // 8 * 5, dtype=torch.int64, device=dev)
+st = torch.zeros(H // 4 * 2 * 5, dtype=torch.int64, device=dev)
 for rep in range(4):
     check(L.capnet_lstm_step_fused_stamped(hp.data_ptr(), wf.data_ptr(), G.data_ptr(), 4 * H, cp.data_ptr(), co.data_ptr(), ho.data_ptr(), b, H, st.data_ptr(), current_stream()))
     torch.cuda.synchronize()
