@@ -11,7 +11,9 @@ namespace capnet {
 // ---- batch statistics -> (scale, shift), running-stat update --------------------------
 // part_sum/part_sq: [tiles][C] per-workgroup partials from the conv epilogue. Reduced in
 // double so that E[x^2]-E[x]^2 does not cancel in fp32.
-constexpr int kFinCh = 32, kFinRows = 32;
+// 16 channels (one 64-B segment) x 64 partial rows per workgroup: C/16 workgroups, and each
+// thread keeps 16 independent loads in flight -- the kernel is pure latency otherwise.
+constexpr int kFinCh = 16, kFinRows = 64;
 
 __global__ __launch_bounds__(kFinCh* kFinRows) void bn_finalize_kernel(
     const float* __restrict__ part_sum, const float* __restrict__ part_sq, int tiles, int C,
@@ -25,15 +27,28 @@ __global__ __launch_bounds__(kFinCh* kFinRows) void bn_finalize_kernel(
   const int c = blockIdx.x * kFinCh + cx;
   double s = 0.0, q = 0.0;
   if (c < C) {
-    for (int t = ry; t < tiles; t += kFinRows) {
-      s += (double)part_sum[(long)t * C + c];
-      q += (double)part_sq[(long)t * C + c];
+    // batches of 8 independent (clamped, masked) loads per thread: the reduction is pure latency
+    for (int t = ry; t < tiles; t += 8 * kFinRows) {
+      float a[8], b[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int tu = min(t + u * kFinRows, tiles - 1);
+        a[u] = part_sum[(long)tu * C + c];
+        b[u] = part_sq[(long)tu * C + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const bool ok = t + u * kFinRows < tiles;
+        s += ok ? (double)a[u] : 0.0;
+        q += ok ? (double)b[u] : 0.0;
+      }
     }
   }
   s_sum[ry][cx] = s;
   s_sq[ry][cx] = q;
   __syncthreads();
   if (ry == 0 && c < C) {
+#pragma unroll 8
     for (int r = 1; r < kFinRows; ++r) {
       s += s_sum[r][cx];
       q += s_sq[r][cx];

@@ -168,15 +168,20 @@ int seq_forward(const SeqDims& d, const int* batch_sizes, const unsigned char* t
   // ---- pack weights
   float* sv = saved;
   if (d.cell == kCellFactored) {
-    for (int g = 0; g < 4; ++g) {
-      RC(copy_d2d(sv + L.Vcat + (size_t)g * F * E, w.Vw[g], (size_t)F * E, s));
-      RC(copy_d2d(sv + L.Scat + (size_t)g * F * F, w.Sw[g], (size_t)F * F, s));
-      RC(copy_d2d(sv + L.Ucat + (size_t)g * H * F, w.Uw[g], (size_t)H * F, s));
-      RC(copy_d2d(sv + L.Wcat + (size_t)g * H * H, w.Ww[g], (size_t)H * H, s));
-      RC(copy_d2d(sv + L.bV + (size_t)g * F, w.Vb[g], F, s));
-      RC(copy_d2d(sv + L.bS + (size_t)g * F, w.Sb[g], F, s));
-      RC(vec_add(w.Ub[g], w.Wb[g], sv + L.bUW + (size_t)g * H, H, s));
-    }
+    // gate-concatenated copies of the 4x6 per-gate tensors: one multi-tensor launch per group
+    auto concat4 = [&](const float* const* src, size_t n, float* dst) -> int {
+      float* ptrs[4];
+      long numel[4];
+      for (int g = 0; g < 4; ++g) { ptrs[g] = const_cast<float*>(src[g]); numel[g] = (long)n; }
+      return pack_tensors(4, ptrs, numel, dst, 0, 1.f, s);
+    };
+    RC(concat4(w.Vw, (size_t)F * E, sv + L.Vcat));
+    RC(concat4(w.Sw, (size_t)F * F, sv + L.Scat));
+    RC(concat4(w.Uw, (size_t)H * F, sv + L.Ucat));
+    RC(concat4(w.Ww, (size_t)H * H, sv + L.Wcat));
+    RC(concat4(w.Vb, F, sv + L.bV));
+    RC(concat4(w.Sb, F, sv + L.bS));
+    for (int g = 0; g < 4; ++g) RC(vec_add(w.Ub[g], w.Wb[g], sv + L.bUW + (size_t)g * H, H, s));
   } else {
     RC(copy_d2d(sv + L.Vcat, w.Vw[0], (size_t)4 * H * E, s));
     RC(copy_d2d(sv + L.Wcat, w.Ww[0], (size_t)4 * H * H, s));
