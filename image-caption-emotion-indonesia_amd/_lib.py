@@ -24,6 +24,9 @@ SIGNATURES = {
                           _l, _i, _vp]),
     "capnet_colsum": (_i, [_vp, _l, _i, _i, _vp, _i, _vp]),
     "capnet_argmax_rows": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "capnet_beam_topk": (_i, [_vp, _l, _i, _i, _vp, _i, _vp, _vp, _vp]),
+    "capnet_att_step_fwd": (_i, [_vp, _vp, _vp, _vp, _l, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i,
+                                 _vp, _vp, _l, _vp]),
     "capnet_trunk_create": (_i, [_i, _i, _i, C.POINTER(_vp)]),
     "capnet_trunk_destroy": (None, [_vp]),
     "capnet_trunk_workspace_bytes": (_sz, [_vp]),

@@ -293,6 +293,97 @@ int argmax_rows(const float* x, int rows, int ld, int V, int* out, hipStream_t s
   return kOk;
 }
 
+// ---- beam-search expansion: log-softmax + running score + top-k over rows*V ------------------
+// One launch per decode step of sample() (stylenet/model.py:233-249): scores[r][v] =
+// prev[r] + log_softmax(logits[r])[v]; the k best of the flattened [rows*V] array, best first,
+// ties to the lower flat index. One workgroup: rows <= 16 beams x V is a few hundred KB.
+constexpr int kBeamThreads = 1024, kBeamMax = 16;
+
+__device__ __forceinline__ void beam_better(float v, long i, float& bv, long& bi) {
+  if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+}
+
+__global__ __launch_bounds__(kBeamThreads) void beam_topk_kernel(
+    const float* __restrict__ logits, long ld, int rows, int V, const float* __restrict__ prev,
+    int k, float* __restrict__ out_scores, long long* __restrict__ out_index) {
+  __shared__ float s_red[kBeamThreads / 64];
+  __shared__ long s_idx[kBeamThreads / 64];
+  __shared__ float s_lse[kBeamMax];
+  __shared__ long s_sel[kBeamMax];
+  __shared__ float s_bcast;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int r = 0; r < rows; ++r) {
+    const float* p = logits + (long)r * ld;
+    float m = -INFINITY;
+    for (int v = tid; v < V; v += kBeamThreads) m = fmaxf(m, p[v]);
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (lane == 0) s_red[wave] = m;
+    __syncthreads();
+    if (tid == 0) {
+      float mm = s_red[0];
+      for (int w = 1; w < kBeamThreads / 64; ++w) mm = fmaxf(mm, s_red[w]);
+      s_bcast = mm;
+    }
+    __syncthreads();
+    m = s_bcast;
+    float sum = 0.f;
+    for (int v = tid; v < V; v += kBeamThreads) sum += expf(p[v] - m);
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    __syncthreads();
+    if (lane == 0) s_red[wave] = sum;
+    __syncthreads();
+    if (tid == 0) {
+      float t = 0.f;
+      for (int w = 0; w < kBeamThreads / 64; ++w) t += s_red[w];
+      s_lse[r] = m + logf(t);
+    }
+    __syncthreads();
+  }
+  for (int j = 0; j < k; ++j) {
+    float bv = -INFINITY;
+    long bi = 0x7fffffffffffffffL;
+    for (int r = 0; r < rows; ++r) {
+      const float* p = logits + (long)r * ld;
+      const float base = prev[r] - s_lse[r];
+      for (int v = tid; v < V; v += kBeamThreads) {
+        const long flat = (long)r * V + v;
+        bool taken = false;
+        for (int q = 0; q < j; ++q) taken |= s_sel[q] == flat;
+        if (!taken) beam_better(base + p[v], flat, bv, bi);
+      }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o);
+      const long oi = __shfl_xor(bi, o);
+      beam_better(ov, oi, bv, bi);
+    }
+    __syncthreads();
+    if (lane == 0) { s_red[wave] = bv; s_idx[wave] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+      float v = s_red[0];
+      long i = s_idx[0];
+      for (int w = 1; w < kBeamThreads / 64; ++w) beam_better(s_red[w], s_idx[w], v, i);
+      s_sel[j] = i;
+      out_scores[j] = v;
+      out_index[j] = i;
+    }
+    __syncthreads();
+  }
+}
+
+int beam_topk(const float* logits, long ld, int rows, int V, const float* prev, int k,
+              float* out_scores, long long* out_index, hipStream_t stream) {
+  CAPNET_REQUIRE(logits && prev && out_scores && out_index, "beam_topk: null argument");
+  CAPNET_REQUIRE(rows >= 1 && rows <= kBeamMax && k >= 1 && k <= kBeamMax && V >= 1 && ld >= V &&
+                     (long)rows * V >= k,
+                 "beam_topk: rows=%d k=%d V=%d (rows, k <= %d; k <= rows*V)", rows, k, V, kBeamMax);
+  hipLaunchKernelGGL(beam_topk_kernel, dim3(1), dim3(kBeamThreads), 0, stream, logits, ld, rows, V,
+                     prev, k, out_scores, out_index);
+  CAPNET_LAUNCH_CHECK();
+  return kOk;
+}
+
 // ---- out[r] = idx[r] >= 0 ? src[idx[r]] : 0  (rows of width C) ----------------------------
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src,
                                                           const int* __restrict__ idx,

@@ -389,3 +389,20 @@ class DecoderFactoredLSTM(nn.Module):
                                        self.C.bias, weights)
         outputs = self.C(hiddens)
         return outputs
+
+    def sample(self, features, start_token, end_token, k=5, factual_limit=-1, mode='factual'):
+        """Beam search, stylenet/model.py:198-294. As in the reference the image features are NOT
+        an input of the decode steps (the first input is B(<start>) and the state starts at zero):
+        `features` only fixes the device. Returns LongTensor [1, L]."""
+        from .beam import beam_search
+        dev = self.B.weight.device
+        self._S(mode)   # validates the mode before any launch
+
+        def step_fn(prev_words, state):
+            hidden, (h, c) = self.forward_step(self.B(prev_words), state, mode=mode)
+            return self.C(hidden), (h, c)
+
+        with torch.no_grad():
+            zeros = torch.zeros(k, self.hidden_size, dtype=torch.float32, device=dev)
+            return beam_search(step_fn, (zeros, zeros.clone()), self.vocab_size, start_token,
+                               end_token, k, self.max_seq_length, dev)

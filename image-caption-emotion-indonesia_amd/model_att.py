@@ -58,6 +58,18 @@ class Attention(nn.Module):
         self.relu = _Marker()
         self.softmax = _Marker()
 
+    def forward(self, encoder_out, decoder_hidden):
+        """(attention-weighted encoding [s, C], alpha [s, P]) -- stylenet/model_att.py:51-70.
+        Inference-only entry (no autograd); training goes through the fused sequence kernels."""
+        with torch.no_grad():
+            s_rows, P, Cdim = encoder_out.shape
+            A = self.encoder_att.weight.shape[0]
+            att1 = self.encoder_att(encoder_out.reshape(s_rows * P, Cdim)).reshape(s_rows, P, A)
+            z = torch.zeros((s_rows, A + Cdim), dtype=torch.float32, device=encoder_out.device)
+            z[:, :A] = self.decoder_att(decoder_hidden)
+            return ops.attention_step(att1.contiguous(), encoder_out.contiguous(), z, A,
+                                      self.full_att.weight, self.full_att.bias)
+
 
 class DecoderFactoredLSTMAtt(nn.Module):
     """stylenet/model_att.py:73-426. `num_layers` is accepted and ignored, as in the reference.
@@ -138,6 +150,56 @@ class DecoderFactoredLSTMAtt(nn.Module):
         for m in (self.init_h, self.init_c, att.encoder_att, att.decoder_att, att.full_att, self.f_beta):
             out += [m.weight, m.bias]
         return out
+
+    def init_hidden_state(self, features):
+        """h0, c0 = init_h / init_c (mean over pixels) -- stylenet/model_att.py:185-194."""
+        mean_features = features.mean(dim=1)
+        return self.init_h(mean_features), self.init_c(mean_features)
+
+    def forward_step(self, embedded, states, mode):
+        """One factored-LSTM step on [embedding | gated context] -- model_att.py:196-236."""
+        h_t, c_t = states
+        _, S = self._mode_modules(mode)
+        V = [getattr(self, "V_" + g) for g in "ifoc"]
+        U = [getattr(self, "U_" + g) for g in "ifoc"]
+        W = [getattr(self, "W_" + g) for g in "ifoc"]
+        pre = torch.cat([U[k](S[k](V[k](embedded))) + W[k](h_t) for k in range(4)], 1)
+        h_t, c_t = ops.lstm_pointwise(pre, c_t, ops.CELL_FACTORED)
+        return h_t, (h_t, c_t)
+
+    def sample(self, features, start_token, end_token, k=5, factual_limit=-1, mode='factual'):
+        """Beam search with attention, stylenet/model_att.py:307-426. `features`: the encoder map
+        of ONE image ([1, S, S, C] or [1, P, C]). encoder_att(features) is computed once (the
+        reference recomputes it for every beam and step). Returns LongTensor [1, L]."""
+        from .beam import beam_search
+        dev = self.B.weight.device
+        attention, _ = self._mode_modules(mode)
+        E, A, Cdim = self.embed_size, self.attention_size, features.size(-1)
+        with torch.no_grad():
+            feat1 = features.reshape(1, -1, Cdim).to(dev).contiguous()
+            P = feat1.size(1)
+            feat_k = feat1.expand(k, P, Cdim).contiguous()
+            att1_k = attention.encoder_att(feat1[0]).reshape(1, P, A).expand(k, P, A).contiguous()
+            h0, c0 = self.init_hidden_state(feat_k)
+            # [decoder_att ; f_beta] stacked: one product with h per step
+            wz = torch.cat([attention.decoder_att.weight, self.f_beta.weight], 0).contiguous()
+            bz = torch.cat([attention.decoder_att.bias, self.f_beta.bias], 0).contiguous()
+
+            def step_fn(prev_words, state):
+                h, c = state
+                s_rows = h.shape[0]
+                z = ops.linear(h, wz, bz).contiguous()
+                xa = torch.empty((s_rows, E + Cdim), dtype=torch.float32, device=dev)
+                xa[:, :E] = self.B(prev_words)
+                # all beams look at the same image: rows of feat_k / att1_k are identical, so
+                # re-indexing them (model_att.py:413) is a slice
+                ops.attention_step(att1_k[:s_rows], feat_k[:s_rows], z, A, attention.full_att.weight,
+                                   attention.full_att.bias, xa=xa, xa_col=E)
+                hidden, (h, c) = self.forward_step(xa, (h, c), mode=mode)
+                return self.C(hidden), (h, c)
+
+            return beam_search(step_fn, (h0, c0), self.vocab_size, start_token, end_token, k,
+                               self.max_seq_length, dev)
 
     def forward(self,
                 captions,

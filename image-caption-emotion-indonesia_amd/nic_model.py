@@ -86,3 +86,18 @@ class DecoderRNN(nn.Module):
         hiddens = ops.decoder_sequence(cfg, captions, features, self.embed.weight,
                                        self.linear.weight, self.linear.bias, weights)
         return self.linear(hiddens)
+
+    def sample(self, features, start_token, end_token, k=5):
+        """Beam search, nic/model.py:117-207 (the image features are not an input of the decode
+        steps there either). Returns LongTensor [1, L]."""
+        from .beam import beam_search
+        dev = self.embed.weight.device
+
+        def step_fn(prev_words, state):
+            hidden, (h, c) = self.forward_step(self.embed(prev_words), state)
+            return self.linear(hidden), (h, c)
+
+        with torch.no_grad():
+            zeros = torch.zeros(k, self.hidden_size, dtype=torch.float32, device=dev)
+            return beam_search(step_fn, (zeros, zeros.clone()), self.vocab_size, start_token,
+                               end_token, k, self.max_seq_length, dev)

@@ -98,6 +98,49 @@ def argmax_rows(x):
     return out
 
 
+def beam_topk(logits, prev_scores, rows, k):
+    """k best of prev_scores[r] + log_softmax(logits[r]) over the first `rows` rows, flattened.
+    Returns (scores [k] float32, flat_index [k] int64) on the device."""
+    _need_cuda(logits)
+    logits = _c(logits)
+    prev_scores = _c(prev_scores)
+    scores = torch.empty(k, dtype=torch.float32, device=logits.device)
+    index = torch.empty(k, dtype=torch.int64, device=logits.device)
+    check(_lib.lib().capnet_beam_topk(ptr(logits), logits.shape[1], rows, logits.shape[1],
+                                      ptr(prev_scores), k, ptr(scores), ptr(index),
+                                      current_stream()), "capnet_beam_topk")
+    return scores, index
+
+
+def attention_step(att1, feat, z, A, w_full, b_full, xa=None, xa_col=0):
+    """One attention step for s rows (no autograd; Attention.forward / sample()).
+    att1 [s, P, A] = encoder_att(features); feat [s, P, C]; z [s, A + C] = [decoder_att(h) |
+    f_beta(h)] pre-activations (the gate half is overwritten with its sigmoid).
+    Returns (awe [s, C] ungated context, alpha [s, P]); if `xa` [s, W] is given, the GATED context
+    is written into xa[:, xa_col : xa_col + C]."""
+    _need_cuda(att1, feat, z)
+    s_rows, P, Adim = att1.shape
+    Cdim = feat.shape[2]
+    if not (att1.is_contiguous() and feat.is_contiguous() and z.is_contiguous()):
+        raise CapnetError("attention_step: inputs must be contiguous")
+    if Adim != A or z.shape[1] != A + Cdim or feat.shape[0] != s_rows or feat.shape[1] != P:
+        raise CapnetError("attention_step: shape mismatch")
+    dev = att1.device
+    alpha = torch.empty((s_rows, P), dtype=torch.float32, device=dev)
+    alphas_bt = torch.empty((s_rows, 1, P), dtype=torch.float32, device=dev)
+    awe = torch.empty((s_rows, Cdim), dtype=torch.float32, device=dev)
+    if xa is None:
+        xa, xa_col = torch.empty((s_rows, Cdim), dtype=torch.float32, device=dev), 0
+    if not xa.is_contiguous() or xa.shape[0] != s_rows or xa_col + Cdim > xa.shape[1] or xa_col % 4:
+        raise CapnetError("attention_step: bad xa")
+    wf, bf = _c(w_full.detach()).reshape(-1), _c(b_full.detach()).reshape(-1)
+    check(_lib.lib().capnet_att_step_fwd(ptr(att1), ptr(feat), ptr(z), C.c_void_p(z.data_ptr() + 4 * A), z.shape[1],
+                                         ptr(wf), ptr(bf), s_rows, P, A, Cdim, ptr(alpha),
+                                         ptr(alphas_bt), 1, 0, ptr(awe), C.c_void_p(xa.data_ptr() + 4 * xa_col),
+                                         xa.shape[1], current_stream()), "capnet_att_step_fwd")
+    return awe, alpha
+
+
 def embedding(idx, weight):
     """weight[idx] (no autograd: used by forward_step()/sample())."""
     _need_cuda(idx, weight)

@@ -54,6 +54,14 @@ int capnet_colsum(const float* x, long ld, int rows, int C, float* out, int accu
  * stylenet/model.py:190, nic/model.py:109. */
 int capnet_argmax_rows(const float* x, int rows, int ld, int V, int* out, capnet_stream_t stream);
 
+/* One beam-search expansion of `sample()` (stylenet/model.py:229-249, model_att.py:362-384,
+ * nic/model.py sample): scores[r][v] = prev_scores[r] + log_softmax(logits[r])[v]; returns the k
+ * best entries of the flattened [rows*V] scores, best first (ties: lower flat index):
+ * top_scores[k], top_index[k] (flat index = r*V + v; the caller splits it with // and %).
+ * rows, k <= 16. The reference passes rows = 1 on the first step (all beams identical). */
+int capnet_beam_topk(const float* logits, long ld, int rows, int V, const float* prev_scores, int k,
+                     float* top_scores, long long* top_index, capnet_stream_t stream);
+
 /* ---- ResNet-152 trunk -------------------------------------------------------------------
  * torchvision resnet152 children[:-1] (pooled [B][2048]) or [:-2] (NHWC map [B][S][S][2048]),
  * as run under torch.no_grad() by EncoderCNN.forward: stylenet/model.py:15-18,23-25,
@@ -195,6 +203,17 @@ size_t capnet_att_saved_floats(const int* dims);
 size_t capnet_att_saved_ints(const int* dims);
 size_t capnet_att_fwd_scratch_floats(const int* dims);
 size_t capnet_att_bwd_scratch_floats(const int* dims);
+/* One attention step for `rows` rows (Attention.forward, stylenet/model_att.py:51-70, plus the
+ * f_beta gate of :283-284), as used per time step inside capnet_att_seq_forward and per decode
+ * step by sample() (model_att.py:352-357). att1 [rows][P][A] = encoder_att(features) (hoisted),
+ * feat [rows][P][C], att2 (ld ldz) = decoder_att(h), gate_io (ld ldz): f_beta(h) in, sigmoid out;
+ * w_full [A], b_full [1]. Outputs: alpha_out [rows][P]; alphas_bt[(row*steps + t)*P + p] (the
+ * user-visible alphas tensor); awe_out [rows][C] (ungated context); xa_out (ld ldx) = gate*awe. */
+int capnet_att_step_fwd(const float* att1, const float* feat, const float* att2, float* gate_io,
+                        long ldz, const float* w_full, const float* b_full, int rows, int P, int A,
+                        int C, float* alpha_out, float* alphas_bt, int steps, int t, float* awe_out,
+                        float* xa_out, long ldx, capnet_stream_t stream);
+
 int capnet_att_seq_forward(const int* dims, const int* batch_sizes, const unsigned char* tf_mask,
                            const long long* captions, const float* features, const float* emb,
                            const float* const* weights, const float* Cw, const float* Cb,

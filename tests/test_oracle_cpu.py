@@ -136,3 +136,29 @@ def test_attention_decoder_matches_reference(cname):
         else:
             assert v.grad is None or float(v.grad.abs().max()) == 0.0, k
     assert n > 30
+
+
+# ---- beam search (sample()) -----------------------------------------------------------
+_SZ = load_golden("sample_tiny.npz")
+
+
+@pytest.mark.parametrize("name", [str(c) for c in _SZ["cases"]])
+def test_beam_search_matches_reference_sequences(name):
+    """oracle/beam_ref.py against sequences produced by the reference's own sample() methods."""
+    from oracle import beam_ref
+    pre = "case.%s." % name
+    c = {k[len(pre):]: _SZ[k] for k in _SZ.files if k.startswith(pre)}
+    p = {k[len("param."):]: t(v) for k, v in c.items() if k.startswith("param.")}
+    start, end = [int(v) for v in _SZ["start_end"]]
+    dims = [int(v) for v in c["dims"]]
+    E, H, F, V, k, maxlen = dims[:6]
+    kind = str(c["kind"])
+    with torch.no_grad():
+        if kind == "factored":
+            seq = beam_ref.sample_factored(p, H, start, end, k=k, mode=str(c["mode"]), max_seq_length=maxlen)
+        elif kind == "nic":
+            seq = beam_ref.sample_lstm(p, H, start, end, k=k, max_seq_length=maxlen)
+        else:
+            seq = beam_ref.sample_factored_att(p, t(c["features"]), start, end, k=k, mode=str(c["mode"]),
+                                               max_seq_length=maxlen)
+    assert seq.tolist() == c["seq"].tolist()

@@ -309,6 +309,110 @@ def gen_att_tiny():
     save("decoder_att_tiny.npz", arrays)
 
 
+class legacy_int_division:
+    """torch 1.1 (the version the reference pins) divided integer tensors with integer results;
+    `top_k_words / self.vocab_size` at stylenet/model.py:249 relies on it. Current torch returns a
+    float tensor there and the next indexing statement raises, so the reference's sample() is run
+    under this shim: `LongTensor / int` floors, everything else is untouched."""
+
+    def __enter__(self):
+        self.orig = torch.Tensor.__truediv__
+
+        def div(a, b):
+            if isinstance(a, torch.Tensor) and not a.is_floating_point() and isinstance(b, int):
+                return torch.div(a, b, rounding_mode="floor")
+            return self.orig(a, b)
+
+        torch.Tensor.__truediv__ = div
+        return self
+
+    def __exit__(self, *exc):
+        torch.Tensor.__truediv__ = self.orig
+
+
+def gen_sample_tiny():
+    """Beam search: the reference's own sample() methods (stylenet/model.py:198-294,
+    nic/model.py:117-207, stylenet/model_att.py:307-426) on tiny seeded decoders. Weights are the
+    seeded synthetic ones scaled up (x5, vocabulary projection x4) so that the next-word
+    distribution is peaky (no near-ties for fp32 noise to flip) and beams terminate at different
+    steps; for every case the first seed whose winning sequence has 5..20 tokens is kept."""
+    arrays, names = {}, []
+    START, END = 1, 2
+
+    def scaled(state, out_prefix):
+        state = dict(state)
+        for key in state:
+            if key.endswith("weight"):
+                state[key] = state[key] * (4.0 if key.startswith(out_prefix) else 5.0)
+        return state
+
+    def search(build, run, out_prefix, seed0):
+        for seed in range(seed0, seed0 + 200):
+            dec = build()
+            dec.eval()
+            state = scaled(synthetic.decoder_state(dec.state_dict(), seed=seed, bias_range=0.1),
+                           out_prefix)
+            dec.load_state_dict(state)
+            with legacy_int_division(), torch.no_grad():
+                seq = run(dec, seed)
+            if 5 <= seq.shape[1] <= 20:
+                return seed, state, seq
+        raise RuntimeError("no seed found")
+
+    def record(name, kind, dims, state, seq, extra=None):
+        names.append(name)
+        arrays["case.%s.kind" % name] = np.array(kind)
+        arrays["case.%s.dims" % name] = np.array(dims)
+        arrays["case.%s.seq" % name] = seq.numpy()
+        for k, v in state.items():
+            arrays["case.%s.param.%s" % (name, k)] = v.numpy()
+        for k, v in (extra or {}).items():
+            arrays["case.%s.%s" % (name, k)] = v
+        print(name, seq.tolist())
+
+    ref = load_ref("stylenet", "model")
+    E, H, F, V = 12, 16, 16, 37
+    for seed0, mode, k, maxlen in [(0, "factual", 5, 40), (40, "happy", 5, 40), (80, "sad", 3, 40),
+                                   (120, "angry", 5, 40), (160, "factual", 5, 6)]:
+        if maxlen == 6:   # the "going on too long" exit (model.py:283-285): keep whatever it returns
+            dec = ref.DecoderFactoredLSTM(E, H, F, V, 1, dropout=0.0, max_seq_length=maxlen)
+            dec.eval()
+            state = scaled(synthetic.decoder_state(dec.state_dict(), seed=6, bias_range=0.1), "C.")
+            dec.load_state_dict(state)
+            with legacy_int_division(), torch.no_grad():
+                seq = dec.sample(torch.zeros(1, E), START, END, k=k, mode=mode)
+            seed = 6
+        else:
+            seed, state, seq = search(
+                lambda: ref.DecoderFactoredLSTM(E, H, F, V, 1, dropout=0.0, max_seq_length=maxlen),
+                lambda d, sd: d.sample(torch.zeros(1, E), START, END, k=k, mode=mode), "C.", seed0)
+        record("factored_%s_k%d_max%d" % (mode, k, maxlen), "factored", [E, H, F, V, k, maxlen],
+               state, seq, {"mode": np.array(mode), "seed": np.array(seed)})
+
+    refn = load_ref("nic", "model")
+    for seed0, k in [(0, 5), (50, 2)]:
+        seed, state, seq = search(lambda: refn.DecoderRNN(E, H, V, 1, dropout=0.0),
+                                  lambda d, sd: d.sample(torch.zeros(1, E), START, END, k=k),
+                                  "linear.", seed0)
+        record("nic_k%d" % k, "nic", [E, H, 0, V, k, 40], state, seq, {"seed": np.array(seed)})
+
+    refa = load_ref("stylenet", "model_att")
+    A, Cf = 16, 512
+
+    def feats(seed):
+        return torch.randn(1, 2, 2, Cf, generator=torch.Generator().manual_seed(seed + 1000))
+
+    for seed0, mode, k in [(0, "factual", 5), (60, "angry", 4)]:
+        seed, state, seq = search(
+            lambda: refa.DecoderFactoredLSTMAtt(A, E, H, F, V, 1, feature_size=Cf, dropout=0.0),
+            lambda d, sd: d.sample(feats(sd), START, END, k=k, mode=mode), "C.", seed0)
+        record("att_%s_k%d" % (mode, k), "att", [E, H, F, V, k, 40, A, Cf], state, seq,
+               {"mode": np.array(mode), "features": feats(seed).numpy(), "seed": np.array(seed)})
+    arrays["cases"] = np.array(names)
+    arrays["start_end"] = np.array([START, END])
+    save("sample_tiny.npz", arrays)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     which = sys.argv[1:] or ["factored_tiny", "nic_tiny", "factored_full"]
@@ -322,3 +426,5 @@ if __name__ == "__main__":
         gen_trunk()
     if "att_tiny" in which:
         gen_att_tiny()
+    if "sample_tiny" in which:
+        gen_sample_tiny()
