@@ -229,12 +229,17 @@ int capnet_seq_backward(const int* dims, const int* batch_sizes, const float* d_
 static AttDims to_adims(const int* d) {
   AttDims r;
   r.B = d[0]; r.T = d[1]; r.steps = d[2]; r.N = d[3]; r.E = d[4]; r.F = d[5]; r.H = d[6];
-  r.V = d[7]; r.A = d[8]; r.P = d[9]; r.C = d[10];
+  r.V = d[7]; r.A = d[8]; r.P = d[9]; r.C = d[10]; r.cell = d[11];
   return r;
 }
-static int to_aweights(const float* const* p, AttWeights* w) {
+static int to_aweights(const float* const* p, AttWeights* w, int cell) {
   CAPNET_REQUIRE(p != nullptr, "att decoder: null weight table");
-  for (int i = 0; i < 44; ++i) CAPNET_REQUIRE(p[i] != nullptr, "att decoder: weight %d is null", i);
+  CAPNET_REQUIRE(cell == kCellFactored || cell == kCellLSTM, "att decoder: unknown cell %d", cell);
+  for (int i = 0; i < 44; ++i) {
+    // nn.LSTMCell: only slot 0 of the V (weight_ih, bias_ih) and W (weight_hh, bias_hh) groups
+    const bool used = cell == kCellFactored || i >= 32 || i == 0 || i == 4 || i == 24 || i == 28;
+    CAPNET_REQUIRE(!used || p[i] != nullptr, "att decoder: weight %d is null", i);
+  }
   for (int g = 0; g < 4; ++g) {
     w->Vw[g] = p[0 + g];  w->Vb[g] = p[4 + g];
     w->Sw[g] = p[8 + g];  w->Sb[g] = p[12 + g];
@@ -271,7 +276,7 @@ int capnet_att_seq_forward(const int* dims, const int* batch_sizes, const unsign
                            int* err_flag, capnet_stream_t stream) {
   CAPNET_REQUIRE(dims != nullptr, "att_seq_forward: null dims");
   AttWeights w;
-  int rc = to_aweights(weights, &w);
+  int rc = to_aweights(weights, &w, dims ? dims[11] : 0);
   if (rc) return rc;
   return att_seq_forward(to_adims(dims), batch_sizes, tf_mask, captions, features, emb, w, Cw, Cb,
                          dropout_p, seed, training, saved, saved_i, scratch, hiddens, alphas,
@@ -285,7 +290,7 @@ int capnet_att_seq_backward(const int* dims, const int* batch_sizes, const float
                             unsigned long long seed, int training, capnet_stream_t stream) {
   CAPNET_REQUIRE(dims && grads, "att_seq_backward: null dims/grads");
   AttWeights w;
-  int rc = to_aweights(weights, &w);
+  int rc = to_aweights(weights, &w, dims ? dims[11] : 0);
   if (rc) return rc;
   AttGrads g;
   g.dVcat = grads[0]; g.dbV = grads[1]; g.dScat = grads[2]; g.dbS = grads[3]; g.dUcat = grads[4];

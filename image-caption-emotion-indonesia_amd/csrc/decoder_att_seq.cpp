@@ -1,5 +1,6 @@
-// Sequence driver of the attention decoder: DecoderFactoredLSTMAtt.forward
-// (stylenet/model_att.py:238-305) and its BPTT, one C call each.
+// Sequence driver of the attention decoders: DecoderFactoredLSTMAtt.forward
+// (stylenet/model_att.py:238-305) and nic DecoderRNNAtt.forward (nic/model_att.py:152-202, the
+// same loop around nn.LSTMCell(E + C, H)) and their BPTT, one C call each.
 //
 // Per step t (rows = batch_sizes[t], previous state h, c -- the initial state is
 // init_h/init_c(mean over pixels of the feature map), :185-194,260):
@@ -12,7 +13,9 @@
 // weight Wz = [W_i; W_f; W_o; W_c; decoder_att; f_beta] ([4H+A+C] x H): the forward writes
 // Z = [gate pre-acts | att2 | f_beta(h)] rows, the backward reads dZ rows and gets dh in one
 // product; the weight gradients of all six matrices are one TN GEMM over all packed rows after
-// the loop. encoder_att(features) is hoisted out of the time loop (the reference recomputes it
+// the loop. With cell = kCellLSTM the V/S/U chain is the single product [x | ctx] . weight_ih^T
+// (gate order i,f,g,o; h = o tanh(c)) and Wz = [weight_hh; decoder_att; f_beta].
+// encoder_att(features) is hoisted out of the time loop (the reference recomputes it
 // every step) and its weight gradient is accumulated per sample and reduced by one GEMM.
 #include <vector>
 
@@ -36,10 +39,11 @@ ALayout make_alayout(const AttDims& d) {
   size_t o = 0;
   auto take = [&](size_t n) { size_t r = o; o += (n + 3) / 4 * 4; return r; };
   const size_t N = d.N, F = d.F, H = d.H;
+  const bool fac = d.cell == kCellFactored;
   L.XA = take(N * L.XW);
   L.Zf = take(N * L.ZW);
-  L.A1 = take(N * 4 * F);
-  L.A2 = take(N * 4 * F);
+  L.A1 = take(fac ? N * 4 * F : 4);
+  L.A2 = take(fac ? N * 4 * F : 4);
   L.Cst = take(N * H);
   L.alpha = take(N * d.P);
   L.awe = take(N * d.C);
@@ -47,9 +51,9 @@ ALayout make_alayout(const AttDims& d) {
   L.mean = take((size_t)d.B * d.C);
   L.h0 = take((size_t)d.B * H);
   L.c0 = take((size_t)d.B * H);
-  L.Vcat = take(4 * F * L.XW);
-  L.Scat = take(4 * F * F);
-  L.Ucat = take(4 * H * F);
+  L.Vcat = take(fac ? 4 * F * L.XW : 4 * H * L.XW);   // LSTM: weight_ih [4H][E+C]
+  L.Scat = take(fac ? 4 * F * F : 4);
+  L.Ucat = take(fac ? 4 * H * F : 4);
   L.Wz = take((size_t)L.ZW * H);
   L.bV = take(4 * F);
   L.bS = take(4 * F);
@@ -68,6 +72,7 @@ ALayout make_alayout(const AttDims& d) {
 constexpr size_t kAttSplitKFloats = 32ull * 64 * 4608;
 
 int check(const AttDims& d, const int* bs) {
+  CAPNET_REQUIRE(d.cell == kCellFactored || d.cell == kCellLSTM, "att decoder: unknown cell %d", d.cell);
   CAPNET_REQUIRE(d.B > 0 && d.T > 0 && d.steps > 0 && d.N > 0 && d.E > 0 && d.F > 0 && d.H > 0 &&
                      d.V > 0 && d.A > 0 && d.P > 0 && d.C > 0,
                  "att decoder: bad dims");
@@ -89,6 +94,8 @@ int check(const AttDims& d, const int* bs) {
 
 #define RC(x) do { int _rc = (x); if (_rc) return _rc; } while (0)
 
+struct GateOrderA { int gi, gf, go, gg, tanh_out; };  // column block of each gate role
+
 int cpy(float* dst, const float* src, size_t n, hipStream_t s) {
   CAPNET_HIP_CHECK(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, s));
   return kOk;
@@ -102,7 +109,7 @@ size_t att_fwd_scratch_floats(const AttDims& d) { return (size_t)d.B * d.V + 64 
 size_t att_bwd_scratch_floats(const AttDims& d) {
   const ALayout L = make_alayout(d);
   const size_t N = d.N;
-  return N * L.ZW + 2 * N * 4 * d.F + N * L.XW + N * d.H + 2 * (size_t)d.B * d.H +
+  return N * L.ZW + 2 * (d.cell == kCellFactored ? N * 4 * d.F : 8) + N * L.XW + N * d.H + 2 * (size_t)d.B * d.H +
          (size_t)d.B * (d.C / 512) * d.P + (size_t)d.B * d.P * d.A + N * d.A + N + 4096 +
          kAttSplitKFloats;
 }
@@ -132,14 +139,22 @@ int att_seq_forward(const AttDims& d, const int* bs, const unsigned char* tf,
                   saved_i + L.prev_row, s));
   }
   // ---- pack weights
-  for (int g = 0; g < 4; ++g) {
-    RC(cpy(sv + L.Vcat + (size_t)g * F * XW, w.Vw[g], (size_t)F * XW, s));
-    RC(cpy(sv + L.Scat + (size_t)g * F * F, w.Sw[g], (size_t)F * F, s));
-    RC(cpy(sv + L.Ucat + (size_t)g * H * F, w.Uw[g], (size_t)H * F, s));
-    RC(cpy(sv + L.Wz + (size_t)g * H * H, w.Ww[g], (size_t)H * H, s));
-    RC(cpy(sv + L.bV + (size_t)g * F, w.Vb[g], F, s));
-    RC(cpy(sv + L.bS + (size_t)g * F, w.Sb[g], F, s));
-    RC(vec_add(w.Ub[g], w.Wb[g], sv + L.bz + (size_t)g * H, H, s));
+  const bool fac = d.cell == kCellFactored;
+  const GateOrderA go = fac ? GateOrderA{0, 1, 2, 3, 0} : GateOrderA{0, 1, 3, 2, 1};
+  if (fac) {
+    for (int g = 0; g < 4; ++g) {
+      RC(cpy(sv + L.Vcat + (size_t)g * F * XW, w.Vw[g], (size_t)F * XW, s));
+      RC(cpy(sv + L.Scat + (size_t)g * F * F, w.Sw[g], (size_t)F * F, s));
+      RC(cpy(sv + L.Ucat + (size_t)g * H * F, w.Uw[g], (size_t)H * F, s));
+      RC(cpy(sv + L.Wz + (size_t)g * H * H, w.Ww[g], (size_t)H * H, s));
+      RC(cpy(sv + L.bV + (size_t)g * F, w.Vb[g], F, s));
+      RC(cpy(sv + L.bS + (size_t)g * F, w.Sb[g], F, s));
+      RC(vec_add(w.Ub[g], w.Wb[g], sv + L.bz + (size_t)g * H, H, s));
+    }
+  } else {
+    RC(cpy(sv + L.Vcat, w.Vw[0], (size_t)4 * H * XW, s));          // weight_ih
+    RC(cpy(sv + L.Wz, w.Ww[0], (size_t)4 * H * H, s));             // weight_hh
+    RC(vec_add(w.Vb[0], w.Wb[0], sv + L.bz, 4 * H, s));            // bias_ih + bias_hh
   }
   RC(cpy(sv + L.Wz + (size_t)4 * H * H, w.dec_att_w, (size_t)A * H, s));
   RC(cpy(sv + L.Wz + (size_t)(4 * H + A) * H, w.f_beta_w, (size_t)C * H, s));
@@ -179,15 +194,21 @@ int att_seq_forward(const AttDims& d, const int* bs, const unsigned char* tf,
                        saved_i + L.row_col, saved_i + L.row_token, sv + L.XA, XW, r0, r0 + b,
                        dropout_p, seed, 0, 1, err_flag, s));
     }
-    // factored chain on [x | gated context]
-    RC(sgemm_splitk(false, true, b, 4 * F, XW, sv + L.XA + (size_t)r0 * XW, XW, sv + L.Vcat, XW,
-                    sv + L.A1 + (size_t)r0 * 4 * F, 4 * F, sv + L.bV, 0, skws, kAttSplitKFloats, s));
-    RC(sgemm(false, true, b, F, F, sv + L.A1 + (size_t)r0 * 4 * F, 4 * F, sv + L.Scat, F,
-             sv + L.A2 + (size_t)r0 * 4 * F, 4 * F, sv + L.bS, 0, 4, F, (long)F * F, F, F, 0, s));
-    RC(sgemm(false, true, b, H, F, sv + L.A2 + (size_t)r0 * 4 * F, 4 * F, sv + L.Ucat, F, Z, ZW,
-             nullptr, 1, 4, F, (long)H * F, H, 0, 0, s));
+    if (fac) {
+      // factored chain on [x | gated context]
+      RC(sgemm_splitk(false, true, b, 4 * F, XW, sv + L.XA + (size_t)r0 * XW, XW, sv + L.Vcat, XW,
+                      sv + L.A1 + (size_t)r0 * 4 * F, 4 * F, sv + L.bV, 0, skws, kAttSplitKFloats, s));
+      RC(sgemm(false, true, b, F, F, sv + L.A1 + (size_t)r0 * 4 * F, 4 * F, sv + L.Scat, F,
+               sv + L.A2 + (size_t)r0 * 4 * F, 4 * F, sv + L.bS, 0, 4, F, (long)F * F, F, F, 0, s));
+      RC(sgemm(false, true, b, H, F, sv + L.A2 + (size_t)r0 * 4 * F, 4 * F, sv + L.Ucat, F, Z, ZW,
+               nullptr, 1, 4, F, (long)H * F, H, 0, 0, s));
+    } else {
+      // nn.LSTMCell input product: gates += [x | gated context] . weight_ih^T
+      RC(sgemm_splitk(false, true, b, 4 * H, XW, sv + L.XA + (size_t)r0 * XW, XW, sv + L.Vcat, XW, Z,
+                      ZW, nullptr, 1, skws, kAttSplitKFloats, s));
+    }
     RC(lstm_pointwise_fwd(Z, ZW, cprev, sv + L.Cst + (size_t)r0 * H, hiddens + (size_t)r0 * H, b, H,
-                          0, 1, 2, 3, 0, s));
+                          go.gi, go.gf, go.go, go.gg, go.tanh_out, s));
   }
   return kOk;
 }
@@ -198,8 +219,10 @@ int att_seq_backward(const AttDims& d, const int* bs, const float* dH, const flo
                      float dropout_p, unsigned long long seed, int training, hipStream_t s) {
   RC(check(d, bs));
   CAPNET_REQUIRE(dH && hiddens && feat && saved && saved_i && scratch, "att_seq_backward: null argument");
-  CAPNET_REQUIRE(g.dVcat && g.dbV && g.dScat && g.dbS && g.dUcat && g.dWz && g.dbz && g.dWe && g.dbe &&
-                     g.dwf && g.dbf && g.dWih && g.dbih && g.dWic && g.dbic && g.dEmb,
+  const bool fac = d.cell == kCellFactored;
+  const GateOrderA go = fac ? GateOrderA{0, 1, 2, 3, 0} : GateOrderA{0, 1, 3, 2, 1};
+  CAPNET_REQUIRE(g.dVcat && g.dWz && g.dbz && g.dWe && g.dbe && g.dwf && g.dbf && g.dWih && g.dbih &&
+                     g.dWic && g.dbic && g.dEmb && (!fac || (g.dbV && g.dScat && g.dbS && g.dUcat)),
                  "att_seq_backward: null gradient buffer");
   const ALayout L = make_alayout(d);
   const int E = d.E, F = d.F, H = d.H, N = d.N, A = d.A, P = d.P, C = d.C, ZW = L.ZW, XW = L.XW;
@@ -209,8 +232,8 @@ int att_seq_backward(const AttDims& d, const int* bs, const float* dH, const flo
   size_t o = 0;
   auto take = [&](size_t n) { size_t r = o; o += (n + 3) / 4 * 4; return r; };
   float* Zb = scratch + take((size_t)N * ZW);
-  float* dA2 = scratch + take((size_t)N * 4 * F);
-  float* dA1 = scratch + take((size_t)N * 4 * F);
+  float* dA2 = scratch + take(fac ? (size_t)N * 4 * F : 4);
+  float* dA1 = scratch + take(fac ? (size_t)N * 4 * F : 4);
   float* dXA = scratch + take((size_t)N * XW);
   float* Hprev = scratch + take((size_t)N * H);
   float* dh_rec = scratch + take((size_t)d.B * H);
@@ -231,13 +254,19 @@ int att_seq_backward(const AttDims& d, const int* bs, const float* dH, const flo
     const float* Zf = sv + L.Zf + (size_t)r0 * ZW;
     float* Z = Zb + (size_t)r0 * ZW;
     RC(lstm_pointwise_bwd(Zf, ZW, sv + L.Cst + (size_t)r0 * H, cprev, dH + (size_t)r0 * H, dh_rec, dc,
-                          Z, ZW, b, b_next, H, 0, 1, 2, 3, 0, s));
-    RC(sgemm(false, false, b, F, H, Z, ZW, sv + L.Ucat, F, dA2 + (size_t)r0 * 4 * F, 4 * F, nullptr,
-             0, 4, H, (long)H * F, F, 0, 0, s));
-    RC(sgemm(false, false, b, F, F, dA2 + (size_t)r0 * 4 * F, 4 * F, sv + L.Scat, F,
-             dA1 + (size_t)r0 * 4 * F, 4 * F, nullptr, 0, 4, F, (long)F * F, F, 0, 0, s));
-    RC(sgemm_splitk(false, false, b, XW, 4 * F, dA1 + (size_t)r0 * 4 * F, 4 * F, sv + L.Vcat, XW,
-                    dXA + (size_t)r0 * XW, XW, nullptr, 0, skws, kAttSplitKFloats, s));
+                          Z, ZW, b, b_next, H, go.gi, go.gf, go.go, go.gg, go.tanh_out, s));
+    if (fac) {
+      RC(sgemm(false, false, b, F, H, Z, ZW, sv + L.Ucat, F, dA2 + (size_t)r0 * 4 * F, 4 * F, nullptr,
+               0, 4, H, (long)H * F, F, 0, 0, s));
+      RC(sgemm(false, false, b, F, F, dA2 + (size_t)r0 * 4 * F, 4 * F, sv + L.Scat, F,
+               dA1 + (size_t)r0 * 4 * F, 4 * F, nullptr, 0, 4, F, (long)F * F, F, 0, 0, s));
+      RC(sgemm_splitk(false, false, b, XW, 4 * F, dA1 + (size_t)r0 * 4 * F, 4 * F, sv + L.Vcat, XW,
+                      dXA + (size_t)r0 * XW, XW, nullptr, 0, skws, kAttSplitKFloats, s));
+    } else {
+      // d[x | ctx] = d gates . weight_ih
+      RC(sgemm_splitk(false, false, b, XW, 4 * H, Z, ZW, sv + L.Vcat, XW, dXA + (size_t)r0 * XW, XW,
+                      nullptr, 0, skws, kAttSplitKFloats, s));
+    }
     RC(att_step_bwd(sv + L.att1, feat, Zf + 4 * H, ZW, Zf + 4 * H + A, ZW, sv + L.awe + (size_t)r0 * C,
                     sv + L.alpha + (size_t)r0 * P, w.full_att_w, dXA + (size_t)r0 * XW + E, XW,
                     dalphas_bt, d.steps, t, b, P, A, C, dalpha_part, Z + 4 * H + A, Z + 4 * H, ZW,
@@ -250,14 +279,20 @@ int att_seq_backward(const AttDims& d, const int* bs, const float* dH, const flo
   RC(gather_prev_rows(hiddens, saved_i + L.prev_row, sv + L.h0, saved_i + L.row_sample, Hprev, N, H, s));
   RC(sgemm(true, false, ZW, H, N, Zb, ZW, Hprev, H, g.dWz, H, nullptr, 0, 1, 0, 0, 0, 0, 0, s));
   RC(colsum(Zb, ZW, N, ZW, g.dbz, 0, s));
-  RC(sgemm(true, false, H, F, N, Zb, ZW, sv + L.A2, 4 * F, g.dUcat, F, nullptr, 0, 4, H, F,
-           (long)H * F, 0, 0, s));
-  RC(colsum(dA2, 4 * F, N, 4 * F, g.dbS, 0, s));
-  RC(sgemm(true, false, F, F, N, dA2, 4 * F, sv + L.A1, 4 * F, g.dScat, F, nullptr, 0, 4, F, F,
-           (long)F * F, 0, 0, s));
-  RC(colsum(dA1, 4 * F, N, 4 * F, g.dbV, 0, s));
-  RC(sgemm(true, false, 4 * F, XW, N, dA1, 4 * F, sv + L.XA, XW, g.dVcat, XW, nullptr, 0, 1, 0, 0, 0,
-           0, 0, s));
+  if (fac) {
+    RC(sgemm(true, false, H, F, N, Zb, ZW, sv + L.A2, 4 * F, g.dUcat, F, nullptr, 0, 4, H, F,
+             (long)H * F, 0, 0, s));
+    RC(colsum(dA2, 4 * F, N, 4 * F, g.dbS, 0, s));
+    RC(sgemm(true, false, F, F, N, dA2, 4 * F, sv + L.A1, 4 * F, g.dScat, F, nullptr, 0, 4, F, F,
+             (long)F * F, 0, 0, s));
+    RC(colsum(dA1, 4 * F, N, 4 * F, g.dbV, 0, s));
+    RC(sgemm(true, false, 4 * F, XW, N, dA1, 4 * F, sv + L.XA, XW, g.dVcat, XW, nullptr, 0, 1, 0, 0, 0,
+             0, 0, s));
+  } else {
+    // d weight_ih [4H][E+C] = d gates^T . [x | ctx]   (d bias_ih = d bias_hh = dbz[0:4H])
+    RC(sgemm(true, false, 4 * H, XW, N, Zb, ZW, sv + L.XA, XW, g.dVcat, XW, nullptr, 0, 1, 0, 0, 0,
+             0, 0, s));
+  }
   RC(colsum(dwf_rows, A, N, A, g.dwf, 0, s));
   RC(colsum(dbf_rows, 1, N, 1, g.dbf, 0, s));
   // encoder_att: d att1 was summed per sample over the steps

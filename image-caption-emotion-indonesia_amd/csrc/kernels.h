@@ -181,6 +181,7 @@ int seq_backward(const SeqDims& d, const int* batch_sizes, const float* dH, cons
 // decoder_att_seq.cpp -- DecoderFactoredLSTMAtt (stylenet/model_att.py:73-305)
 struct AttDims {
   int B, T, steps, N, E, F, H, V, A, P, C;
+  int cell;  // kCellFactored: DecoderFactoredLSTMAtt; kCellLSTM: nic DecoderRNNAtt (nn.LSTMCell)
 };
 struct AttWeights {
   const float* Vw[4]; const float* Vb[4];   // V_g: [F][E+C]

@@ -468,18 +468,31 @@ def decoder_sequence(cfg, captions, features, emb, Cw, Cb, weights):
 # ---------------------------------------------------------------------------------------
 # autograd: whole-sequence attention decoder (DecoderFactoredLSTMAtt)
 # ---------------------------------------------------------------------------------------
+def _att_slots(ws, cell):
+    """The 44-slot weight table of capnet_att_seq_forward/backward."""
+    if cell == CELL_FACTORED:
+        return ws
+    slots = [None] * 32
+    slots[0], slots[4], slots[24], slots[28] = ws[0], ws[1], ws[2], ws[3]
+    return slots + list(ws[4:])
+
+
 class DecoderAttSeqFn(torch.autograd.Function):
     """(hiddens [N,H], alphas [B,steps,P]) of the attention recurrence.
 
-    weights: 44 tensors in the order of capnet_att_seq_forward (V w x4, V b x4, S w x4, S b x4,
-    U w x4, U b x4, W w x4, W b x4, init_h w,b, init_c w,b, encoder_att w,b, decoder_att w,b,
-    full_att w,b, f_beta w,b). `features` gets no gradient (frozen trunk)."""
+    weights, cfg["cell"] == CELL_FACTORED (default): 44 tensors in the order of
+    capnet_att_seq_forward (V w x4, V b x4, S w x4, S b x4, U w x4, U b x4, W w x4, W b x4,
+    init_h w,b, init_c w,b, encoder_att w,b, decoder_att w,b, full_att w,b, f_beta w,b).
+    cfg["cell"] == CELL_LSTM (nic DecoderRNNAtt): 16 tensors weight_ih, bias_ih, weight_hh,
+    bias_hh followed by the same 12 attention / init tensors.
+    `features` gets no gradient (frozen trunk)."""
 
     @staticmethod
     def forward(ctx, cfg, captions, features, emb, Cw, Cb, *weights):
         _need_cuda(captions, features, emb, Cw, Cb, *weights)
-        if len(weights) != 44:
-            raise CapnetError("attention decoder takes 44 weight tensors")
+        cell = cfg.get("cell", CELL_FACTORED)
+        if len(weights) != (44 if cell == CELL_FACTORED else 16):
+            raise CapnetError("attention decoder takes 44 (factored) / 16 (LSTMCell) weight tensors")
         captions = _c(captions)
         if captions.dtype != torch.int64:
             raise CapnetError("captions must be int64")
@@ -487,7 +500,8 @@ class DecoderAttSeqFn(torch.autograd.Function):
         bs, tf = cfg["batch_sizes"], cfg["tf_mask"]
         B, T = captions.shape
         V, E = emb.shape
-        H, F, A = cfg["hidden_size"], cfg["factored_size"], cfg["attention_size"]
+        H, A = cfg["hidden_size"], cfg["attention_size"]
+        F = cfg["factored_size"] if cell == CELL_FACTORED else 4
         features = _c(features)
         if features.dim() != 3 or features.shape[0] != B:
             raise CapnetError("features must be [batch, pixels, feature_size]")
@@ -495,7 +509,7 @@ class DecoderAttSeqFn(torch.autograd.Function):
         N = sum(bs)
         if len(tf) != len(bs) or bs[0] != B:
             raise CapnetError("attention decoder: batch_sizes / tf_mask do not match the batch")
-        dims = [B, T, len(bs), N, E, F, H, V, A, P, Cf]
+        dims = [B, T, len(bs), N, E, F, H, V, A, P, Cf, cell]
         ws = [_c(w) for w in weights]
         emb_c, Cw_c, Cb_c = _c(emb), _c(Cw), _c(Cb)
         cdims = int_array(dims)
@@ -507,7 +521,7 @@ class DecoderAttSeqFn(torch.autograd.Function):
         alphas = torch.empty((B, len(bs), P), dtype=torch.float32, device=dev)
         tfm = (C.c_ubyte * len(tf))(*[1 if x else 0 for x in tf])
         check(L.capnet_att_seq_forward(cdims, int_array(bs), tfm, ptr(captions), ptr(features),
-                                       ptr(emb_c), ptr_array(ws), ptr(Cw_c), ptr(Cb_c),
+                                       ptr(emb_c), ptr_array(_att_slots(ws, cell)), ptr(Cw_c), ptr(Cb_c),
                                        float(cfg["dropout"]), int(cfg["seed"]), int(cfg["training"]),
                                        ptr(saved), ptr(saved_i), ptr(scratch), ptr(hiddens),
                                        ptr(alphas), ptr(err_flag(dev)), current_stream()),
@@ -522,7 +536,7 @@ class DecoderAttSeqFn(torch.autograd.Function):
         saved, saved_i, hiddens, features = ctx.saved_tensors[:4]
         ws = list(ctx.saved_tensors[4:])
         cfg, dims = ctx.cfg, ctx.dims
-        B, T, steps, N, E, F, H, V, A, P, Cf = dims
+        B, T, steps, N, E, F, H, V, A, P, Cf, cell = dims
         dev = saved.device
         L = _lib.lib()
         cdims = int_array(dims)
@@ -534,17 +548,27 @@ class DecoderAttSeqFn(torch.autograd.Function):
             return torch.empty(shape, dtype=torch.float32, device=dev)
 
         ZW, XW = 4 * H + A + Cf, E + Cf
-        dV, dbV, dS, dbS, dU = new(4 * F, XW), new(4 * F), new(4, F, F), new(4 * F), new(4, H, F)
+        if cell == CELL_FACTORED:
+            dV, dbV, dS, dbS, dU = new(4 * F, XW), new(4 * F), new(4, F, F), new(4 * F), new(4, H, F)
+        else:
+            dV, dbV, dS, dbS, dU = new(4 * H, XW), None, None, None, None
         dWz, dbz = new(ZW, H), new(ZW)
         dWe, dbe, dwf, dbf = new(A, Cf), new(A), new(1, A), new(1)
         dWih, dbih, dWic, dbic = new(H, Cf), new(H), new(H, Cf), new(H)
         dEmb = new(V, E)
         grads = [dV, dbV, dS, dbS, dU, dWz, dbz, dWe, dbe, dwf, dbf, dWih, dbih, dWic, dbic, dEmb]
         check(L.capnet_att_seq_backward(cdims, int_array(cfg["batch_sizes"]), ptr(d_hiddens),
-                                        ptr(d_alphas), ptr(hiddens), ptr(features), ptr_array(ws),
+                                        ptr(d_alphas), ptr(hiddens), ptr(features),
+                                        ptr_array(_att_slots(ws, cell)),
                                         ptr(saved), ptr(saved_i), ptr(scratch), ptr_array(grads),
                                         float(cfg["dropout"]), int(cfg["seed"]), int(cfg["training"]),
                                         current_stream()), "capnet_att_seq_backward")
+        tail = [dWih, dbih, dWic, dbic, dWe, dbe,
+                dWz[4 * H:4 * H + A], dbz[4 * H:4 * H + A], dwf, dbf,
+                dWz[4 * H + A:], dbz[4 * H + A:]]
+        if cell != CELL_FACTORED:
+            wg = [dV, dbz[:4 * H], dWz[:4 * H], dbz[:4 * H].clone()] + tail
+            return (None, None, None, dEmb, None, None) + tuple(wg)
         wg = ([dV[g * F:(g + 1) * F] for g in range(4)] +
               [dbV[g * F:(g + 1) * F] for g in range(4)] +
               [dS[g] for g in range(4)] +

@@ -189,9 +189,13 @@ int capnet_seq_backward(const int* dims, const int* batch_sizes, const float* d_
                         float* scratch, float* const* grads, float dropout_p,
                         unsigned long long seed, int training, capnet_stream_t stream);
 
-/* ---- attention decoder: DecoderFactoredLSTMAtt.forward (stylenet/model_att.py:238-305) ----
- * dims (host int[11]) = {B, T, steps, N, E, F, H, V, A, P, C}: A attention size, P pixels
- * (14*14), C feature size (2048; must be a multiple of 512). captions are the reference's
+/* ---- attention decoders: DecoderFactoredLSTMAtt.forward (stylenet/model_att.py:238-305) and
+ * DecoderRNNAtt.forward (nic/model_att.py:152-202) ----
+ * dims (host int[12]) = {B, T, steps, N, E, F, H, V, A, P, C, cell}: A attention size, P pixels
+ * (14*14), C feature size (2048; must be a multiple of 512); cell 0 = factored LSTM, cell 1 =
+ * nn.LSTMCell(E+C, H) (F ignored, pass 4; weights[0]/[4] = weight_ih [4H][E+C] / bias_ih,
+ * weights[24]/[28] = weight_hh / bias_hh, the other V/S/U/W slots NULL; grads[0] = d weight_ih,
+ * grads[5]/[6] first 4H rows = d weight_hh / d bias_ih = d bias_hh, grads[1..4] may be NULL). captions are the reference's
  * captions[:, :-1] (T columns), batch_sizes / tf_mask as for capnet_seq_forward, features the
  * NHWC map [B][P][C] of the attention encoder (no gradient: the trunk is frozen).
  * weights (host array of 44 device pointers): [0..31] V/S/U/W weights and biases per gate as in

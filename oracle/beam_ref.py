@@ -3,6 +3,7 @@
   sample_factored      <- DecoderFactoredLSTM.sample,     stylenet/model.py:198-294
   sample_lstm          <- DecoderRNN.sample,              nic/model.py:117-207
   sample_factored_att  <- DecoderFactoredLSTMAtt.sample,  stylenet/model_att.py:307-426
+  sample_lstm_att      <- DecoderRNNAtt.sample,           nic/model_att.py:204-297
 The loop follows the reference statement by statement (tensor bookkeeping included) with ONE
 documented deviation: `top_k_words / vocab_size` (model.py:249) is written `//`. Under the
 torch 1.1 the reference pins, `/` on a LongTensor was an integer division; under current torch the
@@ -92,5 +93,23 @@ def sample_factored_att(p, features, start_token, end_token, k=5, mode="factual"
         x = torch.cat([p["B.weight"][prev_words].squeeze(1), awe], dim=1)
         h, c = D.factored_step(p, x, h, c, mode)
         return Fn.linear(h, p["C.weight"], p["C.bias"]), (h, c, f)
+
+    return _beam(step_fn, (h0, c0, feat), V, start_token, end_token, k, max_seq_length)
+
+
+def sample_lstm_att(p, features, start_token, end_token, k=5, max_seq_length=40):
+    V = p["linear.weight"].shape[0]
+    feat = features.reshape(1, -1, features.size(-1))
+    feat = feat.expand(k, feat.size(1), feat.size(2))
+    mean = feat.mean(dim=1)
+    h0, c0 = D._lin(p, "init_h", mean), D._lin(p, "init_c", mean)
+
+    def step_fn(prev_words, state):
+        h, c, f = state
+        awe, _ = D.attention_step(p, "attention", f, h)
+        awe = torch.sigmoid(D._lin(p, "f_beta", h)) * awe
+        x = torch.cat([p["embed.weight"][prev_words].squeeze(1), awe], dim=1)
+        h, c = D.lstmcell_step(p, x, h, c)
+        return Fn.linear(h, p["linear.weight"], p["linear.bias"]), (h, c, f)
 
     return _beam(step_fn, (h0, c0, feat), V, start_token, end_token, k, max_seq_length)

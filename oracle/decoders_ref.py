@@ -6,6 +6,8 @@ the reference (loss.backward(), stylenet/train_multitask.py:386).
 
   factored_lstm_forward  <- DecoderFactoredLSTM.forward / forward_step, stylenet/model.py:115-196
   lstm_forward           <- DecoderRNN.forward / forward_step,          nic/model.py:74-115
+  factored_att_forward   <- DecoderFactoredLSTMAtt.forward,             stylenet/model_att.py:238-305
+  lstm_att_forward       <- DecoderRNNAtt.forward,                      nic/model_att.py:152-202
 The teacher-forcing decisions are an explicit list (one bool per time step); callers draw them
 with `random.random() < ratio` in step order, which is what stylenet/model.py:181 does.
 """
@@ -121,13 +123,12 @@ def attention_step(p, prefix, feat, h):
     return (feat * alpha.unsqueeze(2)).sum(dim=1), alpha
 
 
-def factored_att_forward(p, captions, lengths, features, tf_mask, mode="factual", drop_mask=None):
-    """Returns (packed logits [N, V], alphas [B, max(lengths), P]). `captions` / `lengths` are what
-    the training loop passes: captions[:, :-1] and lengths - 1 (train_multitask_att.py:402-408)."""
+def _att_run(p, step, emb_name, out_name, att, captions, lengths, features, tf_mask, drop_mask):
+    """Shared loop of stylenet/model_att.py:238-305 and nic/model_att.py:152-202."""
     B = captions.size(0)
     feat = features.reshape(B, -1, features.size(-1))
     P = feat.size(1)
-    emb_w = p["B.weight"]
+    emb_w = p[emb_name + ".weight"]
     embeddings = emb_w[captions]
     if drop_mask is not None:
         embeddings = embeddings * drop_mask
@@ -135,10 +136,8 @@ def factored_att_forward(p, captions, lengths, features, tf_mask, mode="factual"
     mean = feat.mean(dim=1)
     h = _lin(p, "init_h", mean)
     c = _lin(p, "init_c", mean)
-    alphas = torch.zeros(B, max(lengths), P, dtype=emb_w.dtype)
     hiddens, alpha_list = [], []
     predicted = captions[:, 0:1]
-    att = MODE_ATT[mode]
     for i, b in enumerate(bs):
         awe, alpha = attention_step(p, att, feat[:b], h[:b])
         gate = torch.sigmoid(_lin(p, "f_beta", h[:b]))
@@ -147,16 +146,30 @@ def factored_att_forward(p, captions, lengths, features, tf_mask, mode="factual"
             x = embeddings[:b, i, :]
         else:
             x = emb_w[predicted][:b, 0, :]
-        h, c = factored_step(p, torch.cat([x, awe], dim=1), h[:b], c[:b], mode)
+        h, c = step(torch.cat([x, awe], dim=1), h[:b], c[:b])
         hiddens.append(h)
         alpha_list.append((b, i, alpha))
-        predicted = Fn.linear(h, p["C.weight"], p["C.bias"]).max(1)[1].unsqueeze(1)
+        predicted = _lin(p, out_name, h).max(1)[1].unsqueeze(1)
     # alphas[:b, i, :] = alpha without in-place writes (keeps autograd simple)
     cols = []
     for b, i, alpha in alpha_list:
         cols.append(torch.cat([alpha, torch.zeros(B - b, P, dtype=alpha.dtype)], 0).unsqueeze(1))
     alphas = torch.cat(cols, 1)
-    return Fn.linear(torch.cat(hiddens, 0), p["C.weight"], p["C.bias"]), alphas
+    return _lin(p, out_name, torch.cat(hiddens, 0)), alphas
+
+
+def factored_att_forward(p, captions, lengths, features, tf_mask, mode="factual", drop_mask=None):
+    """DecoderFactoredLSTMAtt.forward. Returns (packed logits [N, V], alphas [B, max(lengths), P]).
+    `captions` / `lengths` are what the training loop passes: captions[:, :-1] and lengths - 1
+    (train_multitask_att.py:402-408)."""
+    return _att_run(p, lambda x, h, c: factored_step(p, x, h, c, mode), "B", "C", MODE_ATT[mode],
+                    captions, lengths, features, tf_mask, drop_mask)
+
+
+def lstm_att_forward(p, captions, lengths, features, tf_mask, drop_mask=None):
+    """nic DecoderRNNAtt.forward (nic/model_att.py:152-202): the same loop around nn.LSTMCell."""
+    return _att_run(p, lambda x, h, c: lstmcell_step(p, x, h, c), "embed", "linear", "attention",
+                    captions, lengths, features, tf_mask, drop_mask)
 
 
 def att_loss(logits, alphas, targets, alpha_c=1.0):

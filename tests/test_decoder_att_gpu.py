@@ -92,3 +92,76 @@ def test_attention_decoder_matches_oracle_seeded(dev, B, V, A, E, F, H, P, mode,
             assert prm.grad is None, k
         else:
             assert grad_close(prm.grad, gr, 5e-4), k
+
+
+# ---- nic DecoderRNNAtt (nic/model_att.py) ------------------------------------------------
+def _nic_step(dec, captions, lengths, feats, seed, ratio, dev):
+    dec.zero_grad()
+    lens = [l - 1 for l in lengths]
+    targets = D.packed_targets(captions[:, 1:], lens).to(dev)
+    random.seed(seed)
+    out, alphas = dec(captions[:, :-1].contiguous().to(dev), lens, feats.to(dev),
+                      teacher_forcing_ratio=ratio)
+    loss = ops.cross_entropy(out, targets) + 1.0 * ((1.0 - alphas.sum(dim=1)) ** 2).mean()
+    loss.backward()
+    ops.check_device_errors()
+    return out, alphas, loss
+
+
+@pytest.mark.parametrize("cname,seed,ratio", [("tf1", 100, 1.0), ("tf0", 101, 0.0), ("tfmix", 3, 0.6)])
+def test_nic_attention_decoder_matches_reference_fixture(dev, cname, seed, ratio):
+    from capnet.nic_model_att import DecoderRNNAtt
+    z = load_golden("decoder_nic_att_tiny.npz")
+    A, E, H, V, Cf, P = z["dims"].tolist()
+    dec = DecoderRNNAtt(A, E, H, V, 1, feature_size=Cf, dropout=0.0)
+    dec.load_state_dict(golden_params(z))
+    dec.to(dev).train()
+    c = golden_case(z, cname)
+    out, alphas, loss = _nic_step(dec, t(z["captions"]), z["lengths"].tolist(), t(z["features"]),
+                                  seed, ratio, dev)
+    assert rel_err(out, c["logits"]) < 2e-5
+    assert rel_err(alphas, c["alphas"]) < 2e-5
+    assert abs(loss.item() - float(c["loss"])) / float(c["loss"]) < 2e-6
+    n = 0
+    for k, prm in dec.named_parameters():
+        assert prm.grad is not None, k
+        assert grad_close(prm.grad, c["grad." + k], 1e-4), k
+        n += 1
+    assert n == 19
+
+
+def test_nic_attention_decoder_matches_oracle_full_size(dev):
+    from capnet.nic_model_att import DecoderRNNAtt
+    B, V, A, E, H, P, Cf, ratio = 12, 1000, 512, 300, 512, 196, 2048, 0.8
+    dec = DecoderRNNAtt(A, E, H, V, 1, feature_size=Cf, dropout=0.0)
+    p = synthetic.decoder_state(dec.state_dict(), seed=3, bias_range=0.05)
+    dec.load_state_dict(p)
+    dec.to(dev).train()
+    _, captions, lengths = synthetic.make_batch(B, V, seed=52, images=False, min_len=4, max_len=11)
+    feats = torch.randn(B, P, Cf, generator=torch.Generator().manual_seed(9)).abs() * 0.5
+    lens = [l - 1 for l in lengths]
+    seed = 11
+    random.seed(seed)
+    tf = [random.random() < ratio for _ in range(max(lens))]
+    pr = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    logits_r, alphas_r = D.lstm_att_forward(pr, captions[:, :-1], lens, feats, tf)
+    loss_r = D.att_loss(logits_r, alphas_r, D.packed_targets(captions[:, 1:], lens))
+    loss_r.backward()
+    out, alphas, loss = _nic_step(dec, captions, lengths, feats, seed, ratio, dev)
+    assert rel_err(out, logits_r) < 1e-4
+    assert rel_err(alphas, alphas_r) < 1e-4
+    assert abs(loss.item() - loss_r.item()) / loss_r.item() < 1e-5
+    for k, prm in dec.named_parameters():
+        assert grad_close(prm.grad, pr[k].grad, 5e-4), k
+
+
+def test_nic_attention_sample_matches_reference_sequence(dev):
+    from capnet.nic_model_att import DecoderRNNAtt
+    z = load_golden("decoder_nic_att_tiny.npz")
+    A, E, H, V, Cf, P = z["dims"].tolist()
+    dec = DecoderRNNAtt(A, E, H, V, 1, feature_size=Cf, dropout=0.0)
+    dec.load_state_dict({k[len("sample.param."):]: t(z[k]) for k in z.files
+                         if k.startswith("sample.param.")})
+    dec.to(dev).eval()
+    seq = dec.sample(t(z["sample.features"]).to(dev), 1, 2, k=int(z["sample.k"]))
+    assert seq.cpu().tolist() == z["sample.seq"].tolist()

@@ -162,3 +162,37 @@ def test_beam_search_matches_reference_sequences(name):
             seq = beam_ref.sample_factored_att(p, t(c["features"]), start, end, k=k, mode=str(c["mode"]),
                                                max_seq_length=maxlen)
     assert seq.tolist() == c["seq"].tolist()
+
+
+# ---- nic DecoderRNNAtt -----------------------------------------------------------------
+@pytest.mark.parametrize("cname", ["tf1", "tf0", "tfmix"])
+def test_nic_attention_decoder_matches_reference(cname):
+    """oracle lstm_att_forward vs nic DecoderRNNAtt run verbatim (fixture)."""
+    z = load_golden("decoder_nic_att_tiny.npz")
+    c = golden_case(z, cname)
+    p = {k: v.clone().requires_grad_(True) for k, v in golden_params(z).items()}
+    captions, lengths, feats = t(z["captions"]), z["lengths"].tolist(), t(z["features"])
+    lens = [l - 1 for l in lengths]
+    tf = [bool(x) for x in c["tf_mask"]]
+    logits, alphas = D.lstm_att_forward(p, captions[:, :-1], lens, feats, tf)
+    loss = D.att_loss(logits, alphas, D.packed_targets(captions[:, 1:], lens))
+    loss.backward()
+    assert rel_err(logits, c["logits"]) < TOL
+    assert rel_err(alphas, c["alphas"]) < TOL
+    assert abs(loss.item() - float(c["loss"])) < 2e-6
+    n = 0
+    for k, v in p.items():
+        key = "grad." + k
+        if key in c:
+            assert rel_err(v.grad, c[key]) < 2e-5 or float(abs(c[key]).max()) < 1e-6, k
+            n += 1
+    assert n >= 18
+
+
+def test_nic_attention_beam_search_matches_reference_sequence():
+    from oracle import beam_ref
+    z = load_golden("decoder_nic_att_tiny.npz")
+    p = {k[len("sample.param."):]: t(z[k]) for k in z.files if k.startswith("sample.param.")}
+    with torch.no_grad():
+        seq = beam_ref.sample_lstm_att(p, t(z["sample.features"]), 1, 2, k=int(z["sample.k"]))
+    assert seq.tolist() == z["sample.seq"].tolist()

@@ -309,6 +309,67 @@ def gen_att_tiny():
     save("decoder_att_tiny.npz", arrays)
 
 
+def gen_nic_att_tiny():
+    """nic DecoderRNNAtt (nic/model_att.py) on the call pattern of nic/train_att.py (captions[:, :-1],
+    lengths-1, loss + alpha penalty), plus its beam search."""
+    ref = load_ref("nic", "model_att")
+    A, E, H, V, Cf, P = 16, 12, 16, 37, 512, 4
+    dec = ref.DecoderRNNAtt(A, E, H, V, 1, feature_size=Cf, dropout=0.0)
+    dec.train()
+    state = synthetic.decoder_state(dec.state_dict(), seed=17, bias_range=0.1)
+    dec.load_state_dict(state)
+    captions, lengths, _ = tiny_inputs(V, E, 27)
+    features = torch.randn(4, 2, 2, Cf, generator=torch.Generator().manual_seed(28))
+    arrays = {"captions": captions.numpy(), "lengths": np.array(lengths), "features": features.numpy(),
+              "dims": np.array([A, E, H, V, Cf, P])}
+    for k, v in state.items():
+        arrays["param." + k] = v.numpy()
+    names = []
+    for cname, seed, ratio in [("tf1", 100, 1.0), ("tf0", 101, 0.0), ("tfmix", 3, 0.6)]:
+        dec.zero_grad()
+        lens = [l - 1 for l in lengths]
+        targets = pack_padded_sequence(captions[:, 1:], lens, batch_first=True)[0]
+        random.seed(seed)
+        outputs, alphas = dec(captions[:, :-1], lens, features, teacher_forcing_ratio=ratio)
+        ce = nn.CrossEntropyLoss()(outputs, targets)
+        loss = ce + 1. * ((1. - alphas.sum(dim=1)) ** 2).mean()
+        loss.backward()
+        names.append(cname)
+        pre = "case.%s." % cname
+        arrays[pre + "logits"] = outputs.detach().numpy()
+        arrays[pre + "alphas"] = alphas.detach().numpy()
+        arrays[pre + "loss"] = loss.detach().numpy()
+        arrays[pre + "tf_mask"] = np.array(tf_draws(seed, max(lens), ratio), dtype=np.uint8)
+        for k, prm in dec.named_parameters():
+            if prm.grad is not None:
+                arrays[pre + "grad." + k] = prm.grad.detach().numpy().copy()
+        print("nic att", cname, "tf", arrays[pre + "tf_mask"].tolist(), "loss", float(loss))
+    arrays["cases"] = np.array(names)
+    # beam search with scaled weights (see gen_sample_tiny)
+    for seed in range(300, 500):
+        dec2 = ref.DecoderRNNAtt(A, E, H, V, 1, feature_size=Cf, dropout=0.0)
+        dec2.eval()
+        st = dict(synthetic.decoder_state(dec2.state_dict(), seed=seed, bias_range=0.1))
+        for key in st:
+            if key.endswith("weight") or "weight_" in key:
+                st[key] = st[key] * (4.0 if key.startswith("linear.") else 5.0)
+        dec2.load_state_dict(st)
+        feats = torch.randn(1, 2, 2, Cf, generator=torch.Generator().manual_seed(seed + 1000))
+        with legacy_int_division(), torch.no_grad():
+            seq = dec2.sample(feats, 1, 2, k=5)
+        if 5 <= seq.shape[1] <= 20:
+            break
+    else:
+        raise RuntimeError("no seed found")
+    print("nic att sample seed", seed, seq.tolist())
+    arrays["sample.seq"] = seq.numpy()
+    arrays["sample.features"] = feats.numpy()
+    arrays["sample.k"] = np.array(5)
+    for k, v in st.items():
+        arrays["sample.param." + k] = v.numpy()
+    save("decoder_nic_att_tiny.npz", arrays)
+
+
 class legacy_int_division:
     """torch 1.1 (the version the reference pins) divided integer tensors with integer results;
     `top_k_words / self.vocab_size` at stylenet/model.py:249 relies on it. Current torch returns a
@@ -428,3 +489,5 @@ if __name__ == "__main__":
         gen_att_tiny()
     if "sample_tiny" in which:
         gen_sample_tiny()
+    if "nic_att_tiny" in which:
+        gen_nic_att_tiny()
