@@ -306,6 +306,10 @@ int capnet_xent_fwd(const float* logits, long ld, int N, int V, const long long*
                     capnet_stream_t stream) {
   return xent_fwd(logits, ld, N, V, targets, lse, row_loss, loss, err_flag, S(stream));
 }
+int capnet_topk_correct(const float* logits, long ld, int N, int V, const long long* targets, int k,
+                        int* count, int* err_flag, capnet_stream_t stream) {
+  return topk_correct(logits, ld, N, V, targets, k, count, err_flag, S(stream));
+}
 int capnet_xent_bwd(const float* logits, long ld, int N, int V, const long long* targets,
                     const float* lse, const float* grad_out, float* dlogits, long ldd,
                     capnet_stream_t stream) {

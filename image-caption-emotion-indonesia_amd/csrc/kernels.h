@@ -129,6 +129,8 @@ int att_step_bwd(const float* att1, const float* feat, const float* att2, long l
 // loss_optim.hip
 int xent_fwd(const float* logits, long ld, int N, int V, const long long* targets, float* lse,
              float* row_loss, float* loss, int* err_flag, hipStream_t stream);
+int topk_correct(const float* logits, long ld, int N, int V, const long long* targets, int k,
+                 int* count, int* err_flag, hipStream_t stream);
 int xent_bwd(const float* logits, long ld, int N, int V, const long long* targets,
              const float* lse, const float* gout, float* dlogits, long ldd, hipStream_t stream);
 int clamp_adam(int n_tensors, float* const* params, float* const* grads, float* const* exp_avg,

@@ -247,6 +247,46 @@ int pack_tensors(int n_tensors, float* const* tensors, const long* numel, float*
   return kOk;
 }
 
+// ---- top-k accuracy: utils.accuracy (stylenet/utils.py:127-140) --------------------------------
+// count += #rows whose target is among the k largest logits. Rank of the target = number of
+// entries that beat it (strictly larger, or equal with a lower index: the order torch.topk
+// returns on ties is unspecified, lower index first is the CPU behaviour). One workgroup per row.
+__global__ __launch_bounds__(256) void topk_correct_kernel(const float* __restrict__ logits, long ld,
+                                                           int V, const long long* __restrict__ targets,
+                                                           int k, int* __restrict__ count,
+                                                           int* __restrict__ err_flag) {
+  const int row = blockIdx.x;
+  const long long tg = targets[row];
+  if (tg < 0 || tg >= V) {
+    if (threadIdx.x == 0) atomicMax(err_flag, 2);
+    return;
+  }
+  const float* p = logits + (long)row * ld;
+  const float tv = p[tg];
+  int beat = 0;
+  for (int v = threadIdx.x; v < V; v += 256) {
+    const float x = p[v];
+    beat += (x > tv || (x == tv && v < tg)) ? 1 : 0;
+  }
+  for (int o = 32; o > 0; o >>= 1) beat += __shfl_xor(beat, o);
+  __shared__ int s_b[4];
+  if ((threadIdx.x & 63) == 0) s_b[threadIdx.x >> 6] = beat;
+  __syncthreads();
+  if (threadIdx.x == 0 && s_b[0] + s_b[1] + s_b[2] + s_b[3] < k) atomicAdd(count, 1);
+}
+
+int topk_correct(const float* logits, long ld, int N, int V, const long long* targets, int k,
+                 int* count, int* err_flag, hipStream_t stream) {
+  CAPNET_REQUIRE(logits && targets && count && err_flag && V > 0 && ld >= V && k > 0 && N >= 0,
+                 "topk_correct: bad argument");
+  CAPNET_HIP_CHECK(hipMemsetAsync(count, 0, sizeof(int), stream));
+  if (N == 0) return kOk;
+  hipLaunchKernelGGL(topk_correct_kernel, dim3(N), dim3(256), 0, stream, logits, ld, V, targets, k,
+                     count, err_flag);
+  CAPNET_LAUNCH_CHECK();
+  return kOk;
+}
+
 // ---- stand-alone element-wise clamp (utils.clip_gradient with a foreign optimiser) -----------
 __global__ __launch_bounds__(256) void clamp_kernel(float* __restrict__ x, long n, float lo,
                                                     float hi) {

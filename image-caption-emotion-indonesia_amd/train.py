@@ -4,6 +4,8 @@
                  (stylenet/train_multitask.py:373-389, 527-537; nic/train_transfer_fac.py:252-296)
   train_factual  stylenet/train_multitask.py:364-408
   train_emotion  stylenet/train_multitask.py:511-557
+  val_factual / val_emotion   stylenet/train_multitask.py:272-361, 411-508 (eval-mode trunk on the
+                 running BN statistics, free-running decode, top-5 accuracy, BLEU-4, one beam sample)
 Same order of operations: targets -> encoder -> decoder -> CrossEntropyLoss -> zero_grad ->
 backward -> clip_gradient -> optimizer.step. The loss stays on the device; `.item()` is taken
 once per log interval instead of every step (the reference syncs every step, :393,396).
@@ -14,7 +16,8 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .utils import AverageMeter, clip_gradient
+from .metrics import corpus_bleu
+from .utils import AverageMeter, accuracy, clip_gradient
 
 
 class CrossEntropyLoss(nn.Module):
@@ -129,3 +132,76 @@ def train_emotion(encoder, decoder, optimizer, criterion, data_loaders, tags, lo
         _drain(pending, losses[j])
     ops.check_device_errors()
     return [l.avg for l in losses]
+
+
+def _unpack_predictions(outputs, batch_sizes, lengths):
+    """Per-sample argmax word ids from packed logits: the `pad_packed_sequence` + `torch.max(s, 1)`
+    + `[:l]` of stylenet/train_multitask.py:311-329 (one argmax kernel over all N rows, then host
+    index arithmetic)."""
+    pred = ops.argmax_rows(outputs).tolist()
+    off = [0]
+    for b in batch_sizes:
+        off.append(off[-1] + b)
+    out = []
+    for i, l in enumerate(lengths):
+        out.append([pred[off[t] + i] for t in range(l)])
+    return out
+
+
+def _validate(encoder, decoder, vocab, criterion, data_loader, mode, device):
+    decoder.eval()
+    encoder.eval()
+    import time
+    from .utils import AverageMeter as _AM
+    batch_time, losses, top5accs = _AM(), _AM(), _AM()
+    t0 = time.time()
+    references, hypotheses = [], []
+    device = device or next(decoder.parameters()).device
+    start, end = vocab.word2idx['<start>'], vocab.word2idx['<end>']
+    features = None
+    kw = {} if mode is None else {"mode": mode}
+    for i, (images, captions, lengths, all_captions) in enumerate(data_loader):
+        images = images.to(device)
+        captions = captions.to(device)
+        targets = ops.packed_targets(captions, lengths)
+        with torch.no_grad():
+            features = encoder(images)
+            outputs = decoder(captions, lengths, features, teacher_forcing_ratio=0, **kw)
+            loss = criterion(outputs, targets)
+        losses.update(loss.item(), sum(lengths))
+        top5accs.update(accuracy(outputs, targets, 5), sum(lengths))
+        batch_time.update(time.time() - t0)
+        for caps in all_captions:
+            caps = [[int(w) for w in (c.tolist() if hasattr(c, "tolist") else c)] for c in caps]
+            references.append([[w for w in c if w != start and w != end] for c in caps])
+        for pred in _unpack_predictions(outputs, ops.batch_sizes_from_lengths(lengths), lengths):
+            hypotheses.append([w for w in pred if w != start and w != end])
+        assert len(references) == len(hypotheses)
+    ops.check_device_errors()
+    bleu4 = corpus_bleu(references, hypotheses)
+    feature = features[0].unsqueeze(0)
+    sampled_ids = decoder.sample(feature, start_token=start, end_token=end, **kw)[0].tolist()
+    sampled_caption = []
+    for word_id in sampled_ids:
+        word = vocab.idx2word[word_id]
+        sampled_caption.append(word)
+        if word == '<end>':
+            break
+    print(sampled_caption)
+    return batch_time.val, top5accs.avg, losses.avg, bleu4
+
+
+def val_factual(encoder, decoder, vocab, criterion, data_loader, device=None):
+    """stylenet/train_multitask.py:272-361. Returns (batch_time, top-5 accuracy %, loss, BLEU-4)."""
+    from .nic_model import DecoderRNN
+    return _validate(encoder, decoder, vocab, criterion, data_loader,
+                     None if isinstance(decoder, DecoderRNN) else "factual", device)
+
+
+def val_emotion(encoder, decoder, vocab, criterion, data_loaders, tags, device=None):
+    """stylenet/train_multitask.py:411-508: one validation pass per emotion loader, decoded in that
+    emotion's mode. Returns (batch_time, [top5 per tag], [loss per tag], [bleu4 per tag])."""
+    res = [_validate(encoder, decoder, vocab, criterion, data_loaders[j], tags[j], device)
+           for j in range(len(tags))]
+    return (res[-1][0] if res else 0.0, [r[1] for r in res], [r[2] for r in res],
+            [r[3] for r in res])

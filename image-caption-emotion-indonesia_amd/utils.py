@@ -1,8 +1,8 @@
 """Host-side helpers of the training loop (stylenet/utils.py:51-60,93-140)."""
 import torch
 
-from . import _lib
-from ._lib import check, current_stream, ptr
+from . import _lib, ops
+from ._lib import CapnetError, check, current_stream, ptr
 from .optim import Adam
 
 
@@ -46,3 +46,20 @@ def adjust_learning_rate(optimizer, shrink_factor):
     """stylenet/utils.py:114-124."""
     for param_group in optimizer.param_groups:
         param_group['lr'] = param_group['lr'] * shrink_factor
+
+
+def accuracy(scores, targets, k):
+    """Top-k accuracy in percent (stylenet/utils.py:127-140): one kernel counts the rows whose
+    target is among the k largest scores; the `.item()` is the same sync the reference has."""
+    if not scores.is_cuda or scores.dtype != torch.float32 or targets.dtype != torch.int64:
+        raise CapnetError("accuracy: scores must be CUDA float32 and targets int64")
+    scores = scores.detach()
+    scores = scores if scores.is_contiguous() else scores.contiguous()
+    targets = targets.reshape(-1).contiguous()
+    batch_size = targets.size(0)
+    count = torch.empty(1, dtype=torch.int32, device=scores.device)
+    check(_lib.lib().capnet_topk_correct(ptr(scores), scores.shape[1], batch_size, scores.shape[1],
+                                         ptr(targets), int(k), ptr(count),
+                                         ptr(ops.err_flag(scores.device)), current_stream()),
+          "capnet_topk_correct")
+    return count.item() * (100.0 / batch_size)

@@ -274,6 +274,12 @@ int capnet_xent_bwd(const float* logits, long ld, int N, int V, const long long*
                     const float* lse, const float* grad_out, float* dlogits, long ldd,
                     capnet_stream_t stream);
 
+/* count[0] = number of rows whose target is among the k largest logits of its row -- the numerator
+ * of utils.accuracy(scores, targets, k) (stylenet/utils.py:127-140; top-5 in val_factual,
+ * train_multitask.py:306). Ties are ranked lower index first. count is overwritten. */
+int capnet_topk_correct(const float* logits, long ld, int N, int V, const long long* targets, int k,
+                        int* count, int* err_flag, capnet_stream_t stream);
+
 /* ---- optimiser: utils.clip_gradient (element-wise clamp, stylenet/utils.py:51-60) fused with
  * torch.optim.Adam.step (stylenet/train_multitask.py:166-167,389; no weight decay, no amsgrad).
  * Host arrays of n device pointers / sizes / per-tensor step counts (>= 1, already

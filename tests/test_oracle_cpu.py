@@ -196,3 +196,21 @@ def test_nic_attention_beam_search_matches_reference_sequence():
     with torch.no_grad():
         seq = beam_ref.sample_lstm_att(p, t(z["sample.features"]), 1, 2, k=int(z["sample.k"]))
     assert seq.tolist() == z["sample.seq"].tolist()
+
+
+# ---- BLEU-4 (host metric of the validation loop) ---------------------------------------------
+def test_corpus_bleu_known_values():
+    from capnet.metrics import corpus_bleu
+    ref = [[1, 2, 3, 4, 5, 6, 7]]
+    assert corpus_bleu([ref], [[1, 2, 3, 4, 5, 6, 7]]) == pytest.approx(1.0)
+    assert corpus_bleu([ref], [[9, 9, 9, 9]]) == 0.0
+    # hand computation: hyp = 1 2 3 4 5 9 7 vs ref: p1 = 6/7, p2 = 4/6, p3 = 3/5, p4 = 2/4, bp = 1
+    want = (6 / 7 * 4 / 6 * 3 / 5 * 2 / 4) ** 0.25
+    assert corpus_bleu([ref], [[1, 2, 3, 4, 5, 9, 7]]) == pytest.approx(want)
+    # brevity penalty: hyp of 5 tokens against a 7-token reference, all n-grams matching
+    import math
+    assert corpus_bleu([ref], [[1, 2, 3, 4, 5]]) == pytest.approx(math.exp(1 - 7 / 5))
+    # clipping and multiple references (Papineni et al. example: "the the the ..." -> 2/7 unigrams)
+    refs = [[1, 5, 6, 7, 1, 8, 9], [10, 6, 11, 5, 7, 1, 8]]
+    hyp = [1, 1, 1, 1, 1, 1, 1]
+    assert corpus_bleu([refs], [hyp], weights=(1.0,)) == pytest.approx(2 / 7)
