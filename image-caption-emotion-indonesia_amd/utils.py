@@ -23,6 +23,44 @@ def clip_gradient(optimizer, grad_clip):
                                               current_stream()), "capnet_clamp")
 
 
+def save_checkpoint(folder, data_name, mode, epoch, epochs_since_improvement, encoder, decoder,
+                    optimizer, lang_optimizer, bleu4, is_best):
+    """stylenet/utils.py:63-90, same arguments and file names
+    (`<mode>_checkpoint_<data_name>.pth.tar`, plus `<mode>_BEST_checkpoint_...` when is_best).
+    The reference pickles the module and optimiser OBJECTS; this writes their state_dicts (keys
+    identical to the reference's classes, tests/test_checkpoint_cpu.py), which load with
+    `torch.load(..., weights_only=True)` and into the reference's own classes."""
+    state = {
+        'epoch': epoch,
+        'epochs_since_improvement': epochs_since_improvement,
+        'bleu-4': bleu4,
+        'encoder': encoder.state_dict(),
+        'decoder': decoder.state_dict(),
+        'optimizer': optimizer.state_dict() if optimizer is not None else None,
+        'lang_optimizer': lang_optimizer.state_dict() if lang_optimizer is not None else None,
+    }
+    filename = folder + '/' + mode + '_checkpoint_' + data_name + '.pth.tar'
+    torch.save(state, filename)
+    if is_best:
+        filename = folder + '/' + mode + '_BEST_checkpoint_' + data_name + '.pth.tar'
+        torch.save(state, filename)
+
+
+def load_checkpoint(path, encoder=None, decoder=None, optimizer=None, lang_optimizer=None,
+                    map_location="cpu"):
+    """Restore a checkpoint written by save_checkpoint; returns its scalar fields."""
+    state = torch.load(path, map_location=map_location, weights_only=True)
+    if encoder is not None:
+        encoder.load_state_dict(state['encoder'])
+    if decoder is not None:
+        decoder.load_state_dict(state['decoder'])
+    if optimizer is not None and state.get('optimizer') is not None:
+        optimizer.load_state_dict(state['optimizer'])
+    if lang_optimizer is not None and state.get('lang_optimizer') is not None:
+        lang_optimizer.load_state_dict(state['lang_optimizer'])
+    return {k: state[k] for k in ('epoch', 'epochs_since_improvement', 'bleu-4')}
+
+
 class AverageMeter(object):
     """stylenet/utils.py:93-111."""
 

@@ -370,6 +370,30 @@ def gen_nic_att_tiny():
     save("decoder_nic_att_tiny.npz", arrays)
 
 
+def gen_state_keys():
+    """state_dict key order and shapes of the reference's decoder classes (App. B of SURVEY.md):
+    what a checkpoint written by the reference contains, so that the mirror classes load it."""
+    import json
+    out = {}
+    ref = load_ref("stylenet", "model")
+    out["stylenet.DecoderFactoredLSTM(300,512,512,1000,1)"] = [
+        [k, list(v.shape)] for k, v in ref.DecoderFactoredLSTM(300, 512, 512, 1000, 1).state_dict().items()]
+    refa = load_ref("stylenet", "model_att")
+    out["stylenet.DecoderFactoredLSTMAtt(512,300,512,512,1000,1)"] = [
+        [k, list(v.shape)] for k, v in refa.DecoderFactoredLSTMAtt(512, 300, 512, 512, 1000, 1).state_dict().items()]
+    refn = load_ref("nic", "model")
+    out["nic.DecoderRNN(300,512,1000,1)"] = [
+        [k, list(v.shape)] for k, v in refn.DecoderRNN(300, 512, 1000, 1).state_dict().items()]
+    refna = load_ref("nic", "model_att")
+    out["nic.DecoderRNNAtt(512,300,512,1000,1)"] = [
+        [k, list(v.shape)] for k, v in refna.DecoderRNNAtt(512, 300, 512, 1000, 1).state_dict().items()]
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, "state_dict_keys.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=0)
+    print("wrote", path, {k: len(v) for k, v in out.items()})
+
+
 class legacy_int_division:
     """torch 1.1 (the version the reference pins) divided integer tensors with integer results;
     `top_k_words / self.vocab_size` at stylenet/model.py:249 relies on it. Current torch returns a
@@ -489,5 +513,7 @@ if __name__ == "__main__":
         gen_att_tiny()
     if "sample_tiny" in which:
         gen_sample_tiny()
+    if "state_keys" in which:
+        gen_state_keys()
     if "nic_att_tiny" in which:
         gen_nic_att_tiny()
