@@ -22,6 +22,7 @@ SIGNATURES = {
     "capnet_abi_version": (_i, []),
     "capnet_sgemm": (_i, [_i, _i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, _vp, _i, _i, _l, _l, _l,
                           _l, _i, _vp]),
+    "capnet_sgemm_splitk": (_i, [_i, _i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, _vp, _i, _vp, _sz, _vp]),
     "capnet_colsum": (_i, [_vp, _l, _i, _i, _vp, _i, _vp]),
     "capnet_argmax_rows": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "capnet_topk_correct": (_i, [_vp, _l, _i, _i, _vp, _i, _vp, _vp, _vp]),

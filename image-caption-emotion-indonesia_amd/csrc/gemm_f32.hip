@@ -111,7 +111,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
        i += (long)gridDim.x * blockDim.x) {
     const int m = (int)(i / N), n = (int)(i - (long)m * N);
     float s = 0.f;
-    for (int k = 0; k < splitk; ++k) s += slab[(long)k * total + i];
+    int k = 0;
+    for (; k + 8 <= splitk; k += 8) {   // 8 independent loads in flight, summed in slab order
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = slab[(long)(k + u) * total + i];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; k < splitk; ++k) s += slab[(long)k * total + i];
     if (bias) s += bias[n];
     float* o = out + (long)m * ldc + n;
     *o = accumulate ? *o + s : s;
@@ -160,40 +168,166 @@ int sgemm(bool ta, bool tb, int M, int N, int K, const float* A, long lda, const
 
 namespace capnet {
 
-// Skinny products of the recurrence (M <= 64 rows per time step): too few output tiles to fill
-// 256 CUs, so K is split across workgroups into slabs in `ws` and summed in a fixed order.
-// Falls back to sgemm when there are enough tiles or no workspace.
+// ---- skinny products of the recurrence (M <= 64 rows per time step) ---------------------------
+// Too few output tiles to fill 256 CUs and too little work per tile to hide a k-loop's memory
+// latency: the generic kernel above spends one HBM round trip per BK = 16 slice. Here a
+// workgroup owns one 64x64 output tile and ONE K chunk (KC = 64 or 128): it issues every load of
+// the chunk at once (one round trip), stages both operands in LDS as 16-B cells along k
+// (conflict-free half-cell reads feed two MFMA k-steps each), and writes its partial tile to a
+// slab; slabs are summed in a fixed order by splitk_reduce_kernel. A is [M][K] row-major;
+// TB: B is [N][K] (nn.Linear weight) else [K][N].
+constexpr int kSkinnyRows = 64;
+constexpr int kSkCell = kSkinnyRows + 1;  // cells per kq column of the A / B^T images
+constexpr int kSkLdb = 80;                // dword row stride of the [k][n] image (TB = false)
+
+template <int KC, bool TB>
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(const float* __restrict__ A, long lda,
+                                                          const float* __restrict__ B, long ldb,
+                                                          float* __restrict__ slab, int M, int N,
+                                                          int K, int tiles_n) {
+  typedef float f32x4v __attribute__((ext_vector_type(4)));
+  typedef float f32x2v __attribute__((ext_vector_type(2)));
+  constexpr int KQ = KC / 4;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  f32x4v* a_cells = reinterpret_cast<f32x4v*>(lds);                  // [KQ][65] cells
+  float* b_img = lds + (size_t)KQ * kSkCell * 4;                     // TB: [KQ][65] cells; else [KC][80]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tn = blockIdx.x % tiles_n, ks = blockIdx.x / tiles_n, tm = blockIdx.y;
+  const int m0 = tm * 64, n0 = tn * 64, k0 = ks * KC;
+  const int kq_real = (min(KC, K - k0) + 3) / 4;   // K % 4 == 0 is required by the host
+  constexpr int NA = (64 * KQ) / 256;              // cells per thread
+  f32x4v va[NA], vb[NA];
+#pragma unroll
+  for (int q = 0; q < NA; ++q) {
+    const int idx = tid + 256 * q;
+    const int row = idx / KQ, kq = idx - row * KQ;
+    const int r = min(m0 + row, M - 1), kk = min(kq, kq_real - 1);
+    va[q] = *reinterpret_cast<const f32x4v*>(A + (long)r * lda + k0 + 4 * kk);
+  }
+  if (TB) {
+#pragma unroll
+    for (int q = 0; q < NA; ++q) {
+      const int idx = tid + 256 * q;
+      const int row = idx / KQ, kq = idx - row * KQ;
+      const int r = min(n0 + row, N - 1), kk = min(kq, kq_real - 1);
+      vb[q] = *reinterpret_cast<const f32x4v*>(B + (long)r * ldb + k0 + 4 * kk);
+    }
+  } else {
+    // [K][N]: thread -> (k row, 16-B column group); N % 4 == 0 required by the host
+#pragma unroll
+    for (int q = 0; q < NA; ++q) {
+      const int idx = tid + 256 * q;
+      const int kr = idx >> 4, c4 = idx & 15;
+      const int kk = min(k0 + kr, K - 1), nn = min(n0 + 4 * c4, N - 4);
+      vb[q] = *reinterpret_cast<const f32x4v*>(B + (long)kk * ldb + nn);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < NA; ++q) {
+    const int idx = tid + 256 * q;
+    const int row = idx / KQ, kq = idx - row * KQ;
+    const float m = (m0 + row < M && kq < kq_real) ? 1.f : 0.f;
+    a_cells[kq * kSkCell + row] = va[q] * m;
+  }
+  if (TB) {
+    f32x4v* b_cells = reinterpret_cast<f32x4v*>(b_img);
+#pragma unroll
+    for (int q = 0; q < NA; ++q) {
+      const int idx = tid + 256 * q;
+      const int row = idx / KQ, kq = idx - row * KQ;
+      const float m = (n0 + row < N && kq < kq_real) ? 1.f : 0.f;
+      b_cells[kq * kSkCell + row] = vb[q] * m;
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < NA; ++q) {
+      const int idx = tid + 256 * q;
+      const int kr = idx >> 4, c4 = idx & 15;
+      const bool ok = k0 + kr < K && n0 + 4 * c4 < N;   // N % 4 == 0: groups are all-or-nothing
+      const float m = ok ? 1.f : 0.f;
+      *reinterpret_cast<f32x4v*>(b_img + kr * kSkLdb + 4 * c4) = vb[q] * m;
+    }
+  }
+  __syncthreads();
+  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const f32x2v* ap = reinterpret_cast<const f32x2v*>(lds) + 2 * (wm * 32 + li) + lh;
+  if (TB) {
+    const f32x2v* bp = reinterpret_cast<const f32x2v*>(b_img) + 2 * (wn * 32 + li) + lh;
+#pragma unroll
+    for (int kq = 0; kq < KQ; ++kq) {
+      const f32x2v a = ap[2 * kq * kSkCell], b = bp[2 * kq * kSkCell];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+    }
+  } else {
+    const float* bp = b_img + (2 * lh) * kSkLdb + wn * 32 + li;
+#pragma unroll
+    for (int kq = 0; kq < KQ; ++kq) {
+      const f32x2v a = ap[2 * kq * kSkCell];
+      const float b0 = bp[(4 * kq) * kSkLdb], b1 = bp[(4 * kq + 1) * kSkLdb];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1, acc, 0, 0, 0);
+    }
+  }
+  float* out = slab + (long)ks * M * N;
+  const int n = n0 + wn * 32 + li;
+  if (n < N) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (m < M) out[(long)m * N + n] = acc[r];
+    }
+  }
+}
+
+template <int KC, bool TB>
+static int launch_skinny(const float* A, long lda, const float* B, long ldb, float* slab, int M, int N,
+                         int K, hipStream_t stream) {
+  const int tiles_n = cdiv(N, 64), tiles_m = cdiv(M, 64), splits = cdiv(K, KC);
+  const size_t lds_bytes = ((size_t)(KC / 4) * kSkCell * 4 +
+                            (TB ? (size_t)(KC / 4) * kSkCell * 4 : (size_t)KC * kSkLdb)) * sizeof(float);
+  auto kern = gemm_skinny_kernel<KC, TB>;
+  static bool attr_set = false;
+  if (lds_bytes > 64 * 1024 && !attr_set) {
+    CAPNET_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)lds_bytes));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(tiles_n * splits, tiles_m), dim3(256), lds_bytes, stream, A, lda, B,
+                     ldb, slab, M, N, K, tiles_n);
+  return kOk;
+}
+
+// K-split product for M <= 128 rows; falls back to sgemm when a slab workspace is missing.
 int sgemm_splitk(bool ta, bool tb, int M, int N, int K, const float* A, long lda, const float* B,
                  long ldb, float* C, long ldc, const float* bias, int accumulate, float* ws,
                  size_t ws_floats, hipStream_t stream) {
   if (M == 0 || N == 0) return kOk;
-  const long tiles = (long)cdiv(M, 64) * cdiv(N, 64);
-  int splitk = 1;
-  if (tiles < 96 && K >= 256) {
-    splitk = (int)(192 / tiles);
-    if (splitk > K / 64) splitk = K / 64;
-    if (splitk > 32) splitk = 32;
-  }
-  while (splitk > 1 && (size_t)splitk * M * N > ws_floats) --splitk;
-  if (splitk <= 1 || !ws)
+  const bool skinny_ok = !ta && ws && M <= 128 && K % 4 == 0 && lda % 4 == 0 && aligned16(A) &&
+                         aligned16(B) && ldb % 4 == 0 && (tb || N % 4 == 0) && N >= 4 && K >= 64;
+  if (!skinny_ok)
     return sgemm(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, 1, 0, 0, 0, 0, 0, stream);
   CAPNET_REQUIRE(A && B && C, "sgemm_splitk: null operand");
-  GemmArgs g;
-  g.A = A; g.B = B; g.C = ws; g.bias = nullptr;
-  g.M = M; g.N = N; g.K = K;
-  g.lda = lda; g.ldb = ldb; g.ldc = N;
-  g.sA = g.sB = g.sC = g.sBias = 0;
-  g.accumulate = 0;
-  g.splitk = splitk;
-  g.kchunk = cdiv(cdiv(K, splitk), 16) * 16;
-  g.splitk = cdiv(K, g.kchunk);
-  g.tiles_m = cdiv(M, 64);
-  g.tiles_n = cdiv(N, 64);
-  const bool vec = aligned16(A) && aligned16(B) && (lda % 4 == 0) && (ldb % 4 == 0);
-  dispatch_layout<64, 64, 16>(g, 1, ta, tb, vec, stream);
+  const long tiles = (long)cdiv(M, 64) * cdiv(N, 64);
+  // one K chunk per workgroup: 64 when that still leaves the chip under-filled, else 128
+  int kc = tiles * cdiv(K, 128) < 200 ? 64 : 128;
+  if ((size_t)cdiv(K, kc) * M * N > ws_floats) kc = 128;
+  if ((size_t)cdiv(K, kc) * M * N > ws_floats)
+    return sgemm(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, 1, 0, 0, 0, 0, 0, stream);
+  const int splits = cdiv(K, kc);
+  if (kc == 64) {
+    if (tb) launch_skinny<64, true>(A, lda, B, ldb, ws, M, N, K, stream);
+    else launch_skinny<64, false>(A, lda, B, ldb, ws, M, N, K, stream);
+  } else {
+    if (tb) launch_skinny<128, true>(A, lda, B, ldb, ws, M, N, K, stream);
+    else launch_skinny<128, false>(A, lda, B, ldb, ws, M, N, K, stream);
+  }
   const long total = (long)M * N;
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)(cdiv(total, 256) > 1024 ? 1024 : cdiv(total, 256))),
-                     dim3(256), 0, stream, ws, g.splitk, M, N, C, ldc, bias, accumulate);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)(cdiv(total, 256) > 2048 ? 2048 : cdiv(total, 256))),
+                     dim3(256), 0, stream, ws, splits, M, N, C, ldc, bias, accumulate);
   CAPNET_LAUNCH_CHECK();
   return kOk;
 }

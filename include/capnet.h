@@ -46,6 +46,17 @@ int capnet_sgemm(int transA, int transB, int M, int N, int K, const float* A, lo
                  int batch, long strideA, long strideB, long strideC, long strideBias,
                  int force_tile, capnet_stream_t stream);
 
+/* The same product for the per-time-step shapes of the decoders (M <= 128 rows, A not transposed):
+ * K is cut into chunks, one workgroup per (64x64 tile, chunk) loads its chunk in one round trip and
+ * writes a partial tile to `workspace` (workspace_floats >= ceil(K/64)*M*N for the finest split);
+ * the partials are summed in a fixed order. Falls back to capnet_sgemm's kernel when the shape
+ * does not qualify. Replaces the per-step nn.Linear calls of stylenet/model.py:147-150,189 and
+ * model_att.py:59-60,283. */
+int capnet_sgemm_splitk(int transA, int transB, int M, int N, int K, const float* A, long lda,
+                        const float* B, long ldb, float* C, long ldc, const float* bias,
+                        int accumulate, float* workspace, size_t workspace_floats,
+                        capnet_stream_t stream);
+
 /* out[c] (+)= sum_r x[r][c]  -- bias gradients (autograd of nn.Linear bias). */
 int capnet_colsum(const float* x, long ld, int rows, int C, float* out, int accumulate,
                   capnet_stream_t stream);

@@ -286,3 +286,30 @@ def test_argmax_first_max(dev):
     x[3, 255] = 2; x[3, 256] = 2
     out = ops.argmax_rows(x.to(dev)).cpu().tolist()
     assert out == [7, 999, 0, 255, 0]
+
+
+# ---- per-step (skinny) product: one K chunk per workgroup + fixed-order slab sum -----------------
+@pytest.mark.parametrize("tb", [True, False])
+@pytest.mark.parametrize("M,N,K", [(64, 2048, 512), (64, 512, 2048), (9, 4608, 512), (64, 8192, 512),
+                                   (33, 300, 2048), (64, 2348, 2048), (96, 512, 512), (1, 64, 64),
+                                   (64, 512, 100), (5, 36, 72)])
+def test_sgemm_splitk_matches_fp64(dev, M, N, K, tb):
+    from capnet._lib import lib, check, ptr, current_stream
+    g = torch.Generator().manual_seed(M * 7 + N + K)
+    A = torch.randn(M, K, generator=g)
+    B = torch.randn(N, K, generator=g) if tb else torch.randn(K, N, generator=g)
+    bias = torch.randn(N, generator=g)
+    C0 = torch.randn(M, N, generator=g)
+    ref = A.double() @ (B.double().t() if tb else B.double()) + bias.double() + C0.double()
+    Ad, Bd, bd, Cd = A.to(dev), B.to(dev), bias.to(dev), C0.to(dev)
+    ws = torch.empty(32 * 64 * 4608, device=dev)
+    check(lib().capnet_sgemm_splitk(0, int(tb), M, N, K, ptr(Ad), K, ptr(Bd), Bd.shape[1], ptr(Cd), N,
+                                    ptr(bd), 1, ptr(ws), ws.numel(), current_stream()))
+    err = (Cd.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 2e-6, err
+    # no workspace: falls back to the generic kernel, same answer
+    Cd2 = C0.to(dev)
+    check(lib().capnet_sgemm_splitk(0, int(tb), M, N, K, ptr(Ad), K, ptr(Bd), Bd.shape[1], ptr(Cd2), N,
+                                    ptr(bd), 1, None, 0, current_stream()))
+    # (one fp32 accumulator over all of K: looser than the chunked sum above)
+    assert (Cd2.cpu().double() - ref).abs().max().item() / ref.abs().max().item() < 6e-6
