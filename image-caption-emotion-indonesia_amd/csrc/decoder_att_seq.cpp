@@ -188,7 +188,8 @@ int att_seq_forward(const AttDims& d, const int* bs, const unsigned char* tf,
                     A, C, sv + L.alpha + (size_t)r0 * P, alphas_bt, d.steps, t,
                     sv + L.awe + (size_t)r0 * C, sv + L.XA + (size_t)r0 * XW + E, XW, s));
     if (t > 0 && !tf[t]) {
-      RC(sgemm(false, true, b, d.V, H, hprev, H, Cw, H, scratch, d.V, Cb, 0, 1, 0, 0, 0, 0, 0, s));
+      RC(sgemm_splitk(false, true, b, d.V, H, hprev, H, Cw, H, scratch, d.V, Cb, 0, skws,
+                      kAttSplitKFloats, s));
       RC(argmax_rows(scratch, b, d.V, d.V, saved_i + L.row_token + r0, s));
       RC(gather_inputs(captions, d.T, nullptr, emb, E, d.V, saved_i + L.row_sample,
                        saved_i + L.row_col, saved_i + L.row_token, sv + L.XA, XW, r0, r0 + b,
@@ -198,10 +199,12 @@ int att_seq_forward(const AttDims& d, const int* bs, const unsigned char* tf,
       // factored chain on [x | gated context]
       RC(sgemm_splitk(false, true, b, 4 * F, XW, sv + L.XA + (size_t)r0 * XW, XW, sv + L.Vcat, XW,
                       sv + L.A1 + (size_t)r0 * 4 * F, 4 * F, sv + L.bV, 0, skws, kAttSplitKFloats, s));
-      RC(sgemm(false, true, b, F, F, sv + L.A1 + (size_t)r0 * 4 * F, 4 * F, sv + L.Scat, F,
-               sv + L.A2 + (size_t)r0 * 4 * F, 4 * F, sv + L.bS, 0, 4, F, (long)F * F, F, F, 0, s));
-      RC(sgemm(false, true, b, H, F, sv + L.A2 + (size_t)r0 * 4 * F, 4 * F, sv + L.Ucat, F, Z, ZW,
-               nullptr, 1, 4, F, (long)H * F, H, 0, 0, s));
+      RC(sgemm_splitk_batched(false, true, b, F, F, sv + L.A1 + (size_t)r0 * 4 * F, 4 * F, sv + L.Scat,
+                              F, sv + L.A2 + (size_t)r0 * 4 * F, 4 * F, sv + L.bS, 0, 4, F,
+                              (long)F * F, F, F, skws, kAttSplitKFloats, s));
+      RC(sgemm_splitk_batched(false, true, b, H, F, sv + L.A2 + (size_t)r0 * 4 * F, 4 * F, sv + L.Ucat,
+                              F, Z, ZW, nullptr, 1, 4, F, (long)H * F, H, 0, skws, kAttSplitKFloats,
+                              s));
     } else {
       // nn.LSTMCell input product: gates += [x | gated context] . weight_ih^T
       RC(sgemm_splitk(false, true, b, 4 * H, XW, sv + L.XA + (size_t)r0 * XW, XW, sv + L.Vcat, XW, Z,
@@ -256,10 +259,11 @@ int att_seq_backward(const AttDims& d, const int* bs, const float* dH, const flo
     RC(lstm_pointwise_bwd(Zf, ZW, sv + L.Cst + (size_t)r0 * H, cprev, dH + (size_t)r0 * H, dh_rec, dc,
                           Z, ZW, b, b_next, H, go.gi, go.gf, go.go, go.gg, go.tanh_out, s));
     if (fac) {
-      RC(sgemm(false, false, b, F, H, Z, ZW, sv + L.Ucat, F, dA2 + (size_t)r0 * 4 * F, 4 * F, nullptr,
-               0, 4, H, (long)H * F, F, 0, 0, s));
-      RC(sgemm(false, false, b, F, F, dA2 + (size_t)r0 * 4 * F, 4 * F, sv + L.Scat, F,
-               dA1 + (size_t)r0 * 4 * F, 4 * F, nullptr, 0, 4, F, (long)F * F, F, 0, 0, s));
+      RC(sgemm_splitk_batched(false, false, b, F, H, Z, ZW, sv + L.Ucat, F, dA2 + (size_t)r0 * 4 * F,
+                              4 * F, nullptr, 0, 4, H, (long)H * F, F, 0, skws, kAttSplitKFloats, s));
+      RC(sgemm_splitk_batched(false, false, b, F, F, dA2 + (size_t)r0 * 4 * F, 4 * F, sv + L.Scat, F,
+                              dA1 + (size_t)r0 * 4 * F, 4 * F, nullptr, 0, 4, F, (long)F * F, F, 0,
+                              skws, kAttSplitKFloats, s));
       RC(sgemm_splitk(false, false, b, XW, 4 * F, dA1 + (size_t)r0 * 4 * F, 4 * F, sv + L.Vcat, XW,
                       dXA + (size_t)r0 * XW, XW, nullptr, 0, skws, kAttSplitKFloats, s));
     } else {

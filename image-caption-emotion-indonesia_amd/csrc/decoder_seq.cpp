@@ -96,25 +96,31 @@ int copy_d2d(float* dst, const float* src, size_t n, hipStream_t s) {
   return kOk;
 }
 
-// gate pre-activations of rows [r0, r1) from their inputs X
-int input_chain(const SeqDims& d, const Layout& L, float* sv, int r0, int r1, hipStream_t s) {
+// gate pre-activations of rows [r0, r1) from their inputs X. ws: slab workspace of the per-step
+// (few rows) products; the all-rows call up front has enough tiles for the plain kernel.
+int input_chain(const SeqDims& d, const Layout& L, float* sv, int r0, int r1, float* ws,
+                size_t ws_floats, hipStream_t s) {
   const int n = r1 - r0;
   if (n <= 0) return kOk;
   const int E = d.E, F = d.F, H = d.H;
   if (d.cell == kCellFactored) {
     // A1 = X . Vcat^T + bV                          [n x 4F]
-    RC(sgemm(false, true, n, 4 * F, E, sv + L.X + (size_t)r0 * E, E, sv + L.Vcat, E,
-             sv + L.A1 + (size_t)r0 * 4 * F, 4 * F, sv + L.bV, 0, 1, 0, 0, 0, 0, 0, s));
+    RC(sgemm_splitk(false, true, n, 4 * F, E, sv + L.X + (size_t)r0 * E, E, sv + L.Vcat, E,
+                    sv + L.A1 + (size_t)r0 * 4 * F, 4 * F, sv + L.bV, 0, n <= 128 ? ws : nullptr,
+                    ws_floats, s));
     // A2[:, g] = A1[:, g] . S_g^T + bS_g             4 gate groups
-    RC(sgemm(false, true, n, F, F, sv + L.A1 + (size_t)r0 * 4 * F, 4 * F, sv + L.Scat, F,
-             sv + L.A2 + (size_t)r0 * 4 * F, 4 * F, sv + L.bS, 0, 4, F, (long)F * F, F, F, 0, s));
+    RC(sgemm_splitk_batched(false, true, n, F, F, sv + L.A1 + (size_t)r0 * 4 * F, 4 * F, sv + L.Scat, F,
+                            sv + L.A2 + (size_t)r0 * 4 * F, 4 * F, sv + L.bS, 0, 4, F, (long)F * F, F,
+                            F, n <= 128 ? ws : nullptr, ws_floats, s));
     // G[:, g] = A2[:, g] . U_g^T + (bU_g + bW_g)
-    RC(sgemm(false, true, n, H, F, sv + L.A2 + (size_t)r0 * 4 * F, 4 * F, sv + L.Ucat, F,
-             sv + L.G + (size_t)r0 * 4 * H, 4 * H, sv + L.bUW, 0, 4, F, (long)H * F, H, H, 0, s));
+    RC(sgemm_splitk_batched(false, true, n, H, F, sv + L.A2 + (size_t)r0 * 4 * F, 4 * F, sv + L.Ucat, F,
+                            sv + L.G + (size_t)r0 * 4 * H, 4 * H, sv + L.bUW, 0, 4, F, (long)H * F, H,
+                            H, n <= 128 ? ws : nullptr, ws_floats, s));
   } else {
     // G = X . W_ih^T + (b_ih + b_hh)
-    RC(sgemm(false, true, n, 4 * H, E, sv + L.X + (size_t)r0 * E, E, sv + L.Vcat, E,
-             sv + L.G + (size_t)r0 * 4 * H, 4 * H, sv + L.bUW, 0, 1, 0, 0, 0, 0, 0, s));
+    RC(sgemm_splitk(false, true, n, 4 * H, E, sv + L.X + (size_t)r0 * E, E, sv + L.Vcat, E,
+                    sv + L.G + (size_t)r0 * 4 * H, 4 * H, sv + L.bUW, 0, n <= 128 ? ws : nullptr,
+                    ws_floats, s));
   }
   return kOk;
 }
@@ -196,22 +202,23 @@ int seq_forward(const SeqDims& d, const int* batch_sizes, const unsigned char* t
   RC(gather_inputs(captions, d.T, features, emb, E, d.V, saved_i + L.row_sample,
                    saved_i + L.row_col, saved_i + L.row_token, sv + L.X, E, 0, N, dropout_p, seed,
                    training && dropout_p > 0.f, 0, err_flag, s));
-  RC(input_chain(d, L, sv, 0, N, s));
+  float* skws = scratch + (size_t)d.B * d.V + 64;
+  RC(input_chain(d, L, sv, 0, N, skws, kSplitKFloats, s));
 
   // ---- recurrence
-  float* skws = scratch + (size_t)d.B * d.V + 64;
   for (int t = 0; t < d.steps; ++t) {
     const int b = batch_sizes[t], r0 = off[t];
     if (t > 0) {
       const float* h_prev = hiddens + (size_t)off[t - 1] * H;
       if (!tf_mask[t]) {
         // predicted = argmax(C h_{t-1}) for the b surviving rows; then this step's input chain
-        RC(sgemm(false, true, b, d.V, H, h_prev, H, Cw, H, scratch, d.V, Cb, 0, 1, 0, 0, 0, 0, 0, s));
+        RC(sgemm_splitk(false, true, b, d.V, H, h_prev, H, Cw, H, scratch, d.V, Cb, 0, skws,
+                        kSplitKFloats, s));
         RC(argmax_rows(scratch, b, d.V, d.V, saved_i + L.row_token + r0, s));
         RC(gather_inputs(captions, d.T, features, emb, E, d.V, saved_i + L.row_sample,
                          saved_i + L.row_col, saved_i + L.row_token, sv + L.X, E, r0, r0 + b,
                          dropout_p, seed, 0, 1, err_flag, s));
-        RC(input_chain(d, L, sv, r0, r0 + b, s));
+        RC(input_chain(d, L, sv, r0, r0 + b, skws, kSplitKFloats, s));
       }
       if (fused_step) {
         // gates += h_{t-1} . Wcat^T, activations and the c/h update in one launch

@@ -184,7 +184,9 @@ template <int KC, bool TB>
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(const float* __restrict__ A, long lda,
                                                           const float* __restrict__ B, long ldb,
                                                           float* __restrict__ slab, int M, int N,
-                                                          int K, int tiles_n) {
+                                                          int K, int tiles_n, long sA, long sB) {
+  // blockIdx.z = batch member z: A + z*sA, B + z*sB, slab columns [z*N, (z+1)*N) of a row of
+  // gridDim.z*N (the gate-batched S_g / U_g products of the factored chain)
   typedef float f32x4v __attribute__((ext_vector_type(4)));
   typedef float f32x2v __attribute__((ext_vector_type(2)));
   constexpr int KQ = KC / 4;
@@ -194,6 +196,8 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const float* __restric
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tn = blockIdx.x % tiles_n, ks = blockIdx.x / tiles_n, tm = blockIdx.y;
   const int m0 = tm * 64, n0 = tn * 64, k0 = ks * KC;
+  A += (long)blockIdx.z * sA;
+  B += (long)blockIdx.z * sB;
   const int kq_real = (min(KC, K - k0) + 3) / 4;   // K % 4 == 0 is required by the host
   constexpr int NA = (64 * KQ) / 256;              // cells per thread
   f32x4v va[NA], vb[NA];
@@ -272,20 +276,21 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const float* __restric
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1, acc, 0, 0, 0);
     }
   }
-  float* out = slab + (long)ks * M * N;
+  const long ldo = (long)gridDim.z * N;
+  float* out = slab + (long)ks * M * ldo + (long)blockIdx.z * N;
   const int n = n0 + wn * 32 + li;
   if (n < N) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (m < M) out[(long)m * N + n] = acc[r];
+      if (m < M) out[(long)m * ldo + n] = acc[r];
     }
   }
 }
 
 template <int KC, bool TB>
 static int launch_skinny(const float* A, long lda, const float* B, long ldb, float* slab, int M, int N,
-                         int K, hipStream_t stream) {
+                         int K, int batch, long sA, long sB, hipStream_t stream) {
   const int tiles_n = cdiv(N, 64), tiles_m = cdiv(M, 64), splits = cdiv(K, KC);
   const size_t lds_bytes = ((size_t)(KC / 4) * kSkCell * 4 +
                             (TB ? (size_t)(KC / 4) * kSkCell * 4 : (size_t)KC * kSkLdb)) * sizeof(float);
@@ -296,40 +301,54 @@ static int launch_skinny(const float* A, long lda, const float* B, long ldb, flo
                                          (int)lds_bytes));
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(tiles_n * splits, tiles_m), dim3(256), lds_bytes, stream, A, lda, B,
-                     ldb, slab, M, N, K, tiles_n);
+  hipLaunchKernelGGL(kern, dim3(tiles_n * splits, tiles_m, batch), dim3(256), lds_bytes, stream, A,
+                     lda, B, ldb, slab, M, N, K, tiles_n, sA, sB);
   return kOk;
 }
 
-// K-split product for M <= 128 rows; falls back to sgemm when a slab workspace is missing.
+// K-split product for M <= 128 rows, optionally batched over `batch` members whose outputs are
+// adjacent column blocks of C (sC == N, bias concatenated); falls back to sgemm otherwise.
+int sgemm_splitk_batched(bool ta, bool tb, int M, int N, int K, const float* A, long lda,
+                         const float* B, long ldb, float* C, long ldc, const float* bias,
+                         int accumulate, int batch, long sA, long sB, long sC, long sBias, float* ws,
+                         size_t ws_floats, hipStream_t stream) {
+  if (M == 0 || N == 0 || batch == 0) return kOk;
+  const bool skinny_ok = !ta && ws && M <= 128 && K % 4 == 0 && lda % 4 == 0 && aligned16(A) &&
+                         aligned16(B) && ldb % 4 == 0 && (tb || N % 4 == 0) && N >= 4 && K >= 64 &&
+                         (batch == 1 || (sC == N && (!bias || sBias == N) && sA % 4 == 0 &&
+                                         sB % 4 == 0 && batch <= 64));
+  if (!skinny_ok)
+    return sgemm(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, batch, sA, sB, sC, sBias,
+                 0, stream);
+  CAPNET_REQUIRE(A && B && C, "sgemm_splitk: null operand");
+  const long tiles = (long)cdiv(M, 64) * cdiv(N, 64) * batch;
+  const size_t out_floats = (size_t)M * N * batch;
+  // one K chunk per workgroup: 64 when that still leaves the chip under-filled, else 128
+  int kc = tiles * cdiv(K, 128) < 200 ? 64 : 128;
+  if ((size_t)cdiv(K, kc) * out_floats > ws_floats) kc = 128;
+  if ((size_t)cdiv(K, kc) * out_floats > ws_floats)
+    return sgemm(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, batch, sA, sB, sC, sBias,
+                 0, stream);
+  const int splits = cdiv(K, kc);
+  if (kc == 64) {
+    if (tb) launch_skinny<64, true>(A, lda, B, ldb, ws, M, N, K, batch, sA, sB, stream);
+    else launch_skinny<64, false>(A, lda, B, ldb, ws, M, N, K, batch, sA, sB, stream);
+  } else {
+    if (tb) launch_skinny<128, true>(A, lda, B, ldb, ws, M, N, K, batch, sA, sB, stream);
+    else launch_skinny<128, false>(A, lda, B, ldb, ws, M, N, K, batch, sA, sB, stream);
+  }
+  const long total = (long)out_floats;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)(cdiv(total, 256) > 2048 ? 2048 : cdiv(total, 256))),
+                     dim3(256), 0, stream, ws, splits, M, N * batch, C, ldc, bias, accumulate);
+  CAPNET_LAUNCH_CHECK();
+  return kOk;
+}
+
 int sgemm_splitk(bool ta, bool tb, int M, int N, int K, const float* A, long lda, const float* B,
                  long ldb, float* C, long ldc, const float* bias, int accumulate, float* ws,
                  size_t ws_floats, hipStream_t stream) {
-  if (M == 0 || N == 0) return kOk;
-  const bool skinny_ok = !ta && ws && M <= 128 && K % 4 == 0 && lda % 4 == 0 && aligned16(A) &&
-                         aligned16(B) && ldb % 4 == 0 && (tb || N % 4 == 0) && N >= 4 && K >= 64;
-  if (!skinny_ok)
-    return sgemm(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, 1, 0, 0, 0, 0, 0, stream);
-  CAPNET_REQUIRE(A && B && C, "sgemm_splitk: null operand");
-  const long tiles = (long)cdiv(M, 64) * cdiv(N, 64);
-  // one K chunk per workgroup: 64 when that still leaves the chip under-filled, else 128
-  int kc = tiles * cdiv(K, 128) < 200 ? 64 : 128;
-  if ((size_t)cdiv(K, kc) * M * N > ws_floats) kc = 128;
-  if ((size_t)cdiv(K, kc) * M * N > ws_floats)
-    return sgemm(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, 1, 0, 0, 0, 0, 0, stream);
-  const int splits = cdiv(K, kc);
-  if (kc == 64) {
-    if (tb) launch_skinny<64, true>(A, lda, B, ldb, ws, M, N, K, stream);
-    else launch_skinny<64, false>(A, lda, B, ldb, ws, M, N, K, stream);
-  } else {
-    if (tb) launch_skinny<128, true>(A, lda, B, ldb, ws, M, N, K, stream);
-    else launch_skinny<128, false>(A, lda, B, ldb, ws, M, N, K, stream);
-  }
-  const long total = (long)M * N;
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)(cdiv(total, 256) > 2048 ? 2048 : cdiv(total, 256))),
-                     dim3(256), 0, stream, ws, splits, M, N, C, ldc, bias, accumulate);
-  CAPNET_LAUNCH_CHECK();
-  return kOk;
+  return sgemm_splitk_batched(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, 1, 0, 0, 0, 0,
+                              ws, ws_floats, stream);
 }
 
 }  // namespace capnet

@@ -13,6 +13,10 @@ int sgemm(bool ta, bool tb, int M, int N, int K, const float* A, long lda, const
 int sgemm_splitk(bool ta, bool tb, int M, int N, int K, const float* A, long lda, const float* B,
                  long ldb, float* C, long ldc, const float* bias, int accumulate, float* ws,
                  size_t ws_floats, hipStream_t stream);
+int sgemm_splitk_batched(bool ta, bool tb, int M, int N, int K, const float* A, long lda,
+                         const float* B, long ldb, float* C, long ldc, const float* bias,
+                         int accumulate, int batch, long sA, long sB, long sC, long sBias, float* ws,
+                         size_t ws_floats, hipStream_t stream);
 
 // conv_f32.hip
 int conv2d_fwd(const float* x, long sxb, long sxh, long sxw, long sxc, const float* w_packed,
