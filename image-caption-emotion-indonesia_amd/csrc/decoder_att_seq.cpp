@@ -301,7 +301,7 @@ int att_seq_backward(const AttDims& d, const int* bs, const float* dH, const flo
   RC(colsum(dbf_rows, 1, N, 1, g.dbf, 0, s));
   // encoder_att: d att1 was summed per sample over the steps
   RC(sgemm(true, false, A, C, d.B * P, datt1, A, feat, C, g.dWe, C, nullptr, 0, 1, 0, 0, 0, 0, 0, s));
-  RC(colsum(datt1, A, d.B * P, A, g.dbe, 0, s));
+  RC(colsum(datt1, A, d.B * P, A, g.dbe, 0, s, skws, kAttSplitKFloats));
   // init_h / init_c: dh0 = dh_rec, dc0 = dc (all B rows are alive at t = 0)
   RC(sgemm(true, false, H, C, d.B, dh_rec, H, sv + L.mean, C, g.dWih, C, nullptr, 0, 1, 0, 0, 0, 0, 0, s));
   RC(colsum(dh_rec, H, d.B, H, g.dbih, 0, s));

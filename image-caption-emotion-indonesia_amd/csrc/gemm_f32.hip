@@ -306,6 +306,16 @@ static int launch_skinny(const float* A, long lda, const float* B, long ldb, flo
   return kOk;
 }
 
+int reduce_slabs(const float* slab, int count, int M, int N, float* out, long ldc, const float* bias,
+                 int accumulate, hipStream_t stream) {
+  CAPNET_REQUIRE(slab && out && count > 0 && M > 0 && N > 0, "reduce_slabs: bad argument");
+  const long total = (long)M * N;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)(cdiv(total, 256) > 2048 ? 2048 : cdiv(total, 256))),
+                     dim3(256), 0, stream, slab, count, M, N, out, ldc, bias, accumulate);
+  CAPNET_LAUNCH_CHECK();
+  return kOk;
+}
+
 // K-split product for M <= 128 rows, optionally batched over `batch` members whose outputs are
 // adjacent column blocks of C (sC == N, bias concatenated); falls back to sgemm otherwise.
 int sgemm_splitk_batched(bool ta, bool tb, int M, int N, int K, const float* A, long lda,

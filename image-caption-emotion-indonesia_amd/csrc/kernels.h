@@ -103,8 +103,11 @@ int argmax_rows(const float* x, int rows, int ld, int V, int* out, hipStream_t s
 int beam_topk(const float* logits, long ld, int rows, int V, const float* prev, int k,
               float* out_scores, long long* out_index, hipStream_t stream);
 int gather_rows(const float* src, const int* idx, float* out, int rows, int C, hipStream_t stream);
-int colsum(const float* x, long ld, int rows, int C, float* out, int accumulate,
-           hipStream_t stream);
+int colsum(const float* x, long ld, int rows, int C, float* out, int accumulate, hipStream_t stream,
+           float* ws = nullptr, size_t ws_floats = 0);
+// out[m][n] = sum_k slab[k][m][n] (+ bias[n]) (+ out[m][n]), fixed order (gemm_f32.hip)
+int reduce_slabs(const float* slab, int count, int M, int N, float* out, long ldc, const float* bias,
+                 int accumulate, hipStream_t stream);
 int scatter_input_grad(const float* dX, long ldx, int N, int E, const int* row_sample, const int* row_col,
                        const int* row_token, float* dEmb, float* dFeat, int V, float p,
                        unsigned long long seed, int use_dropout, hipStream_t stream);

@@ -437,31 +437,60 @@ int gather_prev_rows(const float* src, const int* idx, const float* first, const
 }
 
 // ---- column sums: out[c] (+)= sum_r x[r][c] ------------------------------------------------
-// one workgroup per 64 columns, 4 row lanes; fixed summation order (deterministic).
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, long ld, int rows,
-                                                     int C, float* __restrict__ out,
-                                                     int accumulate) {
-  __shared__ float s[4][64];
-  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cx;
+// Bias gradients. A workgroup owns 32 columns (one 128-B segment per row) and a chunk of rows;
+// its 32 row lanes each keep 8 loads in flight and are summed through LDS in a fixed order
+// (deterministic). With a workspace, long inputs are cut into row chunks whose partial sums are
+// added by the slab reducer of gemm_f32.hip.
+constexpr int kColsumCols = 32, kColsumLanes = 32;
+
+__global__ __launch_bounds__(kColsumCols* kColsumLanes) void colsum_kernel(
+    const float* __restrict__ x, long ld, int rows, int C, int rows_per_chunk,
+    float* __restrict__ out, long out_chunk_stride, int accumulate) {
+  __shared__ float s[kColsumLanes][kColsumCols + 1];
+  const int cx = threadIdx.x % kColsumCols, ry = threadIdx.x / kColsumCols;
+  const int c = blockIdx.x * kColsumCols + cx;
+  const int r0 = blockIdx.y * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
   float acc = 0.f;
-  if (c < C)
-    for (int r = ry; r < rows; r += 4) acc += x[(long)r * ld + c];
+  if (c < C) {
+    for (int r = r0 + ry; r < r1; r += 8 * kColsumLanes) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = x[(long)min(r + u * kColsumLanes, r1 - 1) * ld + c];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += (r + u * kColsumLanes < r1) ? v[u] : 0.f;
+    }
+  }
   s[ry][cx] = acc;
   __syncthreads();
   if (ry == 0 && c < C) {
-    const float t = s[0][cx] + s[1][cx] + s[2][cx] + s[3][cx];
-    out[c] = accumulate ? out[c] + t : t;
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < kColsumLanes; ++k) t += s[k][cx];
+    float* o = out + (long)blockIdx.y * out_chunk_stride + c;
+    *o = accumulate ? *o + t : t;
   }
 }
 
-int colsum(const float* x, long ld, int rows, int C, float* out, int accumulate,
-           hipStream_t stream) {
+int colsum(const float* x, long ld, int rows, int C, float* out, int accumulate, hipStream_t stream,
+           float* ws, size_t ws_floats) {
   CAPNET_REQUIRE(x && out && C > 0 && rows >= 0, "colsum: bad argument");
-  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(C, 64)), dim3(256), 0, stream, x, ld, rows, C, out,
-                     accumulate);
+  int chunks = 1;
+  if (ws && rows > 4096) {
+    chunks = min(32, rows / 1024);
+    if ((size_t)chunks * C > ws_floats) chunks = 1;
+  }
+  const int rpc = chunks > 1 ? cdiv(rows, chunks) : (rows > 0 ? rows : 1);
+  if (chunks > 1) chunks = cdiv(rows, rpc);
+  if (chunks <= 1) {
+    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(C, kColsumCols), 1), dim3(kColsumCols * kColsumLanes), 0,
+                       stream, x, ld, rows, C, rpc, out, 0l, accumulate);
+    CAPNET_LAUNCH_CHECK();
+    return kOk;
+  }
+  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(C, kColsumCols), chunks), dim3(kColsumCols * kColsumLanes),
+                     0, stream, x, ld, rows, C, rpc, ws, (long)C, 0);
   CAPNET_LAUNCH_CHECK();
-  return kOk;
+  return reduce_slabs(ws, chunks, 1, C, out, C, nullptr, accumulate, stream);
 }
 
 // ---- embedding / feature gradient scatter --------------------------------------------------
