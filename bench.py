@@ -41,8 +41,22 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-conv-events", action="store_true",
                     help="do not bracket conv kernels with hipEvents (roofline becomes null)")
+    ap.add_argument("--no-lstm-roofline", action="store_true",
+                    help="skip the LSTM-step microbenchmark (PMC passes profile the train step only)")
     ap.add_argument("--cpu-steps", type=int, default=2)
     return ap.parse_args()
+
+
+def pmc_traffic():
+    """HBM bytes per conv launch from the TCC counters (FETCH_SIZE x2 on gfx950 + WRITE_SIZE),
+    measured offline by tools/pmc_traffic.sh on this same command and committed under profiles/
+    (PMC passes cannot run inside the timed bench). None if the file is absent."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f)["conv_bytes_per_launch"]
+    except Exception:
+        return None
 
 
 def log(msg):
@@ -221,37 +235,45 @@ def main():
         capnet._lib.check(lib.capnet_trunk_collect_timing(plan["handle"], C.byref(ms), C.byref(n), C.byref(fl)))
         if n.value > 0:
             achieved = fl.value / (ms.value * 1e-3) / 1e12
-            roofline = {"bound": "mfma", "kernel": "conv_f32_kernel (implicit-GEMM conv, v_mfma_f32_32x32x2_f32)",
+            roofline = {"bound": "mfma",
+                        "kernel": "conv_f32_v2_kernel (implicit-GEMM conv, v_mfma_f32_32x32x2_f32; each "
+                                  "launch = the conv, its tail fix-up if any; the 7x7 stem is conv_f32_kernel)",
                         "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                        "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": pmc_traffic(),
                         "launches": n.value, "avg_launch_us": round(ms.value * 1e3 / n.value, 2),
                         "flops_per_launch": fl.value / n.value}
 
     # secondary roofline: the recurrent LSTM step (5.77 MB of algorithmic HBM
     # traffic per step at b=64, H=512), timed with events on the launch stream
     lstm = None
-    if rank == 0:
+    if rank == 0 and not args.no_lstm_roofline:
         Hh, bb = 512, 64
         hp = torch.randn(bb, Hh, device=dev) * 0.1
         wc = torch.randn(4 * Hh, Hh, device=dev) * 0.05
         wfrag = torch.empty(lib.capnet_lstm_wfrag_floats(Hh), device=dev)
         capnet._lib.check(lib.capnet_lstm_pack_wfrag(wc.data_ptr(), wfrag.data_ptr(), Hh, 0,
                                                      capnet._lib.current_stream()))
-        gts0 = torch.randn(bb, 4 * Hh, device=dev)
-        cp = torch.randn(bb, Hh, device=dev) * 0.1
-        co, ho, gts = torch.empty_like(cp), torch.empty_like(cp), gts0.clone()
+        # 24 dependent steps (one caption's worth): step i reads h, c of step i-1 and its own rows
+        # of the pre-activation buffer, as in capnet_seq_forward
+        n_steps, n_rep = 24, 20
+        gts = torch.randn(n_steps, bb, 4 * Hh, device=dev)
+        hbuf = [hp, torch.empty_like(hp)]
+        cbuf = [torch.randn(bb, Hh, device=dev) * 0.1, torch.empty(bb, Hh, device=dev)]
         st = capnet._lib.current_stream()
+        step_no = [0]
 
         def lstm_step():
-            capnet._lib.check(lib.capnet_lstm_step_fused(hp.data_ptr(), wfrag.data_ptr(), gts.data_ptr(),
-                                                         4 * Hh, cp.data_ptr(), co.data_ptr(),
-                                                         ho.data_ptr(), bb, Hh, 0, st))
-        for _ in range(5):
+            i = step_no[0] % n_steps
+            step_no[0] += 1
+            capnet._lib.check(lib.capnet_lstm_step_fused(
+                hbuf[i % 2].data_ptr(), wfrag.data_ptr(), gts[i].data_ptr(), 4 * Hh,
+                cbuf[i % 2].data_ptr(), cbuf[(i + 1) % 2].data_ptr(), hbuf[(i + 1) % 2].data_ptr(),
+                bb, Hh, 0, st))
+        for _ in range(n_steps):
             lstm_step()
         torch.cuda.synchronize()
-        # 24 dependent steps (one caption's worth) captured in a hipGraph, so that the host's
-        # ctypes/launch cost (~8 us per call) is not what gets timed
-        n_steps, n_rep = 24, 20
+        # captured in a hipGraph, so that the host's ctypes/launch cost (~8 us per call) is not
+        # what gets timed
         side = torch.cuda.Stream()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.stream(side):

@@ -1,0 +1,53 @@
+"""Per-launch HBM traffic of the conv kernels from the two rocprofv3 --pmc passes of
+tools/pmc_traffic.sh. Corrections per /opt/skills/guides/MI355X_MICROARCH.md (HBM section):
+FETCH_SIZE is reported in KB and counts 64 B per 128-B request on gfx950 for wide coalesced
+reads -> doubled; WRITE_SIZE (KB) is exact for 16-B-per-lane stores.
+
+usage: python tools/pmc_summarize.py gpurun_out/pmc > profiles/round1_pmc_traffic.json
+"""
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def collect(d, counter):
+    path = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+    if not path:
+        raise SystemExit("no counter_collection.csv under " + d)
+    per = {}
+    for r in csv.DictReader(open(path[0])):
+        if r["Counter_Name"] != counter:
+            continue
+        name = r["Kernel_Name"].split("(")[0]
+        a = per.setdefault(name, [0, 0.0])
+        a[0] += 1
+        a[1] += float(r["Counter_Value"])
+    return per
+
+
+def main():
+    root = sys.argv[1]
+    fetch = collect(os.path.join(root, "fetch"), "FETCH_SIZE")
+    write = collect(os.path.join(root, "write"), "WRITE_SIZE")
+    conv = lambda n: "conv_f32" in n or "conv_tail_fixup" in n
+    launches = sum(v[0] for k, v in fetch.items() if "conv_f32" in k)     # fix-ups belong to a conv
+    fetch_kb = sum(v[1] for k, v in fetch.items() if conv(k))
+    write_kb = sum(v[1] for k, v in write.items() if conv(k))
+    out = {
+        "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --steps 2 "
+                   "--warmup 1 --no-cpu-baseline --no-conv-events --no-lstm-roofline",
+        "conv_launches": launches,
+        "fetch_size_kb_raw": fetch_kb,
+        "write_size_kb": write_kb,
+        "conv_bytes_per_launch": round((2.0 * fetch_kb + write_kb) * 1024.0 / max(launches, 1)),
+        "algorithmic_bytes_per_launch": round((232e6 + 2 * 90e6 * 64) / 155),
+        "note": "FETCH_SIZE doubled (gfx950 tallies 128-B read requests at 64 B); per conv launch incl. "
+                "its tail fix-up; algorithmic = (232 MB weights + 2 x 90 MB x 64 activations) / 155 convs",
+    }
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
