@@ -47,14 +47,14 @@ def parse():
     return ap.parse_args()
 
 
-def pmc_traffic():
+def pmc_traffic(key="conv_bytes_per_launch"):
     """HBM bytes per conv launch from the TCC counters (FETCH_SIZE x2 on gfx950 + WRITE_SIZE),
     measured offline by tools/pmc_traffic.sh on this same command and committed under profiles/
     (PMC passes cannot run inside the timed bench). None if the file is absent."""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1_pmc_traffic.json")
     try:
         with open(path) as f:
-            return json.load(f)["conv_bytes_per_launch"]
+            return json.load(f)[key]
     except Exception:
         return None
 
@@ -295,7 +295,8 @@ def main():
         step_bytes = 4 * Hh * Hh * 4 + bb * 4 * Hh * 4 + bb * Hh * 4 * 4 + bb * 4 * Hh * 4
         lstm = {"bound": "hbm", "kernel": "lstm_step_fused_kernel (b=64, H=512; 24 dependent steps replayed from a hipGraph)",
                 "achieved": round(step_bytes / us / 1e3, 1), "peak": 8000.0, "unit": "GB/s",
-                "frac": round(step_bytes / us / 1e3 / 8000.0, 4), "traffic": None,
+                "frac": round(step_bytes / us / 1e3 / 8000.0, 4),
+                "traffic": pmc_traffic("lstm_step_bytes_per_launch"),
                 "bytes_per_step": step_bytes, "us_per_step": round(us, 2)}
 
     if rank == 0:

@@ -35,6 +35,10 @@ def main():
     launches = sum(v[0] for k, v in fetch.items() if "conv_f32" in k)     # fix-ups belong to a conv
     fetch_kb = sum(v[1] for k, v in fetch.items() if conv(k))
     write_kb = sum(v[1] for k, v in write.items() if conv(k))
+    ls = lambda n: "lstm_step_fused_kernel" in n
+    ls_n = sum(v[0] for k, v in fetch.items() if ls(k))
+    ls_bytes = (2.0 * sum(v[1] for k, v in fetch.items() if ls(k)) +
+                sum(v[1] for k, v in write.items() if ls(k))) * 1024.0
     out = {
         "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --steps 2 "
                    "--warmup 1 --no-cpu-baseline --no-conv-events --no-lstm-roofline",
@@ -43,6 +47,8 @@ def main():
         "write_size_kb": write_kb,
         "conv_bytes_per_launch": round((2.0 * fetch_kb + write_kb) * 1024.0 / max(launches, 1)),
         "algorithmic_bytes_per_launch": round((232e6 + 2 * 90e6 * 64) / 155),
+        "lstm_step_launches": ls_n,
+        "lstm_step_bytes_per_launch": round(ls_bytes / max(ls_n, 1)),
         "note": "FETCH_SIZE doubled (gfx950 tallies 128-B read requests at 64 B); per conv launch incl. "
                 "its tail fix-up; algorithmic = (232 MB weights + 2 x 90 MB x 64 activations) / 155 convs",
     }
