@@ -25,6 +25,8 @@ SIGNATURES = {
     "capnet_sgemm_splitk": (_i, [_i, _i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, _vp, _i, _vp, _sz, _vp]),
     "capnet_colsum": (_i, [_vp, _l, _i, _i, _vp, _i, _vp]),
     "capnet_argmax_rows": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "capnet_resize_u8": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp]),
+    "capnet_crop_flip_normalize": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _i, _f, _f, _vp]),
     "capnet_topk_correct": (_i, [_vp, _l, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "capnet_beam_topk": (_i, [_vp, _l, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "capnet_att_step_fwd": (_i, [_vp, _vp, _vp, _vp, _l, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i,

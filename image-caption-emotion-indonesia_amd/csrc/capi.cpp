@@ -314,6 +314,17 @@ int capnet_xent_fwd(const float* logits, long ld, int N, int V, const long long*
                     capnet_stream_t stream) {
   return xent_fwd(logits, ld, N, V, targets, lse, row_loss, loss, err_flag, S(stream));
 }
+int capnet_resize_u8(const unsigned char* src, int Hs, int Ws, unsigned char* tmp, unsigned char* dst,
+                     int Ho, int Wo, const int* bounds_h, const int* coef_h, int kmax_h,
+                     const int* bounds_v, const int* coef_v, int kmax_v, capnet_stream_t stream) {
+  return resize_u8(src, Hs, Ws, tmp, dst, Ho, Wo, bounds_h, coef_h, kmax_h, bounds_v, coef_v, kmax_v,
+                   S(stream));
+}
+int capnet_crop_flip_normalize(const unsigned char* src, int B, int Hs, int Ws, const int* params,
+                               float* dst, int Hc, int Wc, const float* mean, const float* stdv,
+                               capnet_stream_t stream) {
+  return crop_flip_normalize(src, B, Hs, Ws, params, dst, Hc, Wc, mean, stdv, S(stream));
+}
 int capnet_topk_correct(const float* logits, long ld, int N, int V, const long long* targets, int k,
                         int* count, int* err_flag, capnet_stream_t stream) {
   return topk_correct(logits, ld, N, V, targets, k, count, err_flag, S(stream));

@@ -133,6 +133,13 @@ int att_step_bwd(const float* att1, const float* feat, const float* att2, long l
                  float* datt2, long ldz, float* datt1_acc, float* dwf_rows, float* dbf_rows,
                  hipStream_t stream);
 
+// image_ops.hip
+int resize_u8(const unsigned char* src, int Hs, int Ws, unsigned char* tmp, unsigned char* dst, int Ho,
+              int Wo, const int* bounds_h, const int* coef_h, int kmax_h, const int* bounds_v,
+              const int* coef_v, int kmax_v, hipStream_t stream);
+int crop_flip_normalize(const unsigned char* src, int B, int Hs, int Ws, const int* params, float* dst,
+                        int Hc, int Wc, const float* mean, const float* stdv, hipStream_t stream);
+
 // loss_optim.hip
 int xent_fwd(const float* logits, long ld, int N, int V, const long long* targets, float* lse,
              float* row_loss, float* loss, int* err_flag, hipStream_t stream);

@@ -285,6 +285,22 @@ int capnet_xent_bwd(const float* logits, long ld, int N, int V, const long long*
                     const float* lse, const float* grad_out, float* dlogits, long ldd,
                     capnet_stream_t stream);
 
+/* ---- input pipeline (stylenet/train_multitask.py:62-69: Resize((336,336)) -> RandomCrop(224) ->
+ * RandomHorizontalFlip -> ToTensor -> Normalize) on uint8 HWC device images ----------------------
+ * capnet_resize_u8: Pillow's two-pass antialiased resample (what torchvision 0.2.2's Resize calls).
+ * src [Hs][Ws][3], tmp [Hs][Wo][3] scratch, dst [Ho][Wo][3]. bounds_* (device int [out][2] =
+ * {first tap, tap count}) and coef_* (device int [out][kmax], 22-bit fixed point) are the filter
+ * tables of the horizontal / vertical pass, built on the host as Pillow's precompute_coeffs does
+ * (capnet.data.resample_tables); the result is bit-identical to PIL.Image.resize(BILINEAR).
+ * capnet_crop_flip_normalize: src [B][Hs][Ws][3] uint8, params (device int [B][3] = {top, left,
+ * flip}), mean/std host float[3]; dst [B][3][Hc][Wc] fp32 = (u8/255 - mean)/std. */
+int capnet_resize_u8(const unsigned char* src, int Hs, int Ws, unsigned char* tmp, unsigned char* dst,
+                     int Ho, int Wo, const int* bounds_h, const int* coef_h, int kmax_h,
+                     const int* bounds_v, const int* coef_v, int kmax_v, capnet_stream_t stream);
+int capnet_crop_flip_normalize(const unsigned char* src, int B, int Hs, int Ws, const int* params,
+                               float* dst, int Hc, int Wc, const float* mean, const float* stdv,
+                               capnet_stream_t stream);
+
 /* count[0] = number of rows whose target is among the k largest logits of its row -- the numerator
  * of utils.accuracy(scores, targets, k) (stylenet/utils.py:127-140; top-5 in val_factual,
  * train_multitask.py:306). Ties are ranked lower index first. count is overwritten. */

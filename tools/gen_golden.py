@@ -394,6 +394,37 @@ def gen_state_keys():
     print("wrote", path, {k: len(v) for k, v in out.items()})
 
 
+def gen_image_tiny():
+    """Resize fixtures produced by Pillow itself (PIL.Image.resize(BILINEAR), what torchvision 0.2.2's
+    Resize calls) and ToTensor/Normalize produced by torch: smooth + noisy uint8 images, down- and
+    up-scaling, non-square."""
+    from PIL import Image
+    rs = np.random.RandomState(7)
+    arrays, names = {}, []
+    for name, (h, w, oh, ow) in {"down": (100, 75, 48, 48), "up": (37, 53, 48, 48),
+                                 "mixed": (30, 200, 64, 40), "same": (48, 48, 48, 48)}.items():
+        yy, xx = np.mgrid[0:h, 0:w]
+        base = np.stack([127 + 100 * np.sin(xx / 7.0 + c) * np.cos(yy / 5.0) for c in range(3)], -1)
+        img = np.clip(base + rs.randn(h, w, 3) * 25, 0, 255).astype(np.uint8)
+        out = np.asarray(Image.fromarray(img).resize((ow, oh), Image.BILINEAR))
+        arrays["resize.%s.in" % name] = img
+        arrays["resize.%s.out" % name] = out
+        names.append(name)
+    arrays["resize_cases"] = np.array(names)
+    # ToTensor + Normalize (torch arithmetic) on a crop with and without flip
+    img = arrays["resize.down.out"]
+    mean, std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+    for tag, (top, left, flip) in {"a": (3, 9, 0), "b": (16, 0, 1)}.items():
+        c = img[top:top + 32, left:left + 32, :]
+        if flip:
+            c = c[:, ::-1, :]
+        t = torch.from_numpy(np.ascontiguousarray(c)).permute(2, 0, 1).float().div(255)
+        t = t.sub(torch.tensor(mean).view(3, 1, 1)).div(torch.tensor(std).view(3, 1, 1))
+        arrays["norm.%s.params" % tag] = np.array([top, left, flip])
+        arrays["norm.%s.out" % tag] = t.numpy()
+    save("image_tiny.npz", arrays)
+
+
 class legacy_int_division:
     """torch 1.1 (the version the reference pins) divided integer tensors with integer results;
     `top_k_words / self.vocab_size` at stylenet/model.py:249 relies on it. Current torch returns a
@@ -513,6 +544,8 @@ if __name__ == "__main__":
         gen_att_tiny()
     if "sample_tiny" in which:
         gen_sample_tiny()
+    if "image_tiny" in which:
+        gen_image_tiny()
     if "state_keys" in which:
         gen_state_keys()
     if "nic_att_tiny" in which:
