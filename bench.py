@@ -144,7 +144,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
-    if world > 1:
+    if world > 1 or os.environ.get("CAPNET_FORCE_ALLREDUCE") == "1":
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
 
@@ -198,7 +198,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -224,7 +224,7 @@ def main():
     log("timed region: %.3f s" % elapsed)
     lib.capnet_trunk_set_timing(plan["handle"], 0)
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    if dist.is_initialized():
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
     ops.check_device_errors()
@@ -332,7 +332,7 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

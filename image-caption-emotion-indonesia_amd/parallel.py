@@ -15,6 +15,8 @@ hide behind that step's ResNet-152 forward, which does not depend on the update.
 """
 import random
 
+import os
+
 import torch
 
 from . import ops
@@ -66,7 +68,10 @@ class DataParallelAdam(Adam):
         super().__init__(params, lr=lr, betas=betas, eps=eps)
         import torch.distributed as dist
         self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
-        self.reducer = GradAllReducer(process_group) if self.world_size > 1 else None
+        # CAPNET_FORCE_ALLREDUCE=1: run the pack / all-reduce / unpack path on a single rank too
+        # (rehearsal of the multi-GPU path on a one-GPU box)
+        force = dist.is_initialized() and os.environ.get("CAPNET_FORCE_ALLREDUCE") == "1"
+        self.reducer = GradAllReducer(process_group) if (self.world_size > 1 or force) else None
         self.overlap = overlap
         self.side = torch.cuda.Stream() if overlap else None
         self.update_done = None
