@@ -30,7 +30,7 @@ SIGNATURES = {
     "capnet_topk_correct": (_i, [_vp, _l, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "capnet_beam_topk": (_i, [_vp, _l, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "capnet_att_step_fwd": (_i, [_vp, _vp, _vp, _vp, _l, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i,
-                                 _vp, _vp, _l, _vp]),
+                                 _vp, _vp, _l, _vp, _vp]),
     "capnet_trunk_create": (_i, [_i, _i, _i, C.POINTER(_vp)]),
     "capnet_trunk_destroy": (None, [_vp]),
     "capnet_trunk_workspace_bytes": (_sz, [_vp]),

@@ -19,75 +19,108 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-// ---- forward 1: scores + softmax ------------------------------------------------------
-// grid = rows of the step. att1 [B][P][A] (indexed by sample), att2 rows at ld `ldz`.
-// alpha_out: packed [N][P] row r; alphas_bt: [B][steps][P] user-visible tensor (row (j, t)).
+// ---- forward 1: raw scores ----------------------------------------------------------------
+// grid = (rows of the step, kScoreChunks pixel chunks): 256 workgroups at b = 64 instead of 64.
+// att1 [B][P][A] (indexed by sample), att2 rows at ld `ldz`. escore [rows][P]: e before softmax.
+constexpr int kScoreChunks = 4;
+
 __global__ __launch_bounds__(kAttThreads) void att_scores_fwd_kernel(
     const float* __restrict__ att1, const float* __restrict__ att2, long ldz,
     const float* __restrict__ wf, const float* __restrict__ bf, int P, int A,
-    float* __restrict__ alpha_out, float* __restrict__ alphas_bt, int steps, int t) {
-  extern __shared__ float sh[];  // e[P]
-  __shared__ float red[8];
+    float* __restrict__ escore) {
   const int j = blockIdx.x;      // row inside the step == sample index
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int pc = (P + kScoreChunks - 1) / kScoreChunks;
+  const int p0 = blockIdx.y * pc, p1 = min(P, p0 + pc);
   const float* a1 = att1 + (long)j * P * A;
   const float* a2 = att2 + (long)j * ldz;
-  for (int p = wave; p < P; p += kAttThreads / 64) {
-    float s = 0.f;
+  const float b0 = bf[0];
+  // a wave takes 4 pixels at a time (4 x A/256 independent 16-B loads in flight per lane)
+  for (int p = p0 + 4 * wave; p < p1; p += 4 * (kAttThreads / 64)) {
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
     for (int a = lane * 4; a < A; a += 256) {
-      const float4 x = *reinterpret_cast<const float4*>(a1 + (long)p * A + a);
       const float4 y = *reinterpret_cast<const float4*>(a2 + a);
       const float4 w = *reinterpret_cast<const float4*>(wf + a);
-      s = fmaf(fmaxf(x.x + y.x, 0.f), w.x, s);
-      s = fmaf(fmaxf(x.y + y.y, 0.f), w.y, s);
-      s = fmaf(fmaxf(x.z + y.z, 0.f), w.z, s);
-      s = fmaf(fmaxf(x.w + y.w, 0.f), w.w, s);
+      float4 x[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        x[u] = *reinterpret_cast<const float4*>(a1 + (long)min(p + u, p1 - 1) * A + a);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        s[u] = fmaf(fmaxf(x[u].x + y.x, 0.f), w.x, s[u]);
+        s[u] = fmaf(fmaxf(x[u].y + y.y, 0.f), w.y, s[u]);
+        s[u] = fmaf(fmaxf(x[u].z + y.z, 0.f), w.z, s[u]);
+        s[u] = fmaf(fmaxf(x[u].w + y.w, 0.f), w.w, s[u]);
+      }
     }
-    s = wave_sum(s);
-    if (lane == 0) sh[p] = s + bf[0];
-  }
-  __syncthreads();
-  float m = -INFINITY;
-  for (int p = threadIdx.x; p < P; p += kAttThreads) m = fmaxf(m, sh[p]);
-  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-  if (lane == 0) red[wave] = m;
-  __syncthreads();
-  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-  float z = 0.f;
-  for (int p = threadIdx.x; p < P; p += kAttThreads) {
-    const float e = expf(sh[p] - m);
-    sh[p] = e;
-    z += e;
-  }
-  z = wave_sum(z);
-  if (lane == 0) red[4 + wave] = z;
-  __syncthreads();
-  z = red[4] + red[5] + red[6] + red[7];
-  const float inv = 1.f / z;
-  for (int p = threadIdx.x; p < P; p += kAttThreads) {
-    const float al = sh[p] * inv;
-    alpha_out[(long)j * P + p] = al;
-    alphas_bt[((long)j * steps + t) * P + p] = al;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float t = wave_sum(s[u]);
+      if (lane == 0 && p + u < p1) escore[(long)j * P + p + u] = t + b0;
+    }
   }
 }
 
-// ---- forward 2: context vector + gate ------------------------------------------------------
-// grid = (rows, C/512); 128 threads x float4. gate_io: in = f_beta(h) pre-activation (ld ldz),
-// out = sigmoid of it (saved for backward). awe_out [rows][C] (pre-gate, saved), xa_out: the
-// decoder input slice (ld ldx) = gate * awe.
+// ---- forward 2: softmax + context vector + gate ----------------------------------------------
+// grid = (rows, C/512); 128 threads x float4. Every workgroup of a row recomputes the row's
+// softmax over P from the raw scores (P is a few hundred values); workgroup y = 0 stores alpha
+// (packed [N][P] row) and the user-visible alphas_bt [B][steps][P] row (j, t).
+// gate_io: in = f_beta(h) pre-activation (ld ldz), out = sigmoid of it (saved for backward).
+// awe_out [rows][C] (pre-gate, saved), xa_out: the decoder input slice (ld ldx) = gate * awe.
 __global__ __launch_bounds__(128) void att_context_fwd_kernel(
-    const float* __restrict__ feat, const float* __restrict__ alpha, int P, int C,
-    float* __restrict__ gate_io, long ldz, float* __restrict__ awe_out,
+    const float* __restrict__ feat, const float* __restrict__ escore, int P, int C,
+    float* __restrict__ gate_io, long ldz, float* __restrict__ alpha_out,
+    float* __restrict__ alphas_bt, int steps, int t, float* __restrict__ awe_out,
     float* __restrict__ xa_out, long ldx) {
   extern __shared__ float al[];  // alpha[P]
+  __shared__ float red[4];
   const int j = blockIdx.x;
-  const int c = blockIdx.y * 512 + threadIdx.x * 4;
-  for (int p = threadIdx.x; p < P; p += 128) al[p] = alpha[(long)j * P + p];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float m = -INFINITY;
+  for (int p = threadIdx.x; p < P; p += 128) {
+    const float e = escore[(long)j * P + p];
+    al[p] = e;
+    m = fmaxf(m, e);
+  }
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if (lane == 0) red[wave] = m;
   __syncthreads();
+  m = fmaxf(red[0], red[1]);
+  float z = 0.f;
+  for (int p = threadIdx.x; p < P; p += 128) {
+    const float e = expf(al[p] - m);
+    al[p] = e;
+    z += e;
+  }
+  z = wave_sum(z);
+  if (lane == 0) red[2 + wave] = z;
+  __syncthreads();
+  const float inv = 1.f / (red[2] + red[3]);
+  for (int p = threadIdx.x; p < P; p += 128) {
+    const float a = al[p] * inv;
+    al[p] = a;
+    if (blockIdx.y == 0) {
+      alpha_out[(long)j * P + p] = a;
+      alphas_bt[((long)j * steps + t) * P + p] = a;
+    }
+  }
+  __syncthreads();
+  const int c = blockIdx.y * 512 + threadIdx.x * 4;
   const float* f = feat + (long)j * P * C + c;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 4
-  for (int p = 0; p < P; ++p) {
+  int p = 0;
+  for (; p + 14 <= P; p += 14) {   // 14 independent 16-B loads in flight per lane
+    float4 v[14];
+#pragma unroll
+    for (int u = 0; u < 14; ++u) v[u] = *reinterpret_cast<const float4*>(f + (long)(p + u) * C);
+#pragma unroll
+    for (int u = 0; u < 14; ++u) {
+      const float a = al[p + u];
+      s.x = fmaf(a, v[u].x, s.x); s.y = fmaf(a, v[u].y, s.y);
+      s.z = fmaf(a, v[u].z, s.z); s.w = fmaf(a, v[u].w, s.w);
+    }
+  }
+  for (; p < P; ++p) {
     const float4 v = *reinterpret_cast<const float4*>(f + (long)p * C);
     const float a = al[p];
     s.x = fmaf(a, v.x, s.x); s.y = fmaf(a, v.y, s.y); s.z = fmaf(a, v.z, s.z); s.w = fmaf(a, v.w, s.w);
@@ -105,24 +138,25 @@ __global__ __launch_bounds__(128) void att_context_fwd_kernel(
 int att_step_fwd(const float* att1, const float* feat, const float* att2, float* gate_io, long ldz,
                  const float* wf, const float* bf, int rows, int P, int A, int C,
                  float* alpha_out, float* alphas_bt, int steps, int t, float* awe_out,
-                 float* xa_out, long ldx, hipStream_t stream) {
+                 float* xa_out, long ldx, float* escore, hipStream_t stream) {
   if (rows <= 0) return kOk;
   CAPNET_REQUIRE(att1 && feat && att2 && gate_io && wf && bf && alpha_out && alphas_bt && awe_out &&
-                     xa_out, "att_step_fwd: null argument");
+                     xa_out && escore, "att_step_fwd: null argument");
   CAPNET_REQUIRE(A % 4 == 0 && C % 512 == 0 && P > 0 && P <= 4096 && ldz % 4 == 0 && ldx % 4 == 0,
                  "att_step_fwd: A=%d C=%d P=%d (need A%%4==0, C%%512==0)", A, C, P);
-  hipLaunchKernelGGL(att_scores_fwd_kernel, dim3(rows), dim3(kAttThreads), P * sizeof(float), stream,
-                     att1, att2, ldz, wf, bf, P, A, alpha_out, alphas_bt, steps, t);
+  hipLaunchKernelGGL(att_scores_fwd_kernel, dim3(rows, kScoreChunks), dim3(kAttThreads), 0, stream,
+                     att1, att2, ldz, wf, bf, P, A, escore);
   hipLaunchKernelGGL(att_context_fwd_kernel, dim3(rows, C / 512), dim3(128), P * sizeof(float),
-                     stream, feat, alpha_out, P, C, gate_io, ldz, awe_out, xa_out, ldx);
+                     stream, feat, escore, P, C, gate_io, ldz, alpha_out, alphas_bt, steps, t, awe_out,
+                     xa_out, ldx);
   CAPNET_LAUNCH_CHECK();
   return kOk;
 }
 
 // ---- backward 1: gate and d(alpha) partials -----------------------------------------------
-// grid = (rows, C/512), 256 threads = 4 waves; a wave owns a pixel at a time, its lanes 512
-// channels (2 x float4). dxa: gradient of the gated context (ld ldx). Outputs:
-//   dgate_out (ld ldz) = d f_beta pre-activation; dalpha_part [rows][C/512][P].
+// grid = (rows, C/512), 256 threads = 4 waves; a wave owns 7 pixels at a time (14 independent
+// 16-B loads in flight), its lanes 512 channels (2 x float4). dxa: gradient of the gated context
+// (ld ldx). Outputs: dgate_out (ld ldz) = d f_beta pre-activation; dalpha_part [rows][C/512][P].
 __global__ __launch_bounds__(kAttThreads) void att_context_bwd_kernel(
     const float* __restrict__ feat, const float* __restrict__ dxa, long ldx,
     const float* __restrict__ gate, long ldzg, const float* __restrict__ awe, int P, int C,
@@ -143,26 +177,41 @@ __global__ __launch_bounds__(kAttThreads) void att_context_bwd_kernel(
     }
   }
   const float* f = feat + (long)j * P * C + c;
-  for (int p = wave; p < P; p += kAttThreads / 64) {
-    const float4 v0 = *reinterpret_cast<const float4*>(f + (long)p * C);
-    const float4 v1 = *reinterpret_cast<const float4*>(f + (long)p * C + 4);
-    float s = d[0] * v0.x + d[1] * v0.y + d[2] * v0.z + d[3] * v0.w + d[4] * v1.x + d[5] * v1.y +
-              d[6] * v1.z + d[7] * v1.w;
-    s = wave_sum(s);
-    if (lane == 0) dalpha_part[((long)j * gridDim.y + cb) * P + p] = s;
+  constexpr int U = 7;
+  for (int p = U * wave; p < P; p += U * (kAttThreads / 64)) {
+    float4 v0[U], v1[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long pp = min(p + u, P - 1);
+      v0[u] = *reinterpret_cast<const float4*>(f + pp * C);
+      v1[u] = *reinterpret_cast<const float4*>(f + pp * C + 4);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float s = d[0] * v0[u].x + d[1] * v0[u].y + d[2] * v0[u].z + d[3] * v0[u].w + d[4] * v1[u].x +
+                d[5] * v1[u].y + d[6] * v1[u].z + d[7] * v1[u].w;
+      s = wave_sum(s);
+      if (lane == 0 && p + u < P) dalpha_part[((long)j * gridDim.y + cb) * P + p + u] = s;
+    }
   }
 }
 
-// ---- backward 2: softmax, relu, full_att / decoder_att / encoder_att gradients --------------
-// grid = rows. dalphas_bt: gradient of the user-visible alphas tensor [B][steps][P] (may be null).
-// Outputs: datt2 (ld ldz), datt1_acc [B][P][A] += , dwf_rows [rows][A], dbf_rows [rows].
+// ---- backward 2: softmax, relu, full_att / decoder_att gradients ---------------------------
+// grid = (rows, A/128): a workgroup owns 128 attention channels of a row (lane = 2 channels),
+// its 4 waves sweep the pixels 7 at a time. Every workgroup of a row recomputes d e = softmax
+// backward over P (a few hundred values); workgroup y = 0 stores it (de_out [rows][P], read after
+// the time loop by att_datt1_kernel) and the full_att bias gradient.
+// dalphas_bt: gradient of the user-visible alphas tensor [B][steps][P] (may be null).
+// Outputs: datt2 (ld ldz), dwf_rows [rows][A], dbf_rows [rows], de_out.
+constexpr int kScoreBwdCh = 128;
+
 __global__ __launch_bounds__(kAttThreads) void att_scores_bwd_kernel(
     const float* __restrict__ att1, const float* __restrict__ att2, long ldz2,
     const float* __restrict__ wf, const float* __restrict__ alpha,
     const float* __restrict__ dalpha_part, int nparts, const float* __restrict__ dalphas_bt,
     int steps, int t, int P, int A, float* __restrict__ datt2, long ldz,
-    float* __restrict__ datt1_acc, float* __restrict__ dwf_rows, float* __restrict__ dbf_rows) {
-  extern __shared__ float sh[];  // de[P], then cross-wave scratch [4][A] x 2
+    float* __restrict__ de_out, float* __restrict__ dwf_rows, float* __restrict__ dbf_rows) {
+  extern __shared__ float sh[];  // de[P], then cross-wave scratch [4][128] x 2
   __shared__ float red[4];
   const int j = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -183,43 +232,50 @@ __global__ __launch_bounds__(kAttThreads) void att_scores_bwd_kernel(
     const float v = alpha[(long)j * P + p] * (de[p] - dot);
     de[p] = v;
     dbf += v;
+    if (blockIdx.y == 0) de_out[(long)j * P + p] = v;
   }
   __syncthreads();
   dbf = wave_sum(dbf);
   if (lane == 0) red[wave] = dbf;
   __syncthreads();
-  if (threadIdx.x == 0) dbf_rows[j] = red[0] + red[1] + red[2] + red[3];
+  if (threadIdx.x == 0 && blockIdx.y == 0) dbf_rows[j] = red[0] + red[1] + red[2] + red[3];
 
-  // each wave sweeps pixels wave, wave+4, ...; lanes own channels a = lane*4 + 256*i
-  const float* a1 = att1 + (long)j * P * A;
-  const float* a2 = att2 + (long)j * ldz2;
-  float* d1 = datt1_acc + (long)j * P * A;
-  float* s_d2 = sh + P;           // [4][A]
-  float* s_dw = sh + P + 4 * A;   // [4][A]
-  for (int a0 = lane * 4; a0 < A; a0 += 256) {
-    const float4 y = *reinterpret_cast<const float4*>(a2 + a0);
-    const float4 w = *reinterpret_cast<const float4*>(wf + a0);
-    float4 g2 = make_float4(0.f, 0.f, 0.f, 0.f), gw = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int p = wave; p < P; p += kAttThreads / 64) {
-      const float e = de[p];
-      const float4 x = *reinterpret_cast<const float4*>(a1 + (long)p * A + a0);
-      float4 acc = *reinterpret_cast<const float4*>(d1 + (long)p * A + a0);
-      const float z0 = x.x + y.x, z1 = x.y + y.y, z2 = x.z + y.z, z3 = x.w + y.w;
-      const float q0 = z0 > 0.f ? e * w.x : 0.f, q1 = z1 > 0.f ? e * w.y : 0.f;
-      const float q2 = z2 > 0.f ? e * w.z : 0.f, q3 = z3 > 0.f ? e * w.w : 0.f;
-      acc.x += q0; acc.y += q1; acc.z += q2; acc.w += q3;
-      *reinterpret_cast<float4*>(d1 + (long)p * A + a0) = acc;
-      g2.x += q0; g2.y += q1; g2.z += q2; g2.w += q3;
-      gw.x = fmaf(e, fmaxf(z0, 0.f), gw.x); gw.y = fmaf(e, fmaxf(z1, 0.f), gw.y);
-      gw.z = fmaf(e, fmaxf(z2, 0.f), gw.z); gw.w = fmaf(e, fmaxf(z3, 0.f), gw.w);
+  const int a0 = blockIdx.y * kScoreBwdCh + lane * 2;
+  float* s_d2 = sh + P;                    // [4][128]
+  float* s_dw = sh + P + 4 * kScoreBwdCh;  // [4][128]
+  float2 g2 = make_float2(0.f, 0.f), gw = make_float2(0.f, 0.f);
+  if (a0 < A) {
+    const float* a1 = att1 + (long)j * P * A + a0;
+    const float2 y = *reinterpret_cast<const float2*>(att2 + (long)j * ldz2 + a0);
+    const float2 w = *reinterpret_cast<const float2*>(wf + a0);
+    constexpr int U = 7;
+    for (int p = U * wave; p < P; p += U * (kAttThreads / 64)) {
+      float2 x[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        x[u] = *reinterpret_cast<const float2*>(a1 + (long)min(p + u, P - 1) * A);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const float e = p + u < P ? de[p + u] : 0.f;
+        const float z0 = x[u].x + y.x, z1 = x[u].y + y.y;
+        g2.x += z0 > 0.f ? e * w.x : 0.f;
+        g2.y += z1 > 0.f ? e * w.y : 0.f;
+        gw.x = fmaf(e, fmaxf(z0, 0.f), gw.x);
+        gw.y = fmaf(e, fmaxf(z1, 0.f), gw.y);
+      }
     }
-    *reinterpret_cast<float4*>(s_d2 + wave * A + a0) = g2;
-    *reinterpret_cast<float4*>(s_dw + wave * A + a0) = gw;
   }
+  *reinterpret_cast<float2*>(s_d2 + wave * kScoreBwdCh + lane * 2) = g2;
+  *reinterpret_cast<float2*>(s_dw + wave * kScoreBwdCh + lane * 2) = gw;
   __syncthreads();
-  for (int a = threadIdx.x; a < A; a += kAttThreads) {
-    datt2[(long)j * ldz + a] = s_d2[a] + s_d2[A + a] + s_d2[2 * A + a] + s_d2[3 * A + a];
-    dwf_rows[(long)j * A + a] = s_dw[a] + s_dw[A + a] + s_dw[2 * A + a] + s_dw[3 * A + a];
+  for (int k = threadIdx.x; k < kScoreBwdCh; k += kAttThreads) {
+    const int a = blockIdx.y * kScoreBwdCh + k;
+    if (a < A) {
+      datt2[(long)j * ldz + a] = s_d2[k] + s_d2[kScoreBwdCh + k] + s_d2[2 * kScoreBwdCh + k] +
+                                 s_d2[3 * kScoreBwdCh + k];
+      dwf_rows[(long)j * A + a] = s_dw[k] + s_dw[kScoreBwdCh + k] + s_dw[2 * kScoreBwdCh + k] +
+                                  s_dw[3 * kScoreBwdCh + k];
+    }
   }
 }
 
@@ -227,21 +283,98 @@ int att_step_bwd(const float* att1, const float* feat, const float* att2, long l
                  const float* gate, long ldzg, const float* awe, const float* alpha,
                  const float* wf, const float* dxa, long ldx, const float* dalphas_bt, int steps,
                  int t, int rows, int P, int A, int C, float* dalpha_part, float* dgate_out,
-                 float* datt2, long ldz, float* datt1_acc, float* dwf_rows, float* dbf_rows,
+                 float* datt2, long ldz, float* de_out, float* dwf_rows, float* dbf_rows,
                  hipStream_t stream) {
   if (rows <= 0) return kOk;
   CAPNET_REQUIRE(att1 && feat && att2 && gate && awe && alpha && wf && dxa && dalpha_part &&
-                     dgate_out && datt2 && datt1_acc && dwf_rows && dbf_rows,
+                     dgate_out && datt2 && de_out && dwf_rows && dbf_rows,
                  "att_step_bwd: null argument");
-  CAPNET_REQUIRE(A % 4 == 0 && C % 512 == 0 && P > 0 && ldz % 4 == 0 && ldx % 4 == 0 &&
-                     (size_t)(P + 8 * A) * 4 <= 64 * 1024,
+  CAPNET_REQUIRE(A % 4 == 0 && C % 512 == 0 && P > 0 && ldz % 4 == 0 && ldx % 4 == 0 && ldz2 % 2 == 0 &&
+                     (size_t)(P + 8 * kScoreBwdCh) * 4 <= 64 * 1024,
                  "att_step_bwd: A=%d C=%d P=%d", A, C, P);
   // gate rows use their own leading dimension (saved forward Z buffer)
   hipLaunchKernelGGL(att_context_bwd_kernel, dim3(rows, C / 512), dim3(kAttThreads), 0, stream, feat,
                      dxa, ldx, gate, ldzg, awe, P, C, dgate_out, ldz, dalpha_part);
-  hipLaunchKernelGGL(att_scores_bwd_kernel, dim3(rows), dim3(kAttThreads),
-                     (P + 8 * A) * sizeof(float), stream, att1, att2, ldz2, wf, alpha, dalpha_part,
-                     C / 512, dalphas_bt, steps, t, P, A, datt2, ldz, datt1_acc, dwf_rows, dbf_rows);
+  hipLaunchKernelGGL(att_scores_bwd_kernel, dim3(rows, cdiv(A, kScoreBwdCh)), dim3(kAttThreads),
+                     (P + 8 * kScoreBwdCh) * sizeof(float), stream, att1, att2, ldz2, wf, alpha,
+                     dalpha_part, C / 512, dalphas_bt, steps, t, P, A, datt2, ldz, de_out, dwf_rows,
+                     dbf_rows);
+  CAPNET_LAUNCH_CHECK();
+  return kOk;
+}
+
+// ---- after the time loop: gradient of att1 = encoder_att(features) ---------------------------
+//   d att1[b][p][a] = w_full[a] * sum_t de[row(b,t)][p] * [att1[b][p][a] + att2[row(b,t)][a] > 0]
+// One pass over att1 (read once, d att1 written once) instead of a read-modify-write of the
+// whole [B][P][A] tensor in every step of the BPTT loop. grid = (B, pixel chunks), 128 threads,
+// lane = 4 channels at a time; the sample's att2 rows and de rows sit in LDS.
+struct AttRowTable { int off[kMaxSteps + 1]; int steps; };
+constexpr int kDatt1Pix = 14;
+
+__global__ __launch_bounds__(128) void att_datt1_kernel(
+    const float* __restrict__ att1, const float* __restrict__ att2_rows, long ldz2,
+    const float* __restrict__ de_rows, const float* __restrict__ wf, AttRowTable rt, int P, int A,
+    int t_chunk, float* __restrict__ datt1) {
+  extern __shared__ float sh[];  // att2 [t_chunk][A] then de [t_chunk][kDatt1Pix]
+  const int b = blockIdx.x;
+  const int p0 = blockIdx.y * kDatt1Pix, np = min(kDatt1Pix, P - p0);
+  int T = 0;  // steps in which sample b is alive: rows off[t] + b while b < batch size of step t
+  while (T < rt.steps && b < rt.off[T + 1] - rt.off[T]) ++T;
+  float* s_a2 = sh;
+  float* s_de = sh + (size_t)t_chunk * A;
+  // t_chunk covers every step unless the sequence is unusually long (then later chunks add)
+  for (int t0 = 0; t0 == 0 || t0 < T; t0 += t_chunk) {
+    const int tc = max(0, min(t_chunk, T - t0));
+    __syncthreads();
+    for (int i = threadIdx.x; i < tc * (A / 4); i += 128) {
+      const int t = i / (A / 4), a4 = i - t * (A / 4);
+      *reinterpret_cast<float4*>(s_a2 + (size_t)t * A + 4 * a4) =
+          *reinterpret_cast<const float4*>(att2_rows + (long)(rt.off[t0 + t] + b) * ldz2 + 4 * a4);
+    }
+    for (int i = threadIdx.x; i < tc * kDatt1Pix; i += 128) {
+      const int t = i / kDatt1Pix, q = i - t * kDatt1Pix;
+      s_de[i] = q < np ? de_rows[(long)(rt.off[t0 + t] + b) * P + p0 + q] : 0.f;
+    }
+    __syncthreads();
+    for (int a = threadIdx.x * 4; a < A; a += 512) {
+      const float4 w = *reinterpret_cast<const float4*>(wf + a);
+      for (int q = 0; q < np; ++q) {
+        const long idx = ((long)b * P + p0 + q) * A + a;
+        const float4 x = *reinterpret_cast<const float4*>(att1 + idx);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int t = 0; t < tc; ++t) {
+          const float e = s_de[t * kDatt1Pix + q];
+          const float4 y = *reinterpret_cast<const float4*>(s_a2 + (size_t)t * A + a);
+          acc.x += x.x + y.x > 0.f ? e : 0.f;
+          acc.y += x.y + y.y > 0.f ? e : 0.f;
+          acc.z += x.z + y.z > 0.f ? e : 0.f;
+          acc.w += x.w + y.w > 0.f ? e : 0.f;
+        }
+        acc.x *= w.x; acc.y *= w.y; acc.z *= w.z; acc.w *= w.w;
+        if (t0 > 0) {
+          const float4 prev = *reinterpret_cast<const float4*>(datt1 + idx);
+          acc.x += prev.x; acc.y += prev.y; acc.z += prev.z; acc.w += prev.w;
+        }
+        *reinterpret_cast<float4*>(datt1 + idx) = acc;
+      }
+    }
+  }
+}
+
+int att_datt1(const float* att1, const float* att2_rows, long ldz2, const float* de_rows,
+              const float* wf, const int* off, int steps, int B, int P, int A, float* datt1,
+              hipStream_t stream) {
+  CAPNET_REQUIRE(att1 && att2_rows && de_rows && wf && off && datt1, "att_datt1: null argument");
+  CAPNET_REQUIRE(steps > 0 && steps <= kMaxSteps && A % 4 == 0 && ldz2 % 4 == 0, "att_datt1: bad argument");
+  AttRowTable rt;
+  rt.steps = steps;
+  for (int t = 0; t <= steps; ++t) rt.off[t] = off[t];
+  int t_chunk = (int)((60 * 1024) / ((size_t)(A + kDatt1Pix) * sizeof(float)));
+  CAPNET_REQUIRE(t_chunk >= 1, "att_datt1: A=%d too large", A);
+  if (t_chunk > steps) t_chunk = steps;
+  const size_t lds = (size_t)t_chunk * (A + kDatt1Pix) * sizeof(float);
+  hipLaunchKernelGGL(att_datt1_kernel, dim3(B, cdiv(P, kDatt1Pix)), dim3(128), lds, stream, att1,
+                     att2_rows, ldz2, de_rows, wf, rt, P, A, t_chunk, datt1);
   CAPNET_LAUNCH_CHECK();
   return kOk;
 }

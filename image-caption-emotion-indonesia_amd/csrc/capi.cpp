@@ -271,10 +271,10 @@ int capnet_beam_topk(const float* logits, long ld, int rows, int V, const float*
 int capnet_att_step_fwd(const float* att1, const float* feat, const float* att2, float* gate_io,
                         long ldz, const float* w_full, const float* b_full, int rows, int P, int A,
                         int C, float* alpha_out, float* alphas_bt, int steps, int t, float* awe_out,
-                        float* xa_out, long ldx, capnet_stream_t stream) {
+                        float* xa_out, long ldx, float* scores_ws, capnet_stream_t stream) {
   CAPNET_REQUIRE(steps > 0 && t >= 0 && t < steps, "att_step_fwd: t=%d steps=%d", t, steps);
   return att_step_fwd(att1, feat, att2, gate_io, ldz, w_full, b_full, rows, P, A, C, alpha_out,
-                      alphas_bt, steps, t, awe_out, xa_out, ldx, S(stream));
+                      alphas_bt, steps, t, awe_out, xa_out, ldx, scores_ws, S(stream));
 }
 int capnet_att_seq_forward(const int* dims, const int* batch_sizes, const unsigned char* tf_mask,
                            const long long* captions, const float* features, const float* emb,

@@ -105,12 +105,14 @@ int cpy(float* dst, const float* src, size_t n, hipStream_t s) {
 
 size_t att_saved_floats(const AttDims& d) { return make_alayout(d).total; }
 size_t att_saved_ints(const AttDims& d) { return make_alayout(d).itotal; }
-size_t att_fwd_scratch_floats(const AttDims& d) { return (size_t)d.B * d.V + 64 + kAttSplitKFloats; }
+size_t att_fwd_scratch_floats(const AttDims& d) {
+  return (size_t)d.B * d.V + 64 + kAttSplitKFloats + (size_t)d.B * d.P + 64;
+}
 size_t att_bwd_scratch_floats(const AttDims& d) {
   const ALayout L = make_alayout(d);
   const size_t N = d.N;
   return N * L.ZW + 2 * (d.cell == kCellFactored ? N * 4 * d.F : 8) + N * L.XW + N * d.H + 2 * (size_t)d.B * d.H +
-         (size_t)d.B * (d.C / 512) * d.P + (size_t)d.B * d.P * d.A + N * d.A + N + 4096 +
+         (size_t)d.B * (d.C / 512) * d.P + (size_t)d.B * d.P * d.A + N * d.A + N + N * d.P + 4096 +
          kAttSplitKFloats;
 }
 
@@ -176,6 +178,7 @@ int att_seq_forward(const AttDims& d, const int* bs, const unsigned char* tf,
                    training && dropout_p > 0.f, 0, err_flag, s));
 
   float* skws = scratch + (size_t)d.B * d.V + 64;
+  float* escore = skws + kAttSplitKFloats;   // raw attention scores of the current step [b][P]
   for (int t = 0; t < d.steps; ++t) {
     const int b = bs[t], r0 = off[t];
     const float* hprev = t > 0 ? hiddens + (size_t)off[t - 1] * H : sv + L.h0;
@@ -186,7 +189,7 @@ int att_seq_forward(const AttDims& d, const int* bs, const unsigned char* tf,
                     kAttSplitKFloats, s));
     RC(att_step_fwd(sv + L.att1, feat, Z + 4 * H, Z + 4 * H + A, ZW, w.full_att_w, w.full_att_b, b, P,
                     A, C, sv + L.alpha + (size_t)r0 * P, alphas_bt, d.steps, t,
-                    sv + L.awe + (size_t)r0 * C, sv + L.XA + (size_t)r0 * XW + E, XW, s));
+                    sv + L.awe + (size_t)r0 * C, sv + L.XA + (size_t)r0 * XW + E, XW, escore, s));
     if (t > 0 && !tf[t]) {
       RC(sgemm_splitk(false, true, b, d.V, H, hprev, H, Cw, H, scratch, d.V, Cb, 0, skws,
                       kAttSplitKFloats, s));
@@ -245,10 +248,10 @@ int att_seq_backward(const AttDims& d, const int* bs, const float* dH, const flo
   float* datt1 = scratch + take((size_t)d.B * P * A);
   float* dwf_rows = scratch + take((size_t)N * A);
   float* dbf_rows = scratch + take((size_t)N);
+  float* de_all = scratch + take((size_t)N * P);   // softmax-backward scores of every row
   float* skws = scratch + take(kAttSplitKFloats);
   CAPNET_HIP_CHECK(hipMemsetAsync(dh_rec, 0, (size_t)d.B * H * sizeof(float), s));
   CAPNET_HIP_CHECK(hipMemsetAsync(dc, 0, (size_t)d.B * H * sizeof(float), s));
-  CAPNET_HIP_CHECK(hipMemsetAsync(datt1, 0, (size_t)d.B * P * A * sizeof(float), s));
 
   for (int t = d.steps - 1; t >= 0; --t) {
     const int b = bs[t], r0 = off[t];
@@ -274,7 +277,7 @@ int att_seq_backward(const AttDims& d, const int* bs, const float* dH, const flo
     RC(att_step_bwd(sv + L.att1, feat, Zf + 4 * H, ZW, Zf + 4 * H + A, ZW, sv + L.awe + (size_t)r0 * C,
                     sv + L.alpha + (size_t)r0 * P, w.full_att_w, dXA + (size_t)r0 * XW + E, XW,
                     dalphas_bt, d.steps, t, b, P, A, C, dalpha_part, Z + 4 * H + A, Z + 4 * H, ZW,
-                    datt1, dwf_rows + (size_t)r0 * A, dbf_rows + r0, s));
+                    de_all + (size_t)r0 * P, dwf_rows + (size_t)r0 * A, dbf_rows + r0, s));
     // dh_{t-1} (or dh0) = dZ . Wz
     RC(sgemm_splitk(false, false, b, H, ZW, Z, ZW, sv + L.Wz, H, dh_rec, H, nullptr, 0, skws,
                     kAttSplitKFloats, s));
@@ -299,7 +302,9 @@ int att_seq_backward(const AttDims& d, const int* bs, const float* dH, const flo
   }
   RC(colsum(dwf_rows, A, N, A, g.dwf, 0, s));
   RC(colsum(dbf_rows, 1, N, 1, g.dbf, 0, s));
-  // encoder_att: d att1 was summed per sample over the steps
+  // encoder_att: d att1 summed per sample over its steps in one pass over att1
+  RC(att_datt1(sv + L.att1, sv + L.Zf + 4 * H, ZW, de_all, w.full_att_w, off.data(), d.steps, d.B, P, A,
+               datt1, s));
   RC(sgemm(true, false, A, C, d.B * P, datt1, A, feat, C, g.dWe, C, nullptr, 0, 1, 0, 0, 0, 0, 0, s));
   RC(colsum(datt1, A, d.B * P, A, g.dbe, 0, s, skws, kAttSplitKFloats));
   // init_h / init_c: dh0 = dh_rec, dc0 = dc (all B rows are alive at t = 0)

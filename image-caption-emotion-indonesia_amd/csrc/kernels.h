@@ -125,13 +125,16 @@ int lstm_step_fused(const float* hprev, const float* Wfrag, float* G, long ldg, 
 int att_step_fwd(const float* att1, const float* feat, const float* att2, float* gate_io, long ldz,
                  const float* wf, const float* bf, int rows, int P, int A, int C,
                  float* alpha_out, float* alphas_bt, int steps, int t, float* awe_out,
-                 float* xa_out, long ldx, hipStream_t stream);
+                 float* xa_out, long ldx, float* escore, hipStream_t stream);
 int att_step_bwd(const float* att1, const float* feat, const float* att2, long ldz2,
                  const float* gate, long ldzg, const float* awe, const float* alpha,
                  const float* wf, const float* dxa, long ldx, const float* dalphas_bt, int steps,
                  int t, int rows, int P, int A, int C, float* dalpha_part, float* dgate_out,
-                 float* datt2, long ldz, float* datt1_acc, float* dwf_rows, float* dbf_rows,
+                 float* datt2, long ldz, float* de_out, float* dwf_rows, float* dbf_rows,
                  hipStream_t stream);
+int att_datt1(const float* att1, const float* att2_rows, long ldz2, const float* de_rows,
+              const float* wf, const int* off, int steps, int B, int P, int A, float* datt1,
+              hipStream_t stream);
 
 // image_ops.hip
 int resize_u8(const unsigned char* src, int Hs, int Ws, unsigned char* tmp, unsigned char* dst, int Ho,

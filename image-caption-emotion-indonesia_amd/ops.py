@@ -129,6 +129,7 @@ def attention_step(att1, feat, z, A, w_full, b_full, xa=None, xa_col=0):
     alpha = torch.empty((s_rows, P), dtype=torch.float32, device=dev)
     alphas_bt = torch.empty((s_rows, 1, P), dtype=torch.float32, device=dev)
     awe = torch.empty((s_rows, Cdim), dtype=torch.float32, device=dev)
+    scores_ws = torch.empty((s_rows, P), dtype=torch.float32, device=dev)
     if xa is None:
         xa, xa_col = torch.empty((s_rows, Cdim), dtype=torch.float32, device=dev), 0
     if not xa.is_contiguous() or xa.shape[0] != s_rows or xa_col + Cdim > xa.shape[1] or xa_col % 4:
@@ -137,7 +138,7 @@ def attention_step(att1, feat, z, A, w_full, b_full, xa=None, xa_col=0):
     check(_lib.lib().capnet_att_step_fwd(ptr(att1), ptr(feat), ptr(z), C.c_void_p(z.data_ptr() + 4 * A), z.shape[1],
                                          ptr(wf), ptr(bf), s_rows, P, A, Cdim, ptr(alpha),
                                          ptr(alphas_bt), 1, 0, ptr(awe), C.c_void_p(xa.data_ptr() + 4 * xa_col),
-                                         xa.shape[1], current_stream()), "capnet_att_step_fwd")
+                                         xa.shape[1], ptr(scores_ws), current_stream()), "capnet_att_step_fwd")
     return awe, alpha
 
 

@@ -223,11 +223,12 @@ size_t capnet_att_bwd_scratch_floats(const int* dims);
  * step by sample() (model_att.py:352-357). att1 [rows][P][A] = encoder_att(features) (hoisted),
  * feat [rows][P][C], att2 (ld ldz) = decoder_att(h), gate_io (ld ldz): f_beta(h) in, sigmoid out;
  * w_full [A], b_full [1]. Outputs: alpha_out [rows][P]; alphas_bt[(row*steps + t)*P + p] (the
- * user-visible alphas tensor); awe_out [rows][C] (ungated context); xa_out (ld ldx) = gate*awe. */
+ * user-visible alphas tensor); awe_out [rows][C] (ungated context); xa_out (ld ldx) = gate*awe.
+ * scores_ws: scratch [rows][P] (the scores before the softmax). */
 int capnet_att_step_fwd(const float* att1, const float* feat, const float* att2, float* gate_io,
                         long ldz, const float* w_full, const float* b_full, int rows, int P, int A,
                         int C, float* alpha_out, float* alphas_bt, int steps, int t, float* awe_out,
-                        float* xa_out, long ldx, capnet_stream_t stream);
+                        float* xa_out, long ldx, float* scores_ws, capnet_stream_t stream);
 
 int capnet_att_seq_forward(const int* dims, const int* batch_sizes, const unsigned char* tf_mask,
                            const long long* captions, const float* features, const float* emb,
