@@ -154,6 +154,8 @@ def _oracle_case(dec, p, forward, B, V, seed, ratio, dev, ragged_len=None, **kw)
     (9, 203, 20, 24, 28, "sad", 0.7),        # ragged everything (non multiples of 4)
     (33, 1000, 300, 64, 96, "factual", 0.8),
     (64, 7411, 300, 512, 512, "factual", 0.8),   # full-size cell, ragged vocabulary
+    (12, 8192, 300, 1024, 512, "happy", 0.8),    # BASELINE configs[4] cell (factored 1024) at 96/8 per GPU
+    (96, 1000, 300, 1024, 512, "factual", 0.8),  # the same cell at the undivided batch 96 (> 64 rows per step)
 ])
 def test_factored_matches_oracle_seeded(dev, B, V, E, F, H, mode, ratio):
     dec = DecoderFactoredLSTM(E, H, F, V, 1, dropout=0.0)
