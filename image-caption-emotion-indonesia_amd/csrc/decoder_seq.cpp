@@ -303,10 +303,12 @@ int seq_backward(const SeqDims& d, const int* batch_sizes, const float* dH, cons
     RC(colsum(dA1, 4 * F, N, 4 * F, g.dbV, 0, s));
     // V: dVcat = dA1^T . X ; dX = dA1 . Vcat
     RC(sgemm(true, false, 4 * F, E, N, dA1, 4 * F, sv + L.X, E, g.dVcat, E, nullptr, 0, 1, 0, 0, 0, 0, 0, s));
-    RC(sgemm(false, false, N, E, 4 * F, dA1, 4 * F, sv + L.Vcat, E, dX, E, nullptr, 0, 1, 0, 0, 0, 0, 0, s));
+    RC(sgemm_splitk(false, false, N, E, 4 * F, dA1, 4 * F, sv + L.Vcat, E, dX, E, nullptr, 0, skws,
+                    kSplitKFloats, s));
   } else {
     RC(sgemm(true, false, 4 * H, E, N, dPre, 4 * H, sv + L.X, E, g.dVcat, E, nullptr, 0, 1, 0, 0, 0, 0, 0, s));
-    RC(sgemm(false, false, N, E, 4 * H, dPre, 4 * H, sv + L.Vcat, E, dX, E, nullptr, 0, 1, 0, 0, 0, 0, 0, s));
+    RC(sgemm_splitk(false, false, N, E, 4 * H, dPre, 4 * H, sv + L.Vcat, E, dX, E, nullptr, 0, skws,
+                    kSplitKFloats, s));
   }
   CAPNET_HIP_CHECK(hipMemsetAsync(g.dEmb, 0, (size_t)d.V * E * sizeof(float), s));
   if (g.dFeat) CAPNET_HIP_CHECK(hipMemsetAsync(g.dFeat, 0, (size_t)d.B * E * sizeof(float), s));

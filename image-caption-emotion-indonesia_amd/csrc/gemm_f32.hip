@@ -157,6 +157,9 @@ int sgemm(bool ta, bool tb, int M, int N, int K, const float* A, long lda, const
   } else if (tile == 64) {
     g.tiles_m = cdiv(M, 64); g.tiles_n = cdiv(N, 64);
     dispatch_layout<64, 64, 16>(g, batch, ta, tb, vec, stream);
+  } else if (tile == 6432) {   // 64x64 tile, 32-deep k slices: half the k-loop round trips
+    g.tiles_m = cdiv(M, 64); g.tiles_n = cdiv(N, 64);
+    dispatch_layout<64, 64, 32>(g, batch, ta, tb, vec, stream);
   } else {
     CAPNET_REQUIRE(false, "sgemm: unknown tile %d", tile);
   }
@@ -327,9 +330,34 @@ int sgemm_splitk_batched(bool ta, bool tb, int M, int N, int K, const float* A, 
                          aligned16(B) && ldb % 4 == 0 && (tb || N % 4 == 0) && N >= 4 && K >= 64 &&
                          (batch == 1 || (sC == N && (!bias || sBias == N) && sA % 4 == 0 &&
                                          sB % 4 == 0 && batch <= 64));
-  if (!skinny_ok)
+  if (!skinny_ok) {
+    // many rows but few output tiles and a long K (dH = dlogits . C: 1037 x 512 x 8192): the
+    // k-loop kernel with K cut into slabs, enough of them to put ~4 workgroups on every CU
+    const long tiles64 = (long)cdiv(M, 64) * cdiv(N, 64);
+    if (ws && batch == 1 && M > 128 && tiles64 < 256 && K >= 1024) {
+      CAPNET_REQUIRE(A && B && C, "sgemm_splitk: null operand");
+      int splitk = (int)(1024 / tiles64);
+      if (splitk > K / 256) splitk = K / 256;
+      while (splitk > 1 && (size_t)splitk * M * N > ws_floats) --splitk;
+      if (splitk > 1) {
+        GemmArgs g;
+        g.A = A; g.B = B; g.C = ws; g.bias = nullptr;
+        g.M = M; g.N = N; g.K = K;
+        g.lda = lda; g.ldb = ldb; g.ldc = N;
+        g.sA = g.sB = g.sC = g.sBias = 0;
+        g.accumulate = 0;
+        g.kchunk = cdiv(cdiv(K, splitk), 16) * 16;
+        g.splitk = cdiv(K, g.kchunk);
+        g.tiles_m = cdiv(M, 64);
+        g.tiles_n = cdiv(N, 64);
+        const bool vec = aligned16(A) && aligned16(B) && (lda % 4 == 0) && (ldb % 4 == 0);
+        dispatch_layout<64, 64, 16>(g, 1, ta, tb, vec, stream);
+        return reduce_slabs(ws, g.splitk, M, N, C, ldc, bias, accumulate, stream);
+      }
+    }
     return sgemm(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, batch, sA, sB, sC, sBias,
                  0, stream);
+  }
   CAPNET_REQUIRE(A && B && C, "sgemm_splitk: null operand");
   const long tiles = (long)cdiv(M, 64) * cdiv(N, 64) * batch;
   const size_t out_floats = (size_t)M * N * batch;

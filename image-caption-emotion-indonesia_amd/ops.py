@@ -79,6 +79,31 @@ def sgemm(A, B, transA=False, transB=False, bias=None, out=None, accumulate=Fals
     return out
 
 
+_splitk_ws = {}
+
+
+def sgemm_splitk(A, B, transB=False, bias=None):
+    """A @ op(B) + bias through capnet_sgemm_splitk: the library cuts K into slabs when the output
+    has few tiles (per-step products; dH = dlogits @ C with K = vocab). One cached 32 MB slab
+    workspace per device."""
+    _need_cuda(A, B, bias)
+    A, B = _c(A), _c(B)
+    M, K = A.shape
+    N = B.shape[0] if transB else B.shape[1]
+    if (B.shape[1] if transB else B.shape[0]) != K:
+        raise CapnetError("sgemm_splitk: inner dimensions differ")
+    key = A.device.index or 0
+    ws = _splitk_ws.get(key)
+    if ws is None:
+        ws = torch.empty(8 * 1024 * 1024, dtype=torch.float32, device=A.device)
+        _splitk_ws[key] = ws
+    out = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    check(_lib.lib().capnet_sgemm_splitk(0, int(transB), M, N, K, ptr(A), A.shape[1], ptr(B), B.shape[1],
+                                         ptr(out), N, ptr(bias), 0, ptr(ws), ws.numel(),
+                                         current_stream()), "capnet_sgemm_splitk")
+    return out
+
+
 def colsum(x, out=None):
     _need_cuda(x)
     x = _c(x)
@@ -252,7 +277,7 @@ class LinearFn(torch.autograd.Function):
         dy = _c(dy)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = sgemm(dy, w)                      # [M,N] @ [N,K]
+            dx = sgemm_splitk(dy, w)               # [M,N] @ [N,K]; K-split when N (vocab) is long
         if ctx.needs_input_grad[1]:
             dw = sgemm(dy, x, transA=True)         # dy^T [N,M] @ x [M,K]
         if ctx.has_bias and ctx.needs_input_grad[2]:

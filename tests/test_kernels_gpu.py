@@ -292,7 +292,7 @@ def test_argmax_first_max(dev):
 @pytest.mark.parametrize("tb", [True, False])
 @pytest.mark.parametrize("M,N,K", [(64, 2048, 512), (64, 512, 2048), (9, 4608, 512), (64, 8192, 512),
                                    (33, 300, 2048), (64, 2348, 2048), (96, 512, 512), (1, 64, 64),
-                                   (64, 512, 100), (5, 36, 72)])
+                                   (64, 512, 100), (5, 36, 72), (1037, 512, 8192), (1037, 300, 2048)])
 def test_sgemm_splitk_matches_fp64(dev, M, N, K, tb):
     from capnet._lib import lib, check, ptr, current_stream
     g = torch.Generator().manual_seed(M * 7 + N + K)
