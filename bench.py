@@ -143,6 +143,9 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no GPU visible); there is no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if world > 1:
+        # the ranks share the host: keep torch's CPU pool small (the step runs no CPU operator)
+        torch.set_num_threads(max(1, min(4, host_cores())))
     import torch.distributed as dist
     if world > 1 or os.environ.get("CAPNET_FORCE_ALLREDUCE") == "1":
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
