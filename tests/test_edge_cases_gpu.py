@@ -1,0 +1,144 @@
+"""Edge cases of the decoder drivers against the CPU oracle: a single sample, single-step
+captions, equal lengths, very ragged lengths, the step cap, a free-running first step
+(the input is B(<start>) instead of the image feature), no-feature calls."""
+import random
+
+import pytest
+import torch
+
+import capnet
+from capnet import ops, synthetic
+from capnet.model import DecoderFactoredLSTM
+from capnet.model_att import DecoderFactoredLSTMAtt
+from capnet.nic_model import DecoderRNN
+from helpers import rel_err
+from oracle import decoders_ref as D
+from oracle import step_ref as S
+
+pytestmark = pytest.mark.gpu
+
+
+def _captions(lengths, V, seed):
+    g = torch.Generator().manual_seed(seed)
+    B, T = len(lengths), max(lengths)
+    c = torch.randint(4, V, (B, T), generator=g)
+    c[:, 0] = 1
+    for i, l in enumerate(lengths):
+        c[i, l - 1] = 2 if l > 1 else 1
+        c[i, l:] = 0
+    return c
+
+
+def _check(dec, p, forward, captions, lengths, feats, tf, dev, **kw):
+    loss_r, grads_r, dfeat_r, logits_r = S.decoder_loss_and_grads(forward, p, captions, lengths, feats, tf, **kw)
+    dec.zero_grad()
+    f = feats.to(dev).requires_grad_(True) if feats is not None else None
+    out = dec(captions.to(dev), lengths, f, tf_mask=tf, **kw)
+    loss = ops.cross_entropy(out, D.packed_targets(captions, lengths).to(dev))
+    loss.backward()
+    ops.check_device_errors()
+    assert out.shape == logits_r.shape
+    assert rel_err(out, logits_r) < 5e-5
+    assert abs(loss.item() - loss_r.item()) / abs(loss_r.item()) < 1e-5
+    for k, prm in dec.named_parameters():
+        if grads_r[k] is None:
+            assert prm.grad is None, k
+        else:
+            assert rel_err(prm.grad, grads_r[k]) < 2e-4 or float(grads_r[k].abs().max()) < 1e-7, k
+    if dfeat_r is not None and f is not None and float(dfeat_r.abs().max()) > 0:
+        assert rel_err(f.grad, dfeat_r) < 2e-4
+
+
+LENGTH_SETS = {
+    "single_sample": [5],
+    "single_step": [1, 1, 1],
+    "one_long_many_short": [17, 2, 2, 1, 1, 1],
+    "all_equal": [6, 6, 6, 6],
+    "two_rows_len2": [2, 2],
+}
+
+
+@pytest.mark.parametrize("name", list(LENGTH_SETS))
+@pytest.mark.parametrize("tf_kind", ["all", "none", "mixed"])
+def test_factored_edge_lengths(dev, name, tf_kind):
+    lengths = LENGTH_SETS[name]
+    E, H, F, V = 20, 32, 24, 57
+    dec = DecoderFactoredLSTM(E, H, F, V, 1, dropout=0.0)
+    p = synthetic.decoder_state(dec.state_dict(), seed=len(lengths), bias_range=0.05)
+    dec.load_state_dict(p)
+    dec.to(dev).train()
+    captions = _captions(lengths, V, 3)
+    feats = torch.randn(len(lengths), E, generator=torch.Generator().manual_seed(4))
+    random.seed(9)
+    T = max(lengths)
+    tf = {"all": [True] * T, "none": [False] * T,
+          "mixed": [random.random() < 0.5 for _ in range(T)]}[tf_kind]
+    _check(dec, p, D.factored_lstm_forward, captions, lengths, feats, tf, dev, mode="factual")
+
+
+def test_factored_without_features(dev):
+    lengths = [7, 4, 2]
+    E, H, F, V = 20, 32, 24, 57
+    dec = DecoderFactoredLSTM(E, H, F, V, 1, dropout=0.0)
+    p = synthetic.decoder_state(dec.state_dict(), seed=2, bias_range=0.05)
+    dec.load_state_dict(p)
+    dec.to(dev).train()
+    _check(dec, p, D.factored_lstm_forward, _captions(lengths, V, 5), lengths, None,
+           [True, False, True, True, False, True, True], dev, mode="sad")
+
+
+@pytest.mark.parametrize("name", ["single_sample", "single_step", "one_long_many_short"])
+def test_nic_edge_lengths(dev, name):
+    lengths = LENGTH_SETS[name]
+    E, H, V = 20, 32, 57
+    dec = DecoderRNN(E, H, V, 1, dropout=0.0)
+    p = synthetic.decoder_state(dec.state_dict(), seed=7, bias_range=0.05)
+    dec.load_state_dict(p)
+    dec.to(dev).train()
+    feats = torch.randn(len(lengths), E, generator=torch.Generator().manual_seed(8))
+    tf = [(i % 3) != 1 for i in range(max(lengths))]
+    _check(dec, p, D.lstm_forward, _captions(lengths, V, 6), lengths, feats, tf, dev)
+
+
+@pytest.mark.parametrize("lengths", [[5], [3, 2, 2], [9, 1]])
+def test_attention_edge_lengths(dev, lengths):
+    A, E, H, F, V, P, Cf = 16, 12, 16, 16, 37, 4, 512
+    dec = DecoderFactoredLSTMAtt(A, E, H, F, V, 1, feature_size=Cf, dropout=0.0)
+    p = synthetic.decoder_state(dec.state_dict(), seed=11, bias_range=0.05)
+    dec.load_state_dict(p)
+    dec.to(dev).train()
+    captions = _captions(lengths, V, 12)
+    feats = torch.randn(len(lengths), P, Cf, generator=torch.Generator().manual_seed(13)).abs()
+    tf = [(i % 2) == 0 for i in range(max(lengths))]
+    pr = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    logits_r, alphas_r = D.factored_att_forward(pr, captions, lengths, feats, tf, mode="factual")
+    loss_r = D.att_loss(logits_r, alphas_r, D.packed_targets(captions, lengths))
+    loss_r.backward()
+    dec.zero_grad()
+    out, alphas = dec(captions.to(dev), lengths, feats.to(dev), tf_mask=tf, mode="factual")
+    loss = ops.cross_entropy(out, D.packed_targets(captions, lengths).to(dev)) + \
+        ((1.0 - alphas.sum(dim=1)) ** 2).mean()
+    loss.backward()
+    assert rel_err(out, logits_r) < 5e-5 and rel_err(alphas, alphas_r) < 5e-5
+    assert abs(loss.item() - loss_r.item()) / loss_r.item() < 1e-5
+    for k, prm in dec.named_parameters():
+        if pr[k].grad is not None:
+            g = pr[k].grad
+            assert (prm.grad.cpu().double() - g.double()).abs().max().item() <= 2e-4 * g.abs().max().item() + 1e-6, k
+
+
+def test_step_cap_and_bad_lengths_raise(dev):
+    E, H, F, V = 12, 16, 16, 37
+    dec = DecoderFactoredLSTM(E, H, F, V, 1, dropout=0.0).to(dev).train()
+    long_len = [200]
+    with pytest.raises(capnet.CapnetError):
+        dec(_captions(long_len, V, 1).to(dev), long_len, None)              # > 128 steps
+    with pytest.raises((capnet.CapnetError, ValueError)):
+        dec(_captions([3, 5], V, 1).to(dev), [3, 5], None)                   # not sorted
+    with pytest.raises((capnet.CapnetError, ValueError)):
+        dec(_captions([3, 2], V, 1).to(dev), [3, 0], None)                   # zero length
+    bad = _captions([4, 3], V, 1)
+    bad[0, 1] = V + 5                                                        # token id out of range
+    dec(bad.to(dev), [4, 3], None, tf_mask=[True] * 4)
+    with pytest.raises(capnet.CapnetError):
+        ops.check_device_errors()
