@@ -41,6 +41,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-conv-events", action="store_true",
                     help="do not bracket conv kernels with hipEvents (roofline becomes null)")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="run trunk and decoder of a step back to back on one stream instead of "
+                         "overlapping step i's decoder with step i+1's trunk (capnet.train.TrunkPipeline)")
     ap.add_argument("--no-lstm-roofline", action="store_true",
                     help="skip the LSTM-step microbenchmark (PMC passes profile the train step only)")
     ap.add_argument("--cpu-steps", type=int, default=2)
@@ -156,7 +159,7 @@ def main():
     from capnet.model import DecoderFactoredLSTM, EncoderCNN
     from capnet.nic_model import DecoderRNN
     from capnet.parallel import DataParallelAdam
-    from capnet.train import CrossEntropyLoss, train_step, train_step_att
+    from capnet.train import CrossEntropyLoss, TrunkPipeline, train_step, train_step_att
     from capnet import model_att
 
     B, V = args.batch, args.vocab
@@ -174,7 +177,8 @@ def main():
     params = list(decoder.parameters())
     if args.decoder != "att":
         params += list(encoder.linear.parameters()) + list(encoder.bn.parameters())
-    optimizer = DataParallelAdam(params, lr=2e-4, overlap=True)
+    # pipelined: everything trainable already runs on the pipeline's side stream, in order
+    optimizer = DataParallelAdam(params, lr=2e-4, overlap=args.no_pipeline)
     if args.decoder != "att":
         optimizer.attach(encoder)
     criterion = CrossEntropyLoss()
@@ -190,8 +194,17 @@ def main():
     loss_scale = float(sum(lengths)) / n_global if world > 1 else None
     random.seed(0)
 
+    pipe = None
+    if not args.no_pipeline:
+        pipe = TrunkPipeline(encoder, decoder, optimizer, criterion, 0.5, attention=args.decoder == "att")
+        pipe.prefetch(images)
+
     def step():
         tf = [random.random() < 0.8 for _ in range(global_steps)]
+        if pipe is not None:
+            # the trunk of the next batch goes to the main stream first, then this batch's
+            # head + decoder + loss + backward + clamp + Adam to the side stream
+            return pipe.step(captions, lengths, next_images=images, tf_mask=tf, loss_scale=loss_scale)
         if args.decoder == "att":
             optimizer.wait_for_update()   # no trainable encoder head to hang the wait on
             return train_step_att(encoder, decoder, optimizer, criterion, images, captions, lengths,
@@ -245,6 +258,24 @@ def main():
                         "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": pmc_traffic(),
                         "launches": n.value, "avg_launch_us": round(ms.value * 1e3 / n.value, 2),
                         "flops_per_launch": fl.value / n.value}
+            if pipe is not None:
+                # In the timed region the convolutions share the chip with the previous batch's
+                # decoder (that is where the throughput comes from, and it lengthens each conv a
+                # little). For reference: the same kernels with nothing else running, 3 extra
+                # untimed trunk passes.
+                torch.cuda.synchronize()
+                lib.capnet_trunk_set_timing(plan["handle"], 1)
+                for _ in range(3):
+                    encoder(images) if args.decoder == "att" else encoder.trunk_features(images)
+                torch.cuda.synchronize()
+                lib.capnet_trunk_set_timing(plan["handle"], 0)
+                capnet._lib.check(lib.capnet_trunk_collect_timing(plan["handle"], C.byref(ms), C.byref(n),
+                                                                 C.byref(fl)))
+                if n.value > 0:
+                    alone = fl.value / (ms.value * 1e-3) / 1e12
+                    roofline["alone"] = {"achieved": round(alone, 2),
+                                         "frac": round(alone / MFMA_F32_PEAK_TFLOPS, 4),
+                                         "note": "same conv launches without the overlapped decoder"}
 
     # secondary roofline: the recurrent LSTM step (5.77 MB of algorithmic HBM
     # traffic per step at b=64, H=512), timed with events on the launch stream
@@ -321,7 +352,8 @@ def main():
                                    "emb 300, V=%d) + ResNet-152 train-mode trunk, batch %d/GPU, 224x224, "
                                    "tf 0.8, dropout %.2f, clamp 0.5 + Adam 2e-4" % (V, B, args.dropout),
                        "decoder": args.decoder, "global_batch": B * world,
-                       "parallelism": "dp%d" % world},
+                       "parallelism": "dp%d" % world,
+                       "pipeline": "step i decoder || step i+1 trunk" if pipe is not None else "none"},
             "loss_first": round(float(first.item()), 5) if first is not None else None,
             "loss_last": round(float(last.item()), 5),
             "roofline": roofline,

@@ -82,53 +82,182 @@ def train_step_att(encoder, decoder, optimizer, criterion, images, captions, len
     return loss.detach()
 
 
+class TrunkPipeline(object):
+    """Software pipeline over training steps: the frozen trunk of batch i+1 on the caller's stream
+    while head + decoder + loss + backward + clamp + Adam of batch i run on a side stream.
+
+    The ResNet-152 trunk runs under no_grad and none of its inputs depend on the parameter update
+    (stylenet/model.py:23-25; train_multitask.py:163-167 only optimises the head and the decoder),
+    so this reorders nothing that is ordered in the reference: every step sees exactly the
+    parameters, running statistics and random draws of the sequential loop, and produces the same
+    numbers. What it changes is that the decoder's many small, latency-bound launches no longer
+    leave the chip idle: they share it with the convolutions of the next batch (which run on a
+    high-priority stream).
+
+        pipe = TrunkPipeline(encoder, decoder, optimizer, criterion, grad_clip)
+        pipe.prefetch(images_0)
+        for i in range(n):
+            loss = pipe.step(captions_i, lengths_i, next_images=images_{i+1} or None)
+        pipe.finish()            # before reading a loss or the parameters on the caller's stream
+    """
+
+    def __init__(self, encoder, decoder, optimizer, criterion, grad_clip, attention=False,
+                 alpha_c=1.0):
+        self.encoder, self.decoder, self.optimizer = encoder, decoder, optimizer
+        self.criterion, self.grad_clip = criterion, grad_clip
+        self.attention, self.alpha_c = attention, alpha_c
+        self.side = torch.cuda.Stream()
+        # the trunk gets a high-priority stream: its convolutions keep the chip, the decoder's
+        # small launches fill what they leave (launch tails, partially filled rounds)
+        self.trunk_stream = torch.cuda.Stream(priority=-1)
+        self._ready = None
+
+    def prefetch(self, images):
+        """Enqueue the trunk of `images` (ordered after the caller's current stream)."""
+        self.trunk_stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.trunk_stream):
+            if self.attention:
+                feats = self.encoder(images)
+            else:
+                feats = self.encoder.trunk_features(images)
+            done = torch.cuda.Event()
+            done.record()
+        images.record_stream(self.trunk_stream)
+        feats.record_stream(self.side)
+        self._ready = (feats, done)
+
+    def step(self, captions, lengths, next_images=None, mode=None, tf_mask=None, loss_scale=None,
+             teacher_forcing_ratio=0.8, zero_encoder_grad=True):
+        if self._ready is None:
+            raise RuntimeError("TrunkPipeline.step() without a prefetched batch")
+        feats, done = self._ready
+        self._ready = None
+        if next_images is not None:
+            self.prefetch(next_images)      # queued before the decoder work of this batch
+        enc, dec = self.encoder, self.decoder
+        kw = {}
+        if mode is not None:
+            kw["mode"] = mode
+        if tf_mask is not None:
+            kw["tf_mask"] = tf_mask
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(done)
+            if self.attention:
+                lens = [l - 1 for l in lengths]
+                targets = ops.packed_targets(captions[:, 1:].contiguous(), lens)
+                outputs, alphas = dec(captions[:, :-1].contiguous(), lens, feats,
+                                      teacher_forcing_ratio=teacher_forcing_ratio, **kw)
+                loss = self.criterion(outputs, targets)
+                loss = loss + self.alpha_c * ((1.0 - alphas.sum(dim=1)) ** 2).mean()
+            else:
+                targets = ops.packed_targets(captions, lengths)
+                if enc.pre_head_hook is not None:
+                    enc.pre_head_hook()
+                features = enc.bn(enc.linear(feats))
+                outputs = dec(captions, lengths, features,
+                              teacher_forcing_ratio=teacher_forcing_ratio, **kw)
+                loss = self.criterion(outputs, targets)
+            dec.zero_grad()
+            if zero_encoder_grad:
+                enc.zero_grad()
+            (loss if loss_scale is None else loss * loss_scale).backward()
+            clip_gradient(self.optimizer, self.grad_clip)
+            self.optimizer.step()
+            loss = loss.detach()
+        return loss
+
+    def finish(self):
+        """Make the caller's stream wait for everything queued by the pipeline."""
+        torch.cuda.current_stream().wait_stream(self.side)
+        torch.cuda.current_stream().wait_stream(self.trunk_stream)
+
+
 def _drain(pending, meter):
     for loss, n in pending:
         meter.update(loss.item(), n)
     del pending[:]
 
 
+def _lookahead(loader):
+    """(index, batch, next batch or None) over a loader."""
+    it = iter(loader)
+    try:
+        cur = next(it)
+    except StopIteration:
+        return
+    i = 0
+    for nxt in it:
+        yield i, cur, nxt
+        cur = nxt
+        i += 1
+    yield i, cur, None
+
+
 def train_factual(encoder, decoder, optimizer, criterion, data_loader, log_step, grad_clip,
-                  device=None):
+                  device=None, pipeline=True):
+    """stylenet/train_multitask.py:364-408. pipeline=True overlaps each batch's trainable half with
+    the next batch's trunk (TrunkPipeline); the numbers are those of the sequential loop."""
     decoder.train()
     encoder.train()
     losses = AverageMeter()
     pending = []
     device = device or next(decoder.parameters()).device
-    for i, (images, captions, lengths, all_captions) in enumerate(data_loader):
-        images = images.to(device, non_blocking=True)
+    pipe = TrunkPipeline(encoder, decoder, optimizer, criterion, grad_clip) if pipeline else None
+    for i, (images, captions, lengths, all_captions), nxt in _lookahead(data_loader):
         captions = captions.to(device, non_blocking=True)
-        loss = train_step(encoder, decoder, optimizer, criterion, images, captions, lengths,
-                          grad_clip)
+        if pipe is None:
+            loss = train_step(encoder, decoder, optimizer, criterion,
+                              images.to(device, non_blocking=True), captions, lengths, grad_clip)
+        else:
+            if i == 0:
+                pipe.prefetch(images.to(device, non_blocking=True))
+            loss = pipe.step(captions, lengths,
+                             next_images=None if nxt is None else nxt[0].to(device, non_blocking=True))
         pending.append((loss, sum(lengths)))
         if i % log_step == 0:
+            if pipe is not None:
+                pipe.finish()
             _drain(pending, losses)
             ops.check_device_errors()
             print("""Step [{}/{}], [FAC], Loss: {:.4f}""".format(i, len(data_loader), losses.val))
+    if pipe is not None:
+        pipe.finish()
     _drain(pending, losses)
     ops.check_device_errors()
     return losses.avg
 
 
 def train_emotion(encoder, decoder, optimizer, criterion, data_loaders, tags, log_step,
-                  grad_clip, device=None):
+                  grad_clip, device=None, pipeline=True):
+    """stylenet/train_multitask.py:511-557 (emotion order drawn with random.sample, as there)."""
     decoder.train()
     encoder.train()
     losses = [AverageMeter() for _ in range(len(tags))]
     device = device or next(decoder.parameters()).device
+    pipe = TrunkPipeline(encoder, decoder, optimizer, criterion, grad_clip) if pipeline else None
     for j in random.sample([i for i in range(len(tags))], len(tags)):
         pending = []
-        for i, (images, captions, lengths, all_captions) in enumerate(data_loaders[j]):
-            images = images.to(device, non_blocking=True)
+        for i, (images, captions, lengths, all_captions), nxt in _lookahead(data_loaders[j]):
             captions = captions.to(device, non_blocking=True)
-            loss = train_step(encoder, decoder, optimizer, criterion, images, captions, lengths,
-                              grad_clip, mode=tags[j], zero_encoder_grad=False)
+            if pipe is None:
+                loss = train_step(encoder, decoder, optimizer, criterion,
+                                  images.to(device, non_blocking=True), captions, lengths, grad_clip,
+                                  mode=tags[j], zero_encoder_grad=False)
+            else:
+                if i == 0:
+                    pipe.prefetch(images.to(device, non_blocking=True))
+                loss = pipe.step(captions, lengths, mode=tags[j], zero_encoder_grad=False,
+                                 next_images=None if nxt is None else nxt[0].to(device, non_blocking=True))
             pending.append((loss, sum(lengths)))
             if i % log_step == 0:
+                if pipe is not None:
+                    pipe.finish()
                 _drain(pending, losses[j])
                 ops.check_device_errors()
                 print("""Step [{}/{}], [{}], Loss: {:.4f}""".format(
                     i, len(data_loaders[j]), tags[j][:3].upper(), losses[j].val))
+        if pipe is not None:
+            pipe.finish()
         _drain(pending, losses[j])
     ops.check_device_errors()
     return [l.avg for l in losses]
