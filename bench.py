@@ -234,9 +234,11 @@ def main():
     last = None
     for _ in range(args.steps):
         last = step()
+    host_enqueue = time.perf_counter() - t0     # host time to queue the steps (GPU may lag behind)
     optimizer.wait_for_update()
     barrier()
     elapsed = time.perf_counter() - t0
+    log("host enqueue %.3f s of %.3f s" % (host_enqueue, elapsed))
     log("timed region: %.3f s" % elapsed)
     lib.capnet_trunk_set_timing(plan["handle"], 0)
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)

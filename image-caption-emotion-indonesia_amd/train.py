@@ -91,8 +91,7 @@ class TrunkPipeline(object):
     so this reorders nothing that is ordered in the reference: every step sees exactly the
     parameters, running statistics and random draws of the sequential loop, and produces the same
     numbers. What it changes is that the decoder's many small, latency-bound launches no longer
-    leave the chip idle: they share it with the convolutions of the next batch (which run on a
-    high-priority stream).
+    leave the chip idle: they share it with the convolutions of the next batch.
 
         pipe = TrunkPipeline(encoder, decoder, optimizer, criterion, grad_clip)
         pipe.prefetch(images_0)
@@ -106,10 +105,13 @@ class TrunkPipeline(object):
         self.encoder, self.decoder, self.optimizer = encoder, decoder, optimizer
         self.criterion, self.grad_clip = criterion, grad_clip
         self.attention, self.alpha_c = attention, alpha_c
-        self.side = torch.cuda.Stream()
-        # the trunk gets a high-priority stream: its convolutions keep the chip, the decoder's
-        # small launches fill what they leave (launch tails, partially filled rounds)
-        self.trunk_stream = torch.cuda.Stream(priority=-1)
+        # The trainable half gets the HIGH-priority stream: its launches are small (a few
+        # workgroups, microseconds) and form a long dependent chain, so they must be dispatched as
+        # soon as they are ready; a convolution of the trunk has thousands of workgroups queued and
+        # loses nothing by yielding a few slots. (With the priorities the other way round the
+        # decoder's kernels only ran in the tails of the convolutions: measured, no overlap.)
+        self.side = torch.cuda.Stream(priority=-1)
+        self.trunk_stream = torch.cuda.Stream()
         self._ready = None
 
     def prefetch(self, images):
