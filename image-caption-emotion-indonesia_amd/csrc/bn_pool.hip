@@ -106,35 +106,48 @@ int bn_eval_scale_shift(const float* gamma, const float* beta, const float* rm, 
 }
 
 // ---- bottleneck tail: out = relu(bn3(y) + identity) or relu(bn3(y) + bn_ds(r)) ---------
+// Two independent 16-B elements per thread and iteration. (Non-temporal loads of the two dead
+// inputs were measured: 0.05 ms slower over the trunk, so the loads are plain.)
+typedef float bn_f32x4 __attribute__((ext_vector_type(4)));
+
 __global__ __launch_bounds__(256) void bn_add_relu_kernel(
-    const float4* __restrict__ y, const float* __restrict__ s1, const float* __restrict__ t1,
-    const float4* __restrict__ res, const float* __restrict__ s2, const float* __restrict__ t2,
-    float4* __restrict__ out, long n4, int C4) {
+    const bn_f32x4* __restrict__ y, const float* __restrict__ s1, const float* __restrict__ t1,
+    const bn_f32x4* __restrict__ res, const float* __restrict__ s2, const float* __restrict__ t2,
+    bn_f32x4* __restrict__ out, long n4, int C4) {
   const long stride = (long)gridDim.x * blockDim.x;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-    const int c = (int)(i % C4) * 4;
-    const float4 a = y[i];
-    const float4 sc = *reinterpret_cast<const float4*>(s1 + c);
-    const float4 sh = *reinterpret_cast<const float4*>(t1 + c);
-    float4 v;
-    v.x = fmaf(a.x, sc.x, sh.x);
-    v.y = fmaf(a.y, sc.y, sh.y);
-    v.z = fmaf(a.z, sc.z, sh.z);
-    v.w = fmaf(a.w, sc.w, sh.w);
-    if (res) {
-      float4 r = res[i];
-      if (s2) {
-        const float4 sc2 = *reinterpret_cast<const float4*>(s2 + c);
-        const float4 sh2 = *reinterpret_cast<const float4*>(t2 + c);
-        r.x = fmaf(r.x, sc2.x, sh2.x);
-        r.y = fmaf(r.y, sc2.y, sh2.y);
-        r.z = fmaf(r.z, sc2.z, sh2.z);
-        r.w = fmaf(r.w, sc2.w, sh2.w);
-      }
-      v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+  for (long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x; i0 < n4; i0 += 2 * stride) {
+    const long idx[2] = {i0, i0 + stride};
+    bn_f32x4 a[2], r[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const long i = idx[u] < n4 ? idx[u] : i0;
+      a[u] = y[i];
+      if (res) r[u] = res[i];
     }
-    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-    out[i] = v;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (idx[u] >= n4) continue;
+      const int c = (int)(idx[u] % C4) * 4;
+      const bn_f32x4 sc = *reinterpret_cast<const bn_f32x4*>(s1 + c);
+      const bn_f32x4 sh = *reinterpret_cast<const bn_f32x4*>(t1 + c);
+      bn_f32x4 v;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = fmaf(a[u][k], sc[k], sh[k]);
+      if (res) {
+        bn_f32x4 rr = r[u];
+        if (s2) {
+          const bn_f32x4 sc2 = *reinterpret_cast<const bn_f32x4*>(s2 + c);
+          const bn_f32x4 sh2 = *reinterpret_cast<const bn_f32x4*>(t2 + c);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) rr[k] = fmaf(rr[k], sc2[k], sh2[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] += rr[k];
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+      out[idx[u]] = v;
+    }
   }
 }
 
@@ -146,8 +159,8 @@ int bn_add_relu(const float* y, const float* s1, const float* t1, const float* r
   CAPNET_REQUIRE((s2 == nullptr) == (t2 == nullptr), "bn_add_relu: s2/t2 pair");
   const long n4 = rows * (C / 4);
   const int blocks = (int)(n4 / 256 < 1 ? 1 : (n4 / 256 > 8192 ? 8192 : n4 / 256));
-  hipLaunchKernelGGL(bn_add_relu_kernel, dim3(blocks), dim3(256), 0, stream, (const float4*)y, s1,
-                     t1, (const float4*)res, s2, t2, (float4*)out, n4, C / 4);
+  hipLaunchKernelGGL(bn_add_relu_kernel, dim3(blocks), dim3(256), 0, stream, (const bn_f32x4*)y, s1,
+                     t1, (const bn_f32x4*)res, s2, t2, (bn_f32x4*)out, n4, C / 4);
   CAPNET_LAUNCH_CHECK();
   return kOk;
 }
