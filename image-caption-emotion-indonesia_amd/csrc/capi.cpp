@@ -121,8 +121,9 @@ void capnet_conv_kmajor_plan(int M, int Cout, int k_rows, int tile, int* out5) {
   conv_v2_plan(M, Cout, k_rows, tile, out5);
 }
 int capnet_conv_kmajor_tiles_m(int M, int Cout, int k_rows, int tile) {
-  if (tile == 0) tile = conv_v2_auto_tile(M, Cout, k_rows);
-  return conv_tiles_m(M, tile);
+  int plan[5];
+  conv_v2_plan(M, Cout, k_rows, tile, plan);   // normalises the tile exactly as the launcher does
+  return conv_tiles_m(M, plan[0]);
 }
 int capnet_bn_finalize(const float* part_sum, const float* part_sq, int tiles, int C, long count,
                        const float* gamma, const float* beta, float* running_mean,

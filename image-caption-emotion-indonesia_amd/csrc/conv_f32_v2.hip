@@ -438,9 +438,17 @@ int conv_v2_auto_tile(int M, int Cout, int Kw) {
   return best;
 }
 
+// A requested tile whose N extent does not divide Cout falls back to the 64-wide one. Every
+// planning helper and the launcher go through this, so workspaces are sized for the tile that runs.
+static int norm_tile(int M, int Cout, int Kw, int tile) {
+  if (tile == 0) return conv_v2_auto_tile(M, Cout, Kw);
+  if (tile == 128 && Cout % 128 != 0) return 12864;
+  return tile;
+}
+
 // out = {tile, tiles, full_tiles, split, k-tiles per slice}
 void conv_v2_plan(int M, int Cout, int Kw, int tile, int* out) {
-  if (tile == 0) tile = conv_v2_auto_tile(M, Cout, Kw);
+  tile = norm_tile(M, Cout, Kw, tile);
   int BM, BN;
   tile_dims(tile, &BM, &BN);
   const int T = cdiv(M, BM) * (Cout / BN);
@@ -450,7 +458,7 @@ void conv_v2_plan(int M, int Cout, int Kw, int tile, int* out) {
 }
 
 size_t conv_v2_slab_floats(int M, int Cout, int Kw, int tile) {
-  if (tile == 0) tile = conv_v2_auto_tile(M, Cout, Kw);
+  tile = norm_tile(M, Cout, Kw, tile);
   int BM, BN;
   tile_dims(tile, &BM, &BN);
   if (Cout % BN != 0) return 0;
@@ -515,8 +523,7 @@ int conv2d_fwd_v2(const float* x, long sxb, long sxh, long sxw, const float* wk,
   g.slabs = slabs;
   g.x_bytes = (unsigned)((long)Bn * sxb * 4);
   g.ss_bytes = (unsigned)(Cin * 4);
-  if (tile == 0) tile = conv_v2_auto_tile(g.M, Cout, Kw);
-  if (Cout % 128 != 0 && tile == 128) tile = 12864;
+  tile = norm_tile(g.M, Cout, Kw, tile);
   if (tile == 128) launch_v2<128, 128>(g, stream);
   else if (tile == 64) launch_v2<64, 64>(g, stream);
   else if (tile == 12864) launch_v2<128, 64>(g, stream);
