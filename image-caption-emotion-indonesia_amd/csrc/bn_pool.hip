@@ -105,6 +105,53 @@ int bn_eval_scale_shift(const float* gamma, const float* beta, const float* rm, 
   return kOk;
 }
 
+// eval mode, every BatchNorm of the trunk in a few launches: up to kBnEvalMax BNs per launch, their
+// pointers travel in the kernel arguments
+constexpr int kBnEvalMax = 32;
+struct BnEvalTable {
+  const float* gamma[kBnEvalMax];
+  const float* beta[kBnEvalMax];
+  const float* rm[kBnEvalMax];
+  const float* rv[kBnEvalMax];
+  float* scale[kBnEvalMax];
+  float* shift[kBnEvalMax];
+  int C[kBnEvalMax];
+};
+
+__global__ __launch_bounds__(256) void bn_eval_multi_kernel(BnEvalTable t, float eps) {
+  const int k = blockIdx.y;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= t.C[k]) return;
+  const float invstd = 1.f / sqrtf(t.rv[k][c] + eps);
+  const float sc = (t.gamma[k] ? t.gamma[k][c] : 1.f) * invstd;
+  t.scale[k][c] = sc;
+  t.shift[k][c] = (t.beta[k] ? t.beta[k][c] : 0.f) - t.rm[k][c] * sc;
+}
+
+int bn_eval_multi(int n, const float* const* gamma, const float* const* beta, const float* const* rm,
+                  const float* const* rv, const int* C, float* const* scale, float* const* shift,
+                  float eps, hipStream_t stream) {
+  CAPNET_REQUIRE(n >= 0 && rm && rv && C && scale && shift, "bn_eval_multi: bad argument");
+  for (int i0 = 0; i0 < n; i0 += kBnEvalMax) {
+    BnEvalTable t;
+    const int cnt = n - i0 < kBnEvalMax ? n - i0 : kBnEvalMax;
+    int maxc = 0;
+    for (int k = 0; k < cnt; ++k) {
+      CAPNET_REQUIRE(rm[i0 + k] && rv[i0 + k] && scale[i0 + k] && shift[i0 + k] && C[i0 + k] > 0,
+                     "bn_eval_multi: BN %d", i0 + k);
+      t.gamma[k] = gamma ? gamma[i0 + k] : nullptr;
+      t.beta[k] = beta ? beta[i0 + k] : nullptr;
+      t.rm[k] = rm[i0 + k]; t.rv[k] = rv[i0 + k];
+      t.scale[k] = scale[i0 + k]; t.shift[k] = shift[i0 + k];
+      t.C[k] = C[i0 + k];
+      maxc = C[i0 + k] > maxc ? C[i0 + k] : maxc;
+    }
+    hipLaunchKernelGGL(bn_eval_multi_kernel, dim3(cdiv(maxc, 256), cnt), dim3(256), 0, stream, t, eps);
+  }
+  CAPNET_LAUNCH_CHECK();
+  return kOk;
+}
+
 // ---- bottleneck tail: out = relu(bn3(y) + identity) or relu(bn3(y) + bn_ds(r)) ---------
 // Two independent 16-B elements per thread and iteration. (Non-temporal loads of the two dead
 // inputs were measured: 0.05 ms slower over the trunk, so the loads are plain.)

@@ -40,6 +40,13 @@ struct ConvArgs2 {
   // slabs ([rem_tile][slice][BM*BN]) summed by conv_tail_fixup_kernel
   int full_tiles, split, kps;
   float* slabs;
+  // inference epilogue (EPI instantiation only): y = act(acc * out_scale[n] + out_shift[n] + res)
+  // -- the BatchNorm that follows the conv folded in from its running statistics, the residual
+  // add and the ReLU of a bottleneck's tail -- instead of raw output + batch statistics
+  const float* out_scale;
+  const float* out_shift;
+  const float* res;
+  int relu_out;
 };
 
 // LDS-DMA of 16 B per lane: LDS[m0_base + 16*lane] = *(sbase + voff). Inline asm on purpose:
@@ -70,7 +77,7 @@ __device__ __forceinline__ void gload16(f32x4& dst, const float* sbase, unsigned
   asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff_bytes), "s"(sbase) : "memory");
 }
 
-template <int BM, int BN>
+template <int BM, int BN, bool EPI>
 __global__ __launch_bounds__(kGemmThreads) void conv_f32_v2_kernel(ConvArgs2 g) {
   constexpr int BK = 16;
   constexpr int LDA = BM + 4;
@@ -309,6 +316,28 @@ __global__ __launch_bounds__(kGemmThreads) void conv_f32_v2_kernel(ConvArgs2 g) 
     return;
   }
 
+  if (EPI) {
+    // ---- inference epilogue: folded BatchNorm (+ residual) (+ ReLU), no statistics ----
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = n0 + wn * (BN / 2) + nt * 32 + li;
+      const float sc = g.out_scale[n], sh = g.out_shift[n];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wm * (BM / 2) + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (m < g.M) {
+            float v = fmaf(acc[mt][nt][r], sc, sh);
+            if (g.res) v += g.res[(long)m * g.Cout + n];
+            if (g.relu_out) v = fmaxf(v, 0.f);
+            g.y[(long)m * g.Cout + n] = v;
+          }
+        }
+      }
+    }
+    return;
+  }
   // ---- epilogue: raw output + batch-statistics partials ----
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
@@ -332,7 +361,7 @@ __global__ __launch_bounds__(kGemmThreads) void conv_f32_v2_kernel(ConvArgs2 g) 
 // One 1024-thread workgroup per tail tile: y = sum of its K-slice slabs (fixed order), plus that
 // tile's column sums / sums of squares for the batch statistics. The slab loads of one output
 // element are independent and issued together (the kernel is pure latency otherwise).
-template <int BM, int BN>
+template <int BM, int BN, bool EPI>
 __global__ __launch_bounds__(1024) void conv_tail_fixup_kernel(ConvArgs2 g) {
   constexpr int RL = 1024 / BN;  // row lanes
   __shared__ float s_sum[RL][BN], s_sq[RL][BN];
@@ -352,12 +381,17 @@ __global__ __launch_bounds__(1024) void conv_tail_fixup_kernel(ConvArgs2 g) {
     for (int k = 0; k < 16; ++k) v += k < sp ? p[k] : 0.f;
     const int m = m0 + ml;
     if (m < g.M) {
+      if (EPI) {
+        v = fmaf(v, g.out_scale[n0 + c], g.out_shift[n0 + c]);
+        if (g.res) v += g.res[(long)m * g.Cout + n0 + c];
+        if (g.relu_out) v = fmaxf(v, 0.f);
+      }
       g.y[(long)m * g.Cout + n0 + c] = v;
       cs += v;
       cq = fmaf(v, v, cq);
     }
   }
-  if (g.part_sum) {
+  if (!EPI && g.part_sum) {
     s_sum[rl][c] = cs;
     s_sq[rl][c] = cq;
     __syncthreads();
@@ -482,10 +516,17 @@ static void launch_v2(ConvArgs2& g, hipStream_t stream) {
     if (sp > 1) { g.full_tiles = full; g.split = sp; g.kps = kps; }
   }
   const int rem = T - g.full_tiles;
-  hipLaunchKernelGGL((conv_f32_v2_kernel<BM, BN>), dim3(g.full_tiles + rem * g.split),
+  if (g.out_scale) {
+    hipLaunchKernelGGL((conv_f32_v2_kernel<BM, BN, true>), dim3(g.full_tiles + rem * g.split),
+                       dim3(kGemmThreads), 0, stream, g);
+    if (rem > 0)
+      hipLaunchKernelGGL((conv_tail_fixup_kernel<BM, BN, true>), dim3(rem), dim3(1024), 0, stream, g);
+    return;
+  }
+  hipLaunchKernelGGL((conv_f32_v2_kernel<BM, BN, false>), dim3(g.full_tiles + rem * g.split),
                      dim3(kGemmThreads), 0, stream, g);
   if (rem > 0)
-    hipLaunchKernelGGL((conv_tail_fixup_kernel<BM, BN>), dim3(rem), dim3(1024), 0, stream, g);
+    hipLaunchKernelGGL((conv_tail_fixup_kernel<BM, BN, false>), dim3(rem), dim3(1024), 0, stream, g);
 }
 
 bool conv_v2_eligible(const float* x, long sxb, long sxh, long sxw, long sxc, int Bn, int Cin,
@@ -499,8 +540,12 @@ bool conv_v2_eligible(const float* x, long sxb, long sxh, long sxw, long sxc, in
 int conv2d_fwd_v2(const float* x, long sxb, long sxh, long sxw, const float* wk, int Kw, float* y,
                   const float* in_scale, const float* in_shift, int relu_in, float* part_sum,
                   float* part_sq, int Bn, int H, int W, int Cin, int Cout, int KH, int KW,
-                  int stride, int pad, int tile, float* slabs, hipStream_t stream) {
+                  int stride, int pad, int tile, float* slabs, hipStream_t stream,
+                  const float* out_scale, const float* out_shift, const float* res, int relu_out) {
   CAPNET_REQUIRE(x && wk && y, "conv2d_fwd_v2: null pointer");
+  CAPNET_REQUIRE((out_scale == nullptr) == (out_shift == nullptr), "conv2d_fwd_v2: epilogue scale/shift pair");
+  CAPNET_REQUIRE(!out_scale || !part_sum, "conv2d_fwd_v2: the folded-BN epilogue produces no statistics");
+  CAPNET_REQUIRE(out_scale || (!res && !relu_out), "conv2d_fwd_v2: residual / ReLU need the epilogue");
   CAPNET_REQUIRE(conv_v2_eligible(x, sxb, sxh, sxw, 1, Bn, Cin, Cout, in_scale, in_shift),
                  "conv2d_fwd_v2: shape/alignment not supported (Cin=%d Cout=%d)", Cin, Cout);
   CAPNET_REQUIRE(Kw == KH * KW * Cin && aligned16(wk), "conv2d_fwd_v2: packed weight stride");
@@ -511,6 +556,7 @@ int conv2d_fwd_v2(const float* x, long sxb, long sxh, long sxw, const float* wk,
   g.x = x; g.wk = wk; g.y = y;
   g.in_scale = in_scale; g.in_shift = in_shift;
   g.part_sum = part_sum; g.part_sq = part_sq;
+  g.out_scale = out_scale; g.out_shift = out_shift; g.res = res; g.relu_out = relu_out;
   g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.KW = KW; g.stride = stride; g.pad = pad;
   g.OH = (H + 2 * pad - KH) / stride + 1;
   g.OW = (W + 2 * pad - KW) / stride + 1;

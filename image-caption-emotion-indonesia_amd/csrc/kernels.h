@@ -30,7 +30,9 @@ bool conv_v2_eligible(const float* x, long sxb, long sxh, long sxw, long sxc, in
 int conv2d_fwd_v2(const float* x, long sxb, long sxh, long sxw, const float* wk, int Kw, float* y,
                   const float* in_scale, const float* in_shift, int relu_in, float* part_sum,
                   float* part_sq, int Bn, int H, int W, int Cin, int Cout, int KH, int KW,
-                  int stride, int pad, int tile, float* slabs, hipStream_t stream);
+                  int stride, int pad, int tile, float* slabs, hipStream_t stream,
+                  const float* out_scale = nullptr, const float* out_shift = nullptr,
+                  const float* res = nullptr, int relu_out = 0);
 size_t conv_v2_slab_floats(int M, int Cout, int Kw, int tile);
 int conv_v2_auto_tile(int M, int Cout, int Kw);
 void conv_v2_plan(int M, int Cout, int Kw, int tile, int* out);
@@ -42,6 +44,9 @@ int bn_finalize(const float* part_sum, const float* part_sq, int tiles, int C, l
                 float momentum, float eps, float* scale, float* shift, hipStream_t stream);
 int bn_eval_scale_shift(const float* gamma, const float* beta, const float* rm, const float* rv,
                         float eps, int C, float* scale, float* shift, hipStream_t stream);
+int bn_eval_multi(int n, const float* const* gamma, const float* const* beta, const float* const* rm,
+                  const float* const* rv, const int* C, float* const* scale, float* const* shift,
+                  float eps, hipStream_t stream);
 int bn_add_relu(const float* y, const float* s1, const float* t1, const float* res,
                 const float* s2, const float* t2, float* out, long rows, int C,
                 hipStream_t stream);

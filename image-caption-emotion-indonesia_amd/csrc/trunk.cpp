@@ -222,6 +222,103 @@ int conv_bn(const Ctx& c, int i, const float* x, long sxb, long sxh, long sxw, l
   return bn_eval_scale_shift(c.gamma[i], c.beta[i], c.rmean[i], c.rvar[i], c.eps, d.Cout,
                              c.scale(i), c.shift(i), c.s);
 }
+// conv i with the BatchNorm that follows it folded into the epilogue (inference)
+int conv_folded(const Ctx& c, int i, const float* x, const float* res, int relu, float* y) {
+  const TrunkConv& d = c.t->convs[i];
+  const long M = (long)c.t->B * d.OH * d.OW;
+  const long sw = d.Cin, sh = (long)d.W * d.Cin, sb = (long)d.H * d.W * d.Cin;
+  CAPNET_REQUIRE(d.kmajor && conv_v2_eligible(x, sb, sh, sw, 1, c.t->B, d.Cin, d.Cout, nullptr, nullptr),
+                 "trunk: conv %d is not eligible for the folded-BN kernel", i);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (c.t->timing) {
+    CAPNET_HIP_CHECK(hipEventCreate(&e0));
+    CAPNET_HIP_CHECK(hipEventCreate(&e1));
+    CAPNET_HIP_CHECK(hipEventRecord(e0, c.s));
+  }
+  const int rc = conv2d_fwd_v2(x, sb, sh, sw, c.w[i], d.Kw, y, nullptr, nullptr, 0, nullptr, nullptr,
+                               c.t->B, d.H, d.W, d.Cin, d.Cout, d.k, d.k, d.stride, d.pad, 0,
+                               c.ws + c.t->off_slab, c.s, c.scale(i), c.shift(i), res, relu);
+  if (c.t->timing) {
+    CAPNET_HIP_CHECK(hipEventRecord(e1, c.s));
+    c.t->ev.push_back(e0);
+    c.t->ev.push_back(e1);
+    c.t->timed_flops += 2.0 * (double)M * d.Cout * d.k * d.k * d.Cin;
+  }
+  return rc;
+}
+
+// Inference trunk (encoder.eval(): validation, sample()): every BatchNorm uses its running
+// statistics, so it is an affine map known before the conv runs. Each conv applies it in its
+// epilogue together with the ReLU, and conv3 of a bottleneck also adds the identity / downsample
+// branch: 155 conv launches and nothing else (no raw tensors, no statistics, no bn_add_relu).
+int trunk_forward_eval(const Ctx& c, const float* images_nchw, float* out_pooled, float* out_map) {
+  Trunk* t = c.t;
+  const int B = t->B;
+  float* ws = c.ws;
+  float* X[2] = {ws + t->off_x[0], ws + t->off_x[1]};
+  float* Y1 = ws + t->off_y1;
+  float* Y2 = ws + t->off_y2;
+  float* Y3 = ws + t->off_y3;
+  float* D = ws + t->off_d;
+  const int n = (int)t->convs.size();
+  {
+    std::vector<const float*> g(n), b(n), rm(n), rv(n);
+    std::vector<float*> sc(n), sh(n);
+    std::vector<int> C(n);
+    for (int i = 0; i < n; ++i) {
+      g[i] = c.gamma[i]; b[i] = c.beta[i]; rm[i] = c.rmean[i]; rv[i] = c.rvar[i];
+      sc[i] = c.scale(i); sh[i] = c.shift(i); C[i] = t->convs[i].Cout;
+    }
+    int rc = bn_eval_multi(n, g.data(), b.data(), rm.data(), rv.data(), C.data(), sc.data(), sh.data(),
+                           c.eps, c.s);
+    if (rc) return rc;
+  }
+  int rc;
+  {
+    // stem: the gather-loader kernel writes the raw conv, BN + ReLU ride on the max-pool
+    const TrunkConv& d = t->convs[0];
+    const long M = (long)B * d.OH * d.OW;
+    rc = conv2d_fwd(images_nchw, (long)3 * d.H * d.W, d.W, 1, (long)d.H * d.W, c.w[0], d.Kw, Y3, nullptr,
+                    nullptr, 0, nullptr, nullptr, B, d.H, d.W, d.Cin, d.Cout, d.k, d.k, d.stride, d.pad,
+                    conv_auto_tile((int)M, d.Cout), c.s);
+    if (rc) return rc;
+    rc = bn_relu_maxpool(Y3, c.scale(0), c.shift(0), X[0], B, d.OH, d.OW, 64, c.s);
+    if (rc) return rc;
+  }
+  int ci = 1, cur = 0;
+  const int blocks[4] = {3, 8, 36, 3};
+  for (int L = 0; L < 4; ++L) {
+    for (int bk = 0; bk < blocks[L]; ++bk) {
+      const int i1 = ci, i2 = ci + 1, i3 = ci + 2;
+      const int id = (bk == 0) ? ci + 3 : -1;
+      ci += (bk == 0) ? 4 : 3;
+      const float* x = X[cur];
+      float* out = X[cur ^ 1];
+      rc = conv_folded(c, i1, x, nullptr, 1, Y1);
+      if (rc) return rc;
+      rc = conv_folded(c, i2, Y1, nullptr, 1, Y2);
+      if (rc) return rc;
+      const float* res = x;
+      if (id >= 0) {
+        rc = conv_folded(c, id, x, nullptr, 0, D);
+        if (rc) return rc;
+        res = D;
+      }
+      rc = conv_folded(c, i3, Y2, res, 1, out);
+      if (rc) return rc;
+      cur ^= 1;
+    }
+  }
+  const int side = t->final_side;
+  if (out_pooled) {
+    rc = global_avgpool(X[cur], out_pooled, B, side * side, 2048, c.s);
+    if (rc) return rc;
+  }
+  if (out_map)
+    CAPNET_HIP_CHECK(hipMemcpyAsync(out_map, X[cur], (size_t)B * side * side * 2048 * sizeof(float),
+                                    hipMemcpyDeviceToDevice, c.s));
+  return kOk;
+}
 }  // namespace
 
 int trunk_forward(Trunk* t, const float* images_nchw, const float* const* w_packed,
@@ -243,6 +340,7 @@ int trunk_forward(Trunk* t, const float* images_nchw, const float* const* w_pack
   float* D = workspace + t->off_d;
   int rc;
   int ci = 0;
+  if (!train) return trunk_forward_eval(c, images_nchw, out_pooled, out_map);
   // stem: NCHW image read through the generic gather loader
   {
     const TrunkConv& d = t->convs[0];

@@ -92,8 +92,12 @@ def test_trunk_eval_mode(dev, golden):
     # the C call takes one momentum for the whole trunk (the first BN's)
     enc._trunk().forward(imgs, True, True, False)
     enc.eval()
-    pooled, _ = enc._trunk().forward(imgs, False, True, False)
-    assert rel_err(pooled, golden["pooled_eval"]) < TOL
+    pooled, fmap = enc._trunk().forward(imgs, False, True, True)
+    e = rel_err(pooled, golden["pooled_eval"])
+    print("eval-mode pooled rel err vs fp64 fixture", e)
+    # (the running statistics come from the train-mode pass above and carry its fp32 noise)
+    assert e < TOL
+    assert rel_err(fmap.mean(dim=(1, 2)), pooled) < 1e-5      # map output of the same pass
 
 
 def test_attention_encoder_map(dev, golden):
@@ -118,3 +122,40 @@ def test_image_shape_errors(dev):
         enc(torch.zeros(2, 3, 100, 100, device=dev))
     with pytest.raises(capnet.CapnetError):
         enc(torch.zeros(2, 1, 224, 224, device=dev))
+
+
+def test_folded_bn_inference_trunk_matches_oracle_with_given_statistics(dev):
+    """encoder.eval(): 155 convs with the BatchNorm folded into their epilogues. Same seeded running
+    statistics on both sides (no batch statistics involved), so the comparison with the fp32 CPU
+    oracle is tight."""
+    from oracle.resnet152_ref import EncoderCNNRef
+    B = 2
+    enc = EncoderCNN(300)
+    st = _encoder_state(enc)
+    g = torch.Generator().manual_seed(99)
+    for k in list(st):
+        if k.startswith("resnet.") and k.endswith("running_mean"):
+            st[k] = torch.randn(st[k].shape, generator=g) * 0.05
+        if k.startswith("resnet.") and k.endswith("running_var"):
+            st[k] = torch.rand(st[k].shape, generator=g) + 0.5
+        if k.startswith("resnet.") and k.endswith("bn3.weight"):
+            st[k] = torch.full_like(st[k], 0.3)      # keeps the residual sum bounded over 50 blocks
+    enc.load_state_dict(st)
+    enc.to(dev).eval()
+    ref = EncoderCNNRef(300)
+    ref.load_state_dict({k: v.clone() for k, v in st.items()})
+    ref.eval()
+    imgs = synthetic.make_batch(B, 100, seed=3)[0]
+    with torch.no_grad():
+        want_pooled = ref.resnet(imgs).reshape(B, -1)
+        want = ref(imgs)
+    pooled, fmap = enc._trunk().forward(imgs.to(dev), False, True, True)
+    e = rel_err(pooled, want_pooled)
+    print("folded-BN trunk vs fp32 oracle", e)
+    assert e < 2e-4
+    assert rel_err(fmap.mean(dim=(1, 2)), want_pooled) < 2e-4
+    with torch.no_grad():
+        got = enc(imgs.to(dev))
+    assert rel_err(got, want) < 5e-4
+    # eval mode must not touch the running statistics
+    assert torch.equal(enc.resnet[1].running_mean.cpu(), st["resnet.1.running_mean"])

@@ -6,7 +6,8 @@ import capnet
 from capnet import synthetic
 from capnet.model import EncoderCNN
 dev = torch.device("cuda:0")
-enc = EncoderCNN(300).to(dev).train()
+enc = EncoderCNN(300).to(dev)
+enc.train() if "--eval" not in sys.argv else enc.eval()
 imgs = synthetic.make_batch(64, 100, seed=0)[0].to(dev)
 for _ in range(3):
     enc.trunk_features(imgs)
@@ -16,4 +17,4 @@ n = 20
 for _ in range(n):
     enc.trunk_features(imgs)
 torch.cuda.synchronize()
-print("trunk only: %.3f ms per batch of 64" % ((time.perf_counter() - t0) / n * 1e3))
+print(("eval " if "--eval" in sys.argv else "train ") + "trunk only: %.3f ms per batch of 64" % ((time.perf_counter() - t0) / n * 1e3))
