@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--no-pipeline", action="store_true",
                     help="run trunk and decoder of a step back to back on one stream instead of "
                          "overlapping step i's decoder with step i+1's trunk (capnet.train.TrunkPipeline)")
+    ap.add_argument("--pipeline-depth", type=int, default=3,
+                    help="trunk passes in flight ahead of the decoder")
     ap.add_argument("--no-lstm-roofline", action="store_true",
                     help="skip the LSTM-step microbenchmark (PMC passes profile the train step only)")
     ap.add_argument("--cpu-steps", type=int, default=2)
@@ -196,8 +198,10 @@ def main():
 
     pipe = None
     if not args.no_pipeline:
-        pipe = TrunkPipeline(encoder, decoder, optimizer, criterion, 0.5, attention=args.decoder == "att")
-        pipe.prefetch(images)
+        pipe = TrunkPipeline(encoder, decoder, optimizer, criterion, 0.5, attention=args.decoder == "att",
+                             depth=args.pipeline_depth)
+        for _ in range(pipe.depth):
+            pipe.prefetch(images)
 
     def step():
         tf = [random.random() < 0.8 for _ in range(global_steps)]
@@ -256,6 +260,9 @@ def main():
             roofline = {"bound": "mfma",
                         "kernel": "conv_f32_v2_kernel (implicit-GEMM conv, v_mfma_f32_32x32x2_f32; each "
                                   "launch = the conv, its tail fix-up if any; the 7x7 stem is conv_f32_kernel)",
+                        "how": "HIP events around every conv launch of the timed region, on its launch stream; "
+                               "duration = time with at least one conv launch running (union of the "
+                               "intervals: two trunk passes are in flight, their launches overlap)",
                         "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": pmc_traffic(),
                         "launches": n.value, "avg_launch_us": round(ms.value * 1e3 / n.value, 2),
@@ -355,7 +362,7 @@ def main():
                                    "tf 0.8, dropout %.2f, clamp 0.5 + Adam 2e-4" % (V, B, args.dropout),
                        "decoder": args.decoder, "global_batch": B * world,
                        "parallelism": "dp%d" % world,
-                       "pipeline": "step i decoder || step i+1 trunk" if pipe is not None else "none"},
+                       "pipeline": ("decoder of step i || trunks of steps i+1..i+%d" % pipe.depth) if pipe is not None else "none"},
             "loss_first": round(float(first.item()), 5) if first is not None else None,
             "loss_last": round(float(last.item()), 5),
             "roofline": roofline,

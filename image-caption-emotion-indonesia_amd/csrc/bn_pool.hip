@@ -20,7 +20,7 @@ __global__ __launch_bounds__(kFinCh* kFinRows) void bn_finalize_kernel(
     double inv_count, double unbias, const float* __restrict__ gamma,
     const float* __restrict__ beta, float* __restrict__ running_mean,
     float* __restrict__ running_var, float momentum, float eps, float* __restrict__ scale,
-    float* __restrict__ shift) {
+    float* __restrict__ shift, float* __restrict__ batch_mean, float* __restrict__ batch_var) {
   __shared__ double s_sum[kFinRows][kFinCh + 1];
   __shared__ double s_sq[kFinRows][kFinCh + 1];
   const int cx = threadIdx.x % kFinCh, ry = threadIdx.x / kFinCh;
@@ -66,19 +66,25 @@ __global__ __launch_bounds__(kFinCh* kFinRows) void bn_finalize_kernel(
       running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
       running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(var * unbias);
     }
+    if (batch_mean) {   // deferred running-statistics update (bn_running_update_multi)
+      batch_mean[c] = (float)mean;
+      batch_var[c] = (float)(var * unbias);
+    }
   }
 }
 
 int bn_finalize(const float* part_sum, const float* part_sq, int tiles, int C, long count,
                 const float* gamma, const float* beta, float* running_mean, float* running_var,
-                float momentum, float eps, float* scale, float* shift, hipStream_t stream) {
+                float momentum, float eps, float* scale, float* shift, hipStream_t stream,
+                float* batch_mean, float* batch_var) {
   CAPNET_REQUIRE(part_sum && part_sq && scale && shift && tiles > 0 && C > 0 && count > 0,
                  "bn_finalize: bad argument");
+  CAPNET_REQUIRE((batch_mean == nullptr) == (batch_var == nullptr), "bn_finalize: batch stat pair");
   const double inv = 1.0 / (double)count;
   const double unbias = count > 1 ? (double)count / (double)(count - 1) : 1.0;
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, kFinCh)), dim3(kFinCh * kFinRows), 0,
                      stream, part_sum, part_sq, tiles, C, inv, unbias, gamma, beta, running_mean,
-                     running_var, momentum, eps, scale, shift);
+                     running_var, momentum, eps, scale, shift, batch_mean, batch_var);
   CAPNET_LAUNCH_CHECK();
   return kOk;
 }
@@ -147,6 +153,47 @@ int bn_eval_multi(int n, const float* const* gamma, const float* const* beta, co
       maxc = C[i0 + k] > maxc ? C[i0 + k] : maxc;
     }
     hipLaunchKernelGGL(bn_eval_multi_kernel, dim3(cdiv(maxc, 256), cnt), dim3(256), 0, stream, t, eps);
+  }
+  CAPNET_LAUNCH_CHECK();
+  return kOk;
+}
+
+// running statistics of many BatchNorms from the batch statistics bn_finalize left behind
+// (same arithmetic as the inline update): the trunk defers them to the end of a pass so that two
+// passes in flight on different streams update them in pass order (capnet.train.TrunkPipeline)
+struct BnRunTable {
+  const float* mean[kBnEvalMax];
+  const float* var[kBnEvalMax];
+  float* rm[kBnEvalMax];
+  float* rv[kBnEvalMax];
+  int C[kBnEvalMax];
+};
+
+__global__ __launch_bounds__(256) void bn_running_update_kernel(BnRunTable t, float momentum) {
+  const int k = blockIdx.y;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= t.C[k]) return;
+  t.rm[k][c] = (1.f - momentum) * t.rm[k][c] + momentum * t.mean[k][c];
+  t.rv[k][c] = (1.f - momentum) * t.rv[k][c] + momentum * t.var[k][c];
+}
+
+int bn_running_update_multi(int n, const float* const* mean, const float* const* var, float* const* rm,
+                            float* const* rv, const int* C, float momentum, hipStream_t stream) {
+  CAPNET_REQUIRE(n >= 0 && mean && var && rm && rv && C, "bn_running_update_multi: bad argument");
+  for (int i0 = 0; i0 < n; i0 += kBnEvalMax) {
+    BnRunTable t;
+    const int cnt = n - i0 < kBnEvalMax ? n - i0 : kBnEvalMax;
+    int maxc = 0;
+    for (int k = 0; k < cnt; ++k) {
+      CAPNET_REQUIRE(mean[i0 + k] && var[i0 + k] && rm[i0 + k] && rv[i0 + k] && C[i0 + k] > 0,
+                     "bn_running_update_multi: BN %d", i0 + k);
+      t.mean[k] = mean[i0 + k]; t.var[k] = var[i0 + k];
+      t.rm[k] = rm[i0 + k]; t.rv[k] = rv[i0 + k];
+      t.C[k] = C[i0 + k];
+      maxc = C[i0 + k] > maxc ? C[i0 + k] : maxc;
+    }
+    hipLaunchKernelGGL(bn_running_update_kernel, dim3(cdiv(maxc, 256), cnt), dim3(256), 0, stream, t,
+                       momentum);
   }
   CAPNET_LAUNCH_CHECK();
   return kOk;

@@ -78,6 +78,13 @@ int capnet_trunk_forward(const capnet_trunk_t* t, const float* images_nchw,
                        bn_bias, bn_running_mean, bn_running_var, train, momentum, eps,
                        reinterpret_cast<float*>(workspace), out_pooled, out_map, S(stream));
 }
+int capnet_trunk_update_running(const capnet_trunk_t* t, const void* workspace,
+                                float* const* bn_running_mean, float* const* bn_running_var,
+                                float momentum, capnet_stream_t stream) {
+  return trunk_update_running(reinterpret_cast<Trunk*>(const_cast<capnet_trunk_t*>(t)),
+                              reinterpret_cast<const float*>(workspace), bn_running_mean, bn_running_var,
+                              momentum, S(stream));
+}
 int capnet_trunk_conv_kmajor(const capnet_trunk_t* t, int i) {
   return trunk_conv_kmajor(reinterpret_cast<const Trunk*>(t), i);
 }

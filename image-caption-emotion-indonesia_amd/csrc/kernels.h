@@ -41,9 +41,12 @@ int conv_tiles_m(int M, int tile);
 // bn_pool.hip
 int bn_finalize(const float* part_sum, const float* part_sq, int tiles, int C, long count,
                 const float* gamma, const float* beta, float* running_mean, float* running_var,
-                float momentum, float eps, float* scale, float* shift, hipStream_t stream);
+                float momentum, float eps, float* scale, float* shift, hipStream_t stream,
+                float* batch_mean = nullptr, float* batch_var = nullptr);
 int bn_eval_scale_shift(const float* gamma, const float* beta, const float* rm, const float* rv,
                         float eps, int C, float* scale, float* shift, hipStream_t stream);
+int bn_running_update_multi(int n, const float* const* mean, const float* const* var, float* const* rm,
+                            float* const* rv, const int* C, float momentum, hipStream_t stream);
 int bn_eval_multi(int n, const float* const* gamma, const float* const* beta, const float* const* rm,
                   const float* const* rv, const int* C, float* const* scale, float* const* shift,
                   float eps, hipStream_t stream);
@@ -72,6 +75,8 @@ int trunk_conv_kmajor(const Trunk* t, int i);
 double trunk_flops(const Trunk* t);
 int trunk_set_timing(Trunk* t, int enable);
 int trunk_collect_timing(Trunk* t, double* conv_ms, long* conv_launches, double* conv_flops);
+int trunk_update_running(Trunk* t, const float* workspace, float* const* bn_rmean, float* const* bn_rvar,
+                         float momentum, hipStream_t stream);
 int trunk_forward(Trunk* t, const float* images_nchw, const float* const* w_packed,
                   const float* const* bn_gamma, const float* const* bn_beta,
                   float* const* bn_rmean, float* const* bn_rvar, int train, float momentum,

@@ -12,6 +12,8 @@
 //   X --conv1--> Y1 raw (+stats) --[bn1+relu on load] conv2--> Y2 raw (+stats)
 //     --[bn2+relu on load] conv3--> Y3 raw (+stats);  [X --convD--> D raw (+stats)]
 //   OUT = relu(bn3(Y3) + (bnD(D) | X))         (bn_add_relu)
+#include <algorithm>
+#include <utility>
 #include <vector>
 
 #include "common.h"
@@ -33,6 +35,7 @@ struct Trunk {
   // workspace layout (float offsets)
   size_t off_x[2], off_y1, off_y2, off_y3, off_d, off_part, off_slab, off_ss, total_floats;
   std::vector<size_t> ss_off;  // per conv: offset of [scale | shift] (2*Cout floats)
+  std::vector<size_t> bs_off;  // per conv: offset of [batch mean | unbiased batch var] (2*Cout floats)
   int final_side;
   // optional per-convolution hipEvent timing (bench.py roofline): pairs recorded on the launch
   // stream around every conv kernel while enabled, summed by trunk_collect_timing
@@ -109,6 +112,7 @@ int trunk_create(int B, int H, int W, Trunk** out) {
   t->off_slab = take(max_slab + 64);
   t->off_ss = off;
   for (auto& c : t->convs) t->ss_off.push_back(take(2 * (size_t)c.Cout));
+  for (auto& c : t->convs) t->bs_off.push_back(take(2 * (size_t)c.Cout));
   t->total_floats = off;
   *out = t;
   return kOk;
@@ -130,13 +134,29 @@ int trunk_set_timing(Trunk* t, int enable) {
 // the last collect.
 int trunk_collect_timing(Trunk* t, double* conv_ms, long* conv_launches, double* conv_flops) {
   CAPNET_REQUIRE(t && conv_ms && conv_launches && conv_flops, "trunk_collect_timing: null");
-  double ms = 0;
+  // Time during which at least one timed conv launch was running: the union of the [start, end]
+  // intervals. With one pass at a time this is the sum of the launch durations; with two passes in
+  // flight on different streams (capnet.train.TrunkPipeline) the launches of the two passes
+  // overlap and a plain sum would count that time twice.
+  std::vector<std::pair<float, float>> iv;
   for (size_t i = 0; i + 1 < t->ev.size(); i += 2) {
     CAPNET_HIP_CHECK(hipEventSynchronize(t->ev[i + 1]));
-    float e = 0;
-    CAPNET_HIP_CHECK(hipEventElapsedTime(&e, t->ev[i], t->ev[i + 1]));
-    ms += e;
+    float a = 0, b = 0;
+    if (i > 0) CAPNET_HIP_CHECK(hipEventElapsedTime(&a, t->ev[0], t->ev[i]));
+    CAPNET_HIP_CHECK(hipEventElapsedTime(&b, t->ev[i], t->ev[i + 1]));
+    iv.emplace_back(a, a + b);
   }
+  std::sort(iv.begin(), iv.end());
+  double ms = 0;
+  float cur_a = 0, cur_b = 0;
+  bool open = false;
+  for (auto& p : iv) {
+    if (!open) { cur_a = p.first; cur_b = p.second; open = true; continue; }
+    if (p.first <= cur_b) { cur_b = std::max(cur_b, p.second); continue; }
+    ms += cur_b - cur_a;
+    cur_a = p.first; cur_b = p.second;
+  }
+  if (open) ms += cur_b - cur_a;
   *conv_ms = ms;
   *conv_launches = (long)(t->ev.size() / 2);
   *conv_flops = t->timed_flops;
@@ -181,6 +201,8 @@ struct Ctx {
   hipStream_t s;
   float* scale(int i) const { return ws + t->ss_off[i]; }
   float* shift(int i) const { return ws + t->ss_off[i] + t->convs[i].Cout; }
+  float* bmean(int i) const { return ws + t->bs_off[i]; }
+  float* bvar(int i) const { return ws + t->bs_off[i] + t->convs[i].Cout; }
 };
 
 // conv i + the (scale, shift) of the BatchNorm that follows it
@@ -216,6 +238,10 @@ int conv_bn(const Ctx& c, int i, const float* x, long sxb, long sxh, long sxw, l
     c.t->timed_flops += 2.0 * (double)M * d.Cout * d.k * d.k * d.Cin;
   }
   if (rc) return rc;
+  if (c.train == 2)   // running statistics deferred to trunk_update_running
+    return bn_finalize(psum, psq, conv_tiles_m((int)M, tile), d.Cout, M, c.gamma[i], c.beta[i],
+                       nullptr, nullptr, c.momentum, c.eps, c.scale(i), c.shift(i), c.s, c.bmean(i),
+                       c.bvar(i));
   if (c.train)
     return bn_finalize(psum, psq, conv_tiles_m((int)M, tile), d.Cout, M, c.gamma[i], c.beta[i],
                        c.rmean[i], c.rvar[i], c.momentum, c.eps, c.scale(i), c.shift(i), c.s);
@@ -320,6 +346,20 @@ int trunk_forward_eval(const Ctx& c, const float* images_nchw, float* out_pooled
   return kOk;
 }
 }  // namespace
+
+int trunk_update_running(Trunk* t, const float* workspace, float* const* bn_rmean, float* const* bn_rvar,
+                         float momentum, hipStream_t stream) {
+  CAPNET_REQUIRE(t && workspace && bn_rmean && bn_rvar, "trunk_update_running: null argument");
+  const int n = (int)t->convs.size();
+  std::vector<const float*> mean(n), var(n);
+  std::vector<int> C(n);
+  for (int i = 0; i < n; ++i) {
+    mean[i] = workspace + t->bs_off[i];
+    var[i] = workspace + t->bs_off[i] + t->convs[i].Cout;
+    C[i] = t->convs[i].Cout;
+  }
+  return bn_running_update_multi(n, mean.data(), var.data(), bn_rmean, bn_rvar, C.data(), momentum, stream);
+}
 
 int trunk_forward(Trunk* t, const float* images_nchw, const float* const* w_packed,
                   const float* const* bn_gamma, const float* const* bn_beta,

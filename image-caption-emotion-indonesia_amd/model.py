@@ -151,10 +151,18 @@ class _TrunkRunner:
                 raise CapnetError("trunk plan has %d convolutions, module has %d" % (n, len(self.convs)))
             nbytes = L.capnet_trunk_workspace_bytes(handle)
             ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
-            p = {"handle": handle, "ws": ws, "side": L.capnet_trunk_final_side(handle),
-                 "flops": L.capnet_trunk_flops(handle)}
+            p = {"handle": handle, "ws": ws, "slots": {0: ws}, "nbytes": nbytes,
+                 "side": L.capnet_trunk_final_side(handle), "flops": L.capnet_trunk_flops(handle)}
             self.plans[key] = p
         return p
+
+    def _workspace(self, plan, slot, dev):
+        """One workspace per pipeline slot (passes in flight on different streams)."""
+        ws = plan["slots"].get(slot)
+        if ws is None:
+            ws = torch.empty(plan["nbytes"] // 4, dtype=torch.float32, device=dev)
+            plan["slots"][slot] = ws
+        return ws
 
     def _pack(self, plan, dev):
         key = (str(dev),) + tuple((c.weight.data_ptr(), c.weight._version) for c in self.convs)
@@ -173,7 +181,10 @@ class _TrunkRunner:
             self.packed, self.packed_key = packed, key
         return self.packed
 
-    def forward(self, images, train, want_pooled, want_map):
+    def forward(self, images, train, want_pooled, want_map, slot=0, defer_stats=False):
+        """defer_stats (train mode only): leave the running statistics alone and return a callable
+        that applies this pass's update (capnet_trunk_update_running + num_batches_tracked) on the
+        then-current stream; the caller decides when (TrunkPipeline orders passes with events)."""
         ops._need_cuda(images)
         if images.dim() != 4 or images.shape[1] != 3:
             raise CapnetError("images must be [B, 3, H, W]")
@@ -183,6 +194,7 @@ class _TrunkRunner:
         plan = self._plan(b, h, w, dev)
         packed = self._pack(plan, dev)
         side = plan["side"]
+        ws = self._workspace(plan, slot, dev)
         pooled = torch.empty((b, 2048), dtype=torch.float32, device=dev) if want_pooled else None
         fmap = torch.empty((b, side, side, 2048), dtype=torch.float32, device=dev) if want_map else None
         bn0 = self.bns[0]
@@ -190,8 +202,17 @@ class _TrunkRunner:
             plan["handle"], ptr(images), ptr_array(packed),
             ptr_array([bn.weight for bn in self.bns]), ptr_array([bn.bias for bn in self.bns]),
             ptr_array([bn.running_mean for bn in self.bns]),
-            ptr_array([bn.running_var for bn in self.bns]), int(train), bn0.momentum, bn0.eps,
-            ptr(plan["ws"]), ptr(pooled), ptr(fmap), current_stream()), "capnet_trunk_forward")
+            ptr_array([bn.running_var for bn in self.bns]),
+            (2 if defer_stats else 1) if train else 0, bn0.momentum, bn0.eps,
+            ptr(ws), ptr(pooled), ptr(fmap), current_stream()), "capnet_trunk_forward")
+        if train and defer_stats:
+            def apply_running_stats():
+                check(_lib.lib().capnet_trunk_update_running(
+                    plan["handle"], ptr(ws), ptr_array([bn.running_mean for bn in self.bns]),
+                    ptr_array([bn.running_var for bn in self.bns]), bn0.momentum, current_stream()),
+                    "capnet_trunk_update_running")
+                torch._foreach_add_([bn.num_batches_tracked for bn in self.bns], 1)
+            return pooled, fmap, apply_running_stats
         if train:
             torch._foreach_add_([bn.num_batches_tracked for bn in self.bns], 1)
         return pooled, fmap
@@ -242,11 +263,17 @@ class EncoderCNN(nn.Module):
             self._runner[0] = _TrunkRunner(self.resnet)
         return self._runner[0]
 
-    def trunk_features(self, images):
-        """children[:-1] of the ResNet under no_grad (model.py:23-25): pooled [B, 2048]."""
+    def trunk_features(self, images, slot=0, defer_stats=False):
+        """children[:-1] of the ResNet under no_grad (model.py:23-25): pooled [B, 2048].
+        slot / defer_stats: see _TrunkRunner.forward (used by capnet.train.TrunkPipeline); with
+        defer_stats in train mode the result is (features, apply_running_stats)."""
         with torch.no_grad():
-            features, _ = self._trunk().forward(images, self.training, True, False)
-        return features.reshape(features.size(0), -1)
+            out = self._trunk().forward(images, self.training, True, False, slot=slot,
+                                        defer_stats=defer_stats and self.training)
+        features = out[0].reshape(out[0].size(0), -1)
+        if defer_stats:
+            return features, (out[2] if len(out) > 2 else None)
+        return features
 
     def forward(self, images):
         features = self.trunk_features(images)

@@ -30,20 +30,30 @@ class EncoderCNN(nn.Module):
             self._runner[0] = _TrunkRunner(self.resnet)
         return self._runner[0]
 
-    def forward(self, images):
+    def forward(self, images, slot=0, defer_stats=False):
+        """slot / defer_stats: see _TrunkRunner.forward (capnet.train.TrunkPipeline); with
+        defer_stats the result is (features, apply_running_stats or None)."""
         with torch.no_grad():
-            _, fmap = self._trunk().forward(images, self.training, False, True)
-            b, side = fmap.shape[0], fmap.shape[1]
-            out_side = self.encoded_image_size
-            if out_side == side:
-                return fmap
-            if out_side % side != 0:
-                raise CapnetError("encoded_image_size %d must be a multiple of the trunk's %d"
-                                  % (out_side, side))
-            out = torch.empty((b, out_side, out_side, 2048), dtype=torch.float32, device=fmap.device)
-            check(_lib.lib().capnet_adaptive_pool_replicate(ptr(fmap), ptr(out), b, side, out_side,
-                                                            2048, current_stream()),
-                  "capnet_adaptive_pool_replicate")
+            res = self._trunk().forward(images, self.training, False, True, slot=slot,
+                                        defer_stats=defer_stats and self.training)
+            fmap = res[1]
+            apply_fn = res[2] if len(res) > 2 else None
+            out = self._pool(fmap)
+        return (out, apply_fn) if defer_stats else out
+
+    def _pool(self, fmap):
+        """AdaptiveAvgPool2d(encoded_image_size) of the 7x7 map: an exact replication."""
+        b, side = fmap.shape[0], fmap.shape[1]
+        out_side = self.encoded_image_size
+        if out_side == side:
+            return fmap
+        if out_side % side != 0:
+            raise CapnetError("encoded_image_size %d must be a multiple of the trunk's %d"
+                              % (out_side, side))
+        out = torch.empty((b, out_side, out_side, 2048), dtype=torch.float32, device=fmap.device)
+        check(_lib.lib().capnet_adaptive_pool_replicate(ptr(fmap), ptr(out), b, side, out_side,
+                                                        2048, current_stream()),
+              "capnet_adaptive_pool_replicate")
         return out
 
 

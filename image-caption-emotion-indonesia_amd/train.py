@@ -83,57 +83,77 @@ def train_step_att(encoder, decoder, optimizer, criterion, images, captions, len
 
 
 class TrunkPipeline(object):
-    """Software pipeline over training steps: the frozen trunk of batch i+1 on the caller's stream
-    while head + decoder + loss + backward + clamp + Adam of batch i run on a side stream.
+    """Software pipeline over training steps: the frozen trunks of the next `depth` batches run on
+    their own streams while head + decoder + loss + backward + clamp + Adam of the current batch
+    run on a side stream.
 
     The ResNet-152 trunk runs under no_grad and none of its inputs depend on the parameter update
     (stylenet/model.py:23-25; train_multitask.py:163-167 only optimises the head and the decoder),
     so this reorders nothing that is ordered in the reference: every step sees exactly the
-    parameters, running statistics and random draws of the sequential loop, and produces the same
-    numbers. What it changes is that the decoder's many small, latency-bound launches no longer
-    leave the chip idle: they share it with the convolutions of the next batch.
+    parameters and random draws of the sequential loop and produces the same numbers; the BatchNorm
+    running statistics of the trunk are updated once per pass, in pass order (the passes defer the
+    update and an event chain orders it, capnet_trunk_update_running). What it changes:
+      * the decoder's many small, latency-bound launches share the chip with the convolutions of
+        the following batches instead of leaving it idle;
+      * `depth` (default 3) trunk passes are in flight: while one sits in a launch-bound bubble
+        (bn_finalize, tail fix-ups: tiny kernels between the convolutions) the convolutions of
+        another one run (tools/trunk_overlap_probe.py: 17.0 -> 15.2-16.0 ms per pass with two;
+        measured step time 18.9 / 16.1 / 15.7 / 16.8 ms at depth 1 / 2 / 3 / 4).
 
         pipe = TrunkPipeline(encoder, decoder, optimizer, criterion, grad_clip)
-        pipe.prefetch(images_0)
+        for k in range(pipe.depth): pipe.prefetch(images_k)      # up to `depth` batches ahead
         for i in range(n):
-            loss = pipe.step(captions_i, lengths_i, next_images=images_{i+1} or None)
+            loss = pipe.step(captions_i, lengths_i, next_images=images_{i+depth} or None)
         pipe.finish()            # before reading a loss or the parameters on the caller's stream
     """
 
     def __init__(self, encoder, decoder, optimizer, criterion, grad_clip, attention=False,
-                 alpha_c=1.0):
+                 alpha_c=1.0, depth=3):
         self.encoder, self.decoder, self.optimizer = encoder, decoder, optimizer
         self.criterion, self.grad_clip = criterion, grad_clip
         self.attention, self.alpha_c = attention, alpha_c
+        self.depth = max(1, int(depth))
         # The trainable half gets the HIGH-priority stream: its launches are small (a few
         # workgroups, microseconds) and form a long dependent chain, so they must be dispatched as
         # soon as they are ready; a convolution of the trunk has thousands of workgroups queued and
-        # loses nothing by yielding a few slots. (With the priorities the other way round the
-        # decoder's kernels only ran in the tails of the convolutions: measured, no overlap.)
+        # loses nothing by yielding a few slots.
         self.side = torch.cuda.Stream(priority=-1)
-        self.trunk_stream = torch.cuda.Stream()
-        self._ready = None
+        self.trunk_streams = [torch.cuda.Stream() for _ in range(self.depth)]
+        self._queue = []          # prefetched batches, oldest first: (features, ready event)
+        self._issued = 0
+        self._stats_done = None   # event after the previous pass's running-statistics update
 
     def prefetch(self, images):
         """Enqueue the trunk of `images` (ordered after the caller's current stream)."""
-        self.trunk_stream.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(self.trunk_stream):
+        if len(self._queue) >= self.depth:
+            raise RuntimeError("TrunkPipeline: %d batches already in flight" % len(self._queue))
+        slot = self._issued % self.depth
+        self._issued += 1
+        stream = self.trunk_streams[slot]
+        stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(stream):
             if self.attention:
-                feats = self.encoder(images)
+                feats, apply_stats = self.encoder(images, slot=slot, defer_stats=True)
             else:
-                feats = self.encoder.trunk_features(images)
-            done = torch.cuda.Event()
-            done.record()
-        images.record_stream(self.trunk_stream)
+                feats, apply_stats = self.encoder.trunk_features(images, slot=slot, defer_stats=True)
+            ready = torch.cuda.Event()
+            ready.record()
+            if apply_stats is not None:
+                # running statistics: after the previous pass's update, whatever stream it ran on
+                if self._stats_done is not None:
+                    stream.wait_event(self._stats_done)
+                apply_stats()
+                self._stats_done = torch.cuda.Event()
+                self._stats_done.record()
+        images.record_stream(stream)
         feats.record_stream(self.side)
-        self._ready = (feats, done)
+        self._queue.append((feats, ready))
 
     def step(self, captions, lengths, next_images=None, mode=None, tf_mask=None, loss_scale=None,
              teacher_forcing_ratio=0.8, zero_encoder_grad=True):
-        if self._ready is None:
+        if not self._queue:
             raise RuntimeError("TrunkPipeline.step() without a prefetched batch")
-        feats, done = self._ready
-        self._ready = None
+        feats, ready = self._queue.pop(0)
         if next_images is not None:
             self.prefetch(next_images)      # queued before the decoder work of this batch
         enc, dec = self.encoder, self.decoder
@@ -143,7 +163,7 @@ class TrunkPipeline(object):
         if tf_mask is not None:
             kw["tf_mask"] = tf_mask
         with torch.cuda.stream(self.side):
-            self.side.wait_event(done)
+            self.side.wait_event(ready)
             if self.attention:
                 lens = [l - 1 for l in lengths]
                 targets = ops.packed_targets(captions[:, 1:].contiguous(), lens)
@@ -168,10 +188,15 @@ class TrunkPipeline(object):
             loss = loss.detach()
         return loss
 
+    def in_flight(self):
+        return len(self._queue)
+
     def finish(self):
         """Make the caller's stream wait for everything queued by the pipeline."""
-        torch.cuda.current_stream().wait_stream(self.side)
-        torch.cuda.current_stream().wait_stream(self.trunk_stream)
+        cur = torch.cuda.current_stream()
+        cur.wait_stream(self.side)
+        for s in self.trunk_streams:
+            cur.wait_stream(s)
 
 
 def _drain(pending, meter):
@@ -180,41 +205,52 @@ def _drain(pending, meter):
     del pending[:]
 
 
-def _lookahead(loader):
-    """(index, batch, next batch or None) over a loader."""
+def _pipelined_loop(pipe, loader, device, step_kwargs):
+    """Yields (i, loss, lengths): keeps `pipe.depth` batches prefetched ahead of the step."""
     it = iter(loader)
-    try:
-        cur = next(it)
-    except StopIteration:
-        return
+    meta = []
+
+    def feed():
+        try:
+            images, captions, lengths, _ = next(it)
+        except StopIteration:
+            return False
+        pipe.prefetch(images.to(device, non_blocking=True))
+        meta.append((captions.to(device, non_blocking=True), lengths))
+        return True
+
+    for _ in range(pipe.depth):
+        if not feed():
+            break
     i = 0
-    for nxt in it:
-        yield i, cur, nxt
-        cur = nxt
+    while meta:
+        captions, lengths = meta.pop(0)
+        loss = pipe.step(captions, lengths, **step_kwargs)
+        feed()
+        yield i, loss, lengths
         i += 1
-    yield i, cur, None
 
 
 def train_factual(encoder, decoder, optimizer, criterion, data_loader, log_step, grad_clip,
                   device=None, pipeline=True):
     """stylenet/train_multitask.py:364-408. pipeline=True overlaps each batch's trainable half with
-    the next batch's trunk (TrunkPipeline); the numbers are those of the sequential loop."""
+    the trunks of the following batches (TrunkPipeline); the numbers are those of the sequential
+    loop."""
     decoder.train()
     encoder.train()
     losses = AverageMeter()
     pending = []
     device = device or next(decoder.parameters()).device
-    pipe = TrunkPipeline(encoder, decoder, optimizer, criterion, grad_clip) if pipeline else None
-    for i, (images, captions, lengths, all_captions), nxt in _lookahead(data_loader):
-        captions = captions.to(device, non_blocking=True)
-        if pipe is None:
-            loss = train_step(encoder, decoder, optimizer, criterion,
-                              images.to(device, non_blocking=True), captions, lengths, grad_clip)
-        else:
-            if i == 0:
-                pipe.prefetch(images.to(device, non_blocking=True))
-            loss = pipe.step(captions, lengths,
-                             next_images=None if nxt is None else nxt[0].to(device, non_blocking=True))
+    if pipeline:
+        pipe = TrunkPipeline(encoder, decoder, optimizer, criterion, grad_clip)
+        steps = _pipelined_loop(pipe, data_loader, device, {})
+    else:
+        pipe = None
+        steps = ((i, train_step(encoder, decoder, optimizer, criterion,
+                                images.to(device, non_blocking=True),
+                                captions.to(device, non_blocking=True), lengths, grad_clip), lengths)
+                 for i, (images, captions, lengths, _) in enumerate(data_loader))
+    for i, loss, lengths in steps:
         pending.append((loss, sum(lengths)))
         if i % log_step == 0:
             if pipe is not None:
@@ -239,17 +275,16 @@ def train_emotion(encoder, decoder, optimizer, criterion, data_loaders, tags, lo
     pipe = TrunkPipeline(encoder, decoder, optimizer, criterion, grad_clip) if pipeline else None
     for j in random.sample([i for i in range(len(tags))], len(tags)):
         pending = []
-        for i, (images, captions, lengths, all_captions), nxt in _lookahead(data_loaders[j]):
-            captions = captions.to(device, non_blocking=True)
-            if pipe is None:
-                loss = train_step(encoder, decoder, optimizer, criterion,
-                                  images.to(device, non_blocking=True), captions, lengths, grad_clip,
-                                  mode=tags[j], zero_encoder_grad=False)
-            else:
-                if i == 0:
-                    pipe.prefetch(images.to(device, non_blocking=True))
-                loss = pipe.step(captions, lengths, mode=tags[j], zero_encoder_grad=False,
-                                 next_images=None if nxt is None else nxt[0].to(device, non_blocking=True))
+        if pipe is not None:
+            steps = _pipelined_loop(pipe, data_loaders[j], device,
+                                    {"mode": tags[j], "zero_encoder_grad": False})
+        else:
+            steps = ((i, train_step(encoder, decoder, optimizer, criterion,
+                                    images.to(device, non_blocking=True),
+                                    captions.to(device, non_blocking=True), lengths, grad_clip,
+                                    mode=tags[j], zero_encoder_grad=False), lengths)
+                     for i, (images, captions, lengths, _) in enumerate(data_loaders[j]))
+        for i, loss, lengths in steps:
             pending.append((loss, sum(lengths)))
             if i % log_step == 0:
                 if pipe is not None:

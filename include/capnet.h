@@ -97,6 +97,16 @@ int capnet_trunk_forward(const capnet_trunk_t* t, const float* images_nchw,
                          float* const* bn_running_var, int train, float momentum, float eps,
                          void* workspace, float* out_pooled, float* out_map,
                          capnet_stream_t stream);
+
+/* train == 2 in capnet_trunk_forward: batch statistics as for train == 1, but the running
+ * statistics are NOT touched; the pass leaves every BatchNorm's batch mean / unbiased variance in
+ * the workspace and this call applies them (same arithmetic, momentum as given). Lets two passes
+ * be in flight on different streams (different workspaces) while the running statistics are still
+ * updated in pass order: the caller orders these calls with stream events
+ * (capnet.train.TrunkPipeline). */
+int capnet_trunk_update_running(const capnet_trunk_t* t, const void* workspace,
+                                float* const* bn_running_mean, float* const* bn_running_var,
+                                float momentum, capnet_stream_t stream);
 /* Per-convolution hipEvent timing for bench.py's roofline: while enabled, every conv kernel
  * launched by capnet_trunk_forward is bracketed by two events on the launch stream;
  * collect synchronises on them and returns the totals since the previous collect. */

@@ -102,7 +102,7 @@ def test_pipelined_steps_equal_sequential_steps(dev):
     """capnet.train.TrunkPipeline (step i's decoder overlapped with step i+1's trunk) must give the
     numbers of the sequential loop: same losses step by step, same parameters at the end."""
     from capnet.train import TrunkPipeline
-    B, V, steps = 8, 1000, 4
+    B, V, steps = 8, 1000, 5
     batches = [synthetic.make_batch(B, V, seed=s) for s in range(steps)]
     random.seed(5)
     tfs = [[random.random() < 0.8 for _ in range(24)] for _ in range(steps)]
@@ -129,11 +129,17 @@ def test_pipelined_steps_equal_sequential_steps(dev):
     enc, dec, opt = build()
     pipe = TrunkPipeline(enc, dec, opt, CrossEntropyLoss(), 0.5)
     dev_batches = [(i.to(dev), c.to(dev), l) for i, c, l in batches]
-    pipe.prefetch(dev_batches[0][0])
+    d = pipe.depth
+    assert d == 3 and steps > d
+    for k in range(d):
+        pipe.prefetch(dev_batches[k][0])      # `depth` trunk passes in flight
+    with pytest.raises(RuntimeError):
+        pipe.prefetch(dev_batches[d][0])      # one more is refused
     got = []
     for k, ((imgs, caps, lens), tf) in enumerate(zip(dev_batches, tfs)):
-        nxt = dev_batches[k + 1][0] if k + 1 < steps else None
+        nxt = dev_batches[k + d][0] if k + d < steps else None
         got.append(pipe.step(caps, lens, next_images=nxt, tf_mask=tf[:max(lens)]))
+    assert pipe.in_flight() == 0
     pipe.finish()
     torch.cuda.synchronize()
     got = [float(l.item()) for l in got]
@@ -150,7 +156,9 @@ def test_pipelined_steps_equal_sequential_steps(dev):
         else:
             # (the differing embedding rows feed the later steps, so the rest agrees closely, not bitwise)
             assert d.max().item() <= 2e-3 * ref_params[k].abs().max().item() + 1e-7, k
-    assert torch.equal(enc.resnet[7][2].bn3.running_mean, ref_rm)      # trunk statistics untouched
+    # the trunk's running statistics saw the four passes in order (deferred, event-ordered updates)
+    assert torch.equal(enc.resnet[7][2].bn3.running_mean, ref_rm)
+    assert int(enc.resnet[1].num_batches_tracked) == steps
     with pytest.raises(RuntimeError):
         pipe.step(dev_batches[0][1], dev_batches[0][2])                # nothing prefetched
 
