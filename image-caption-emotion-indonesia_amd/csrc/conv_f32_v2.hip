@@ -77,7 +77,14 @@ __device__ __forceinline__ void gload16(f32x4& dst, const float* sbase, unsigned
   asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff_bytes), "s"(sbase) : "memory");
 }
 
-template <int BM, int BN, bool EPI>
+// MODE (compile time, chosen by the launcher): bit 0 PRE = the previous BatchNorm (+ReLU) is
+// applied while the A tile is staged; bit 1 MASK = some staged element must be forced to 0
+// (padding taps of a 3x3, rows past M in a ragged last M tile). As runtime flags hipcc
+// if-converted both paths: every k-tile paid fma + med3 + 8 v_cndmask whether it needed them or
+// not (measured 2.5-4 VALU instructions per MFMA, and f32 MFMA shares its pipe with the VALU).
+// Specialised: a 1x1 conv on an activated input stages with no VALU at all, conv3 with fma + max,
+// conv2 with fma + med3.
+template <int BM, int BN, bool EPI, int MODE>
 __global__ __launch_bounds__(kGemmThreads) void conv_f32_v2_kernel(ConvArgs2 g) {
   constexpr int BK = 16;
   constexpr int LDA = BM + 4;
@@ -127,13 +134,13 @@ __global__ __launch_bounds__(kGemmThreads) void conv_f32_v2_kernel(ConvArgs2 g) 
       boff[ps] = b * g.sxb + 4 * kc;
     }
   }
-  const bool pre = g.in_scale != nullptr;
+  constexpr bool pre = (MODE & 1) != 0;
   const float inf = __builtin_inff();
   const float lo = g.relu_in ? 0.f : -inf;  // v_med3(x, lo, hi): relu iff lo == 0
 
   // need_mask: some staged element must become 0 (padding taps; rows past M in a ragged last
   // M tile). Otherwise store() issues no VALU at all besides the prologue's fma.
-  const bool need_mask = pre || g.pad > 0 || (g.M % BM) != 0;
+  constexpr bool need_mask = (MODE & 2) != 0;
   unsigned voff[PASSES];         // byte offset of this thread's float4 for the current tap
   float hi[PASSES], lw[PASSES];  // v_med3(x, lw, hi): (lo, +inf) inside the image, (0, 0) outside
   int tap = (kt0 * BK) / g.Cin, c0 = kt0 * BK - tap * g.Cin;
@@ -145,8 +152,10 @@ __global__ __launch_bounds__(kGemmThreads) void conv_f32_v2_kernel(ConvArgs2 g) 
       const bool inb = (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
       const int ihc = min(max(ih, 0), g.H - 1), iwc = min(max(iw, 0), g.W - 1);
       voff[ps] = (unsigned)(boff[ps] + ihc * g.sxh + iwc * g.sxw) * 4u;
-      hi[ps] = inb ? inf : 0.f;
-      lw[ps] = inb ? lo : 0.f;
+      if (need_mask) {
+        hi[ps] = inb ? inf : 0.f;
+        lw[ps] = inb ? lo : 0.f;
+      }
     }
   };
   set_tap(tap);
@@ -191,6 +200,7 @@ __global__ __launch_bounds__(kGemmThreads) void conv_f32_v2_kernel(ConvArgs2 g) 
   // hi/ok of the tile that was LOADED (set_tap above may already have moved on): keep a copy
   float hi_ld[PASSES], lw_ld[PASSES];
   auto snapshot = [&]() {
+    if (!need_mask) return;
 #pragma unroll
     for (int ps = 0; ps < PASSES; ++ps) {
       hi_ld[ps] = hi[ps];
@@ -201,10 +211,17 @@ __global__ __launch_bounds__(kGemmThreads) void conv_f32_v2_kernel(ConvArgs2 g) 
   auto store = [&](int stage) {
     // every load and DMA of this tile has landed after this wait (vmcnt retires in order); the
     // "+v" operands make the loaded registers defined HERE for the compiler
-    if (PASSES == 2)
-      asm volatile("s_waitcnt vmcnt(0)" : "+v"(av[0]), "+v"(av[PASSES - 1]), "+v"(scv), "+v"(shv)::"memory");
-    else
-      asm volatile("s_waitcnt vmcnt(0)" : "+v"(av[0]), "+v"(scv), "+v"(shv)::"memory");
+    if (pre) {
+      if (PASSES == 2)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(av[0]), "+v"(av[PASSES - 1]), "+v"(scv), "+v"(shv)::"memory");
+      else
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(av[0]), "+v"(scv), "+v"(shv)::"memory");
+    } else {
+      if (PASSES == 2)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(av[0]), "+v"(av[PASSES - 1])::"memory");
+      else
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(av[0])::"memory");
+    }
     float* d0 = lds + stage * A_ST + awr;
 #pragma unroll
     for (int ps = 0; ps < PASSES; ++ps) {
@@ -223,6 +240,12 @@ __global__ __launch_bounds__(kGemmThreads) void conv_f32_v2_kernel(ConvArgs2 g) 
         x1 = __builtin_amdgcn_fmed3f(x1, l, h);
         x2 = __builtin_amdgcn_fmed3f(x2, l, h);
         x3 = __builtin_amdgcn_fmed3f(x3, l, h);
+      } else if (pre) {
+        // nothing to zero: only the ReLU of the folded BatchNorm (lo = 0) or nothing (lo = -inf)
+        x0 = fmaxf(x0, lo);
+        x1 = fmaxf(x1, lo);
+        x2 = fmaxf(x2, lo);
+        x3 = fmaxf(x3, lo);
       }
       float* d = d0 + ps * 64;
       d[0 * LDA] = x0;
@@ -516,15 +539,30 @@ static void launch_v2(ConvArgs2& g, hipStream_t stream) {
     if (sp > 1) { g.full_tiles = full; g.split = sp; g.kps = kps; }
   }
   const int rem = T - g.full_tiles;
+  // staging mode of the A tile (see the kernel's MODE): PRE iff a BatchNorm is folded into the
+  // load, MASK iff something must be zeroed (padding, ragged last M tile)
+  const int mode = (g.in_scale ? 1 : 0) | ((g.pad > 0 || (g.M % BM) != 0) ? 2 : 0);
+  const dim3 grid(g.full_tiles + rem * g.split), block(kGemmThreads);
+#define CAPNET_CONV_LAUNCH(E, MD) \
+  hipLaunchKernelGGL((conv_f32_v2_kernel<BM, BN, E, MD>), grid, block, 0, stream, g)
   if (g.out_scale) {
-    hipLaunchKernelGGL((conv_f32_v2_kernel<BM, BN, true>), dim3(g.full_tiles + rem * g.split),
-                       dim3(kGemmThreads), 0, stream, g);
+    switch (mode) {
+      case 0: CAPNET_CONV_LAUNCH(true, 0); break;
+      case 1: CAPNET_CONV_LAUNCH(true, 1); break;
+      case 2: CAPNET_CONV_LAUNCH(true, 2); break;
+      default: CAPNET_CONV_LAUNCH(true, 3); break;
+    }
     if (rem > 0)
       hipLaunchKernelGGL((conv_tail_fixup_kernel<BM, BN, true>), dim3(rem), dim3(1024), 0, stream, g);
     return;
   }
-  hipLaunchKernelGGL((conv_f32_v2_kernel<BM, BN, false>), dim3(g.full_tiles + rem * g.split),
-                     dim3(kGemmThreads), 0, stream, g);
+  switch (mode) {
+    case 0: CAPNET_CONV_LAUNCH(false, 0); break;
+    case 1: CAPNET_CONV_LAUNCH(false, 1); break;
+    case 2: CAPNET_CONV_LAUNCH(false, 2); break;
+    default: CAPNET_CONV_LAUNCH(false, 3); break;
+  }
+#undef CAPNET_CONV_LAUNCH
   if (rem > 0)
     hipLaunchKernelGGL((conv_tail_fixup_kernel<BM, BN, false>), dim3(rem), dim3(1024), 0, stream, g);
 }
