@@ -47,7 +47,23 @@ struct ConvArgs2 {
   const float* out_shift;
   const float* res;
   int relu_out;
+  // exact n / d for n < 2^24 as (n * mul) >> sh (host: magic_div): the per-thread pixel
+  // decomposition m -> (image, oh, ow) costs 3 VALU per division instead of ~35
+  unsigned ohw_mul, ohw_sh, ow_mul, ow_sh;
 };
+
+// mul = ceil(2^k / d), k = 24 + ceil(log2 d): exact quotient for every n < 2^24
+static void magic_div(unsigned d, unsigned* mul, unsigned* sh) {
+  unsigned l = 0;
+  while ((1u << l) < d) ++l;
+  const unsigned k = 24 + l;
+  const unsigned long long m = ((1ull << k) + d - 1) / d;
+  *mul = (unsigned)m;   // < 2^25
+  *sh = k;
+}
+__device__ __forceinline__ unsigned fast_div(unsigned n, unsigned mul, unsigned sh) {
+  return (unsigned)(((unsigned long long)n * mul) >> sh);
+}
 
 // LDS-DMA of 16 B per lane: LDS[m0_base + 16*lane] = *(sbase + voff). Inline asm on purpose:
 // with the builtin, hipcc cannot tell the DMA's LDS destination from the stage being read and
@@ -125,9 +141,9 @@ __global__ __launch_bounds__(kGemmThreads) void conv_f32_v2_kernel(ConvArgs2 g) 
     for (int ps = 0; ps < PASSES; ++ps) {
       const int m = m0 + rl + ps * 64;
       const int mc = m < g.M ? m : g.M - 1;
-      const int b = mc / ohw;
+      const int b = (int)fast_div((unsigned)mc, g.ohw_mul, g.ohw_sh);
       const int rem = mc - b * ohw;
-      const int oh = rem / g.OW;
+      const int oh = (int)fast_div((unsigned)rem, g.ow_mul, g.ow_sh);
       const int ow = rem - oh * g.OW;
       ih0[ps] = m < g.M ? oh * g.stride - g.pad : -(1 << 20);  // rows past M: never in the image
       iw0[ps] = ow * g.stride - g.pad;
@@ -362,15 +378,36 @@ __global__ __launch_bounds__(kGemmThreads) void conv_f32_v2_kernel(ConvArgs2 g) 
     return;
   }
   // ---- epilogue: raw output + batch-statistics partials ----
+  if (!need_mask) {
+    // every row of the tile is inside M (MASK is set otherwise): no guards, one scalar base and
+    // 32-bit byte offsets (the launcher checks M*Cout*4 < 4 GB) -- one v_add per store instead of
+    // a compare, an exec mask and a 64-bit multiply-add
+    const unsigned step = (unsigned)g.Cout * 4u;
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int n = n0 + wn * (BN / 2) + nt * 32 + li;
+    for (int nt = 0; nt < NT; ++nt) {
+      const unsigned n = (unsigned)(n0 + wn * (BN / 2) + nt * 32 + li);
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
+      for (int mt = 0; mt < MT; ++mt) {
+        const unsigned row0 = (unsigned)(m0 + wm * (BM / 2) + mt * 32 + 4 * lh);
+        const unsigned base = (row0 * (unsigned)g.Cout + n) * 4u;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * (BM / 2) + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (m < g.M) g.y[(long)m * g.Cout + n] = acc[mt][nt][r];
+        for (int r = 0; r < 16; ++r) {
+          const unsigned off = base + (unsigned)((r & 3) + 8 * (r >> 2)) * step;
+          asm volatile("global_store_dword %0, %1, %2" ::"v"(off), "v"(acc[mt][nt][r]), "s"(g.y) : "memory");
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = n0 + wn * (BN / 2) + nt * 32 + li;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wm * (BM / 2) + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (m < g.M) g.y[(long)m * g.Cout + n] = acc[mt][nt][r];
+        }
       }
     }
   }
@@ -541,7 +578,9 @@ static void launch_v2(ConvArgs2& g, hipStream_t stream) {
   const int rem = T - g.full_tiles;
   // staging mode of the A tile (see the kernel's MODE): PRE iff a BatchNorm is folded into the
   // load, MASK iff something must be zeroed (padding, ragged last M tile)
-  const int mode = (g.in_scale ? 1 : 0) | ((g.pad > 0 || (g.M % BM) != 0) ? 2 : 0);
+  // (MASK also when the output does not fit 32-bit byte offsets: the unguarded store path uses them)
+  const int mode = (g.in_scale ? 1 : 0) |
+                   ((g.pad > 0 || (g.M % BM) != 0 || (long)g.M * g.Cout * 4 >= (1L << 32)) ? 2 : 0);
   const dim3 grid(g.full_tiles + rem * g.split), block(kGemmThreads);
 #define CAPNET_CONV_LAUNCH(E, MD) \
   hipLaunchKernelGGL((conv_f32_v2_kernel<BM, BN, E, MD>), grid, block, 0, stream, g)
@@ -600,8 +639,10 @@ int conv2d_fwd_v2(const float* x, long sxb, long sxh, long sxw, const float* wk,
   g.OW = (W + 2 * pad - KW) / stride + 1;
   g.sxb = (int)sxb; g.sxh = (int)sxh; g.sxw = (int)sxw;
   const long M = (long)Bn * g.OH * g.OW;
-  CAPNET_REQUIRE(M < (1L << 31), "conv2d_fwd_v2: too many output pixels");
+  CAPNET_REQUIRE(M < (1L << 24), "conv2d_fwd_v2: too many output pixels (%ld >= 2^24)", M);
   g.M = (int)M;
+  magic_div((unsigned)(g.OH * g.OW), &g.ohw_mul, &g.ohw_sh);
+  magic_div((unsigned)g.OW, &g.ow_mul, &g.ow_sh);
   g.Kw = Kw;
   g.relu_in = relu_in;
   g.slabs = slabs;
