@@ -50,6 +50,7 @@ struct ConvArgs2 {
   // exact n / d for n < 2^24 as (n * mul) >> sh (host: magic_div): the per-thread pixel
   // decomposition m -> (image, oh, ow) costs 3 VALU per division instead of ~35
   unsigned ohw_mul, ohw_sh, ow_mul, ow_sh;
+  unsigned tn_mul, tn_sh, cin_mul, cin_sh, kw_mul, kw_sh, split_mul, split_sh;  // tiles_n, Cin, KW, split
 };
 
 // mul = ceil(2^k / d), k = 24 + ceil(log2 d): exact quotient for every n < 2^24
@@ -124,12 +125,13 @@ __global__ __launch_bounds__(kGemmThreads) void conv_f32_v2_kernel(ConvArgs2 g) 
     id = xcd_remap(blockIdx.x, g.full_tiles);
   } else {
     const int u = blockIdx.x - g.full_tiles;
-    id = g.full_tiles + u / g.split;
-    slice = u - (u / g.split) * g.split;
+    const int uq = (int)fast_div((unsigned)u, g.split_mul, g.split_sh);
+    id = g.full_tiles + uq;
+    slice = u - uq * g.split;
     kt0 = slice * g.kps;
     kt1 = min(nk, kt0 + g.kps);
   }
-  const int tm = id / g.tiles_n, tn = id - tm * g.tiles_n;
+  const int tm = (int)fast_div((unsigned)id, g.tn_mul, g.tn_sh), tn = id - tm * g.tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
 
   // ---- A staging geometry (fixed per thread) ----
@@ -159,9 +161,9 @@ __global__ __launch_bounds__(kGemmThreads) void conv_f32_v2_kernel(ConvArgs2 g) 
   constexpr bool need_mask = (MODE & 2) != 0;
   unsigned voff[PASSES];         // byte offset of this thread's float4 for the current tap
   float hi[PASSES], lw[PASSES];  // v_med3(x, lw, hi): (lo, +inf) inside the image, (0, 0) outside
-  int tap = (kt0 * BK) / g.Cin, c0 = kt0 * BK - tap * g.Cin;
+  int tap = (int)fast_div((unsigned)(kt0 * BK), g.cin_mul, g.cin_sh), c0 = kt0 * BK - tap * g.Cin;
   auto set_tap = [&](int t) {
-    const int r = t / g.KW, s = t - r * g.KW;
+    const int r = (int)fast_div((unsigned)t, g.kw_mul, g.kw_sh), s = t - r * g.KW;
 #pragma unroll
     for (int ps = 0; ps < PASSES; ++ps) {
       const int ih = ih0[ps] + r, iw = iw0[ps] + s;
@@ -567,6 +569,9 @@ static void launch_v2(ConvArgs2& g, hipStream_t stream) {
   g.tiles_m = cdiv(g.M, BM);
   g.tiles_n = g.Cout / BN;
   const int T = g.tiles_m * g.tiles_n;
+  magic_div((unsigned)g.tiles_n, &g.tn_mul, &g.tn_sh);
+  magic_div((unsigned)g.Cin, &g.cin_mul, &g.cin_sh);
+  magic_div((unsigned)g.KW, &g.kw_mul, &g.kw_sh);
   g.full_tiles = T;
   g.split = 1;
   g.kps = g.Kw / 16;
@@ -575,6 +580,7 @@ static void launch_v2(ConvArgs2& g, hipStream_t stream) {
     plan_tail(T, g.Kw / 16, BM, BN, &full, &sp, &kps);
     if (sp > 1) { g.full_tiles = full; g.split = sp; g.kps = kps; }
   }
+  magic_div((unsigned)g.split, &g.split_mul, &g.split_sh);
   const int rem = T - g.full_tiles;
   // staging mode of the A tile (see the kernel's MODE): PRE iff a BatchNorm is folded into the
   // load, MASK iff something must be zeroed (padding, ragged last M tile)
