@@ -342,6 +342,47 @@ def main():
                 "traffic": pmc_traffic("lstm_step_bytes_per_launch"),
                 "bytes_per_step": step_bytes, "us_per_step": round(us, 2)}
 
+    # the two other rooflines SURVEY.md 8(d) names, timed with events on the launch stream:
+    # the vocabulary projection (MFMA) and the attention step after the encoder_att hoist (HBM)
+    extra = None
+    if rank == 0 and not args.no_lstm_roofline:
+        def timed(fn, reps):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) * 1e3 / reps      # us
+        Nt, Hh = sum(lengths), 512
+        hid = torch.randn(Nt, Hh, device=dev)
+        cw = torch.randn(V, Hh, device=dev) * 0.05
+        cb = torch.zeros(V, device=dev)
+        us_v = timed(lambda: ops.sgemm(hid, cw, transB=True, bias=cb), 20)
+        fl = 2.0 * Nt * V * Hh
+        bb, P, A, Cf = 64, 196, 512, 2048
+        att1 = torch.randn(bb, P, A, device=dev)
+        feat = torch.randn(bb, P, Cf, device=dev).abs()
+        z = torch.randn(bb, A + Cf, device=dev)
+        wf, bf = torch.randn(1, A, device=dev) * 0.1, torch.zeros(1, device=dev)
+        us_a = timed(lambda: ops.attention_step(att1, feat, z.clone(), A, wf, bf), 20)
+        us_clone = timed(lambda: z.clone(), 20)
+        us_a -= us_clone
+        by = bb * (P * A * 4 + P * Cf * 4)
+        extra = {
+            "vocab_projection": {"bound": "mfma", "kernel": "gemm_f32_kernel<128,128> (logits = hiddens . C^T, "
+                                 "%d x %d x %d)" % (Nt, V, Hh), "achieved": round(fl / us_v / 1e6, 2),
+                                 "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                 "frac": round(fl / us_v / 1e6 / MFMA_F32_PEAK_TFLOPS, 4), "us": round(us_v, 1)},
+            "attention_step": {"bound": "hbm", "kernel": "att_scores_fwd + att_context_fwd (b=64, P=196, A=512, "
+                               "C=2048; att1 + feature map read once per row)", "achieved": round(by / us_a / 1e3, 1),
+                               "peak": 8000.0, "unit": "GB/s", "frac": round(by / us_a / 1e3 / 8000.0, 4),
+                               "bytes_per_step": by, "us_per_step": round(us_a, 1)},
+        }
+
     if rank == 0:
         total_images = B * world * args.steps
         out = {
@@ -367,6 +408,7 @@ def main():
             "loss_last": round(float(last.item()), 5),
             "roofline": roofline,
             "roofline_lstm_step": lstm,
+            "roofline_other": extra,
         }
         if args.decoder != "factored":
             out["config"]["workload"] = out["config"]["workload"].replace(
