@@ -41,6 +41,7 @@ SIGNATURES = {
     "capnet_trunk_forward": (_i, [_vp, _vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp),
                                   C.POINTER(_vp), C.POINTER(_vp), _i, C.c_float, C.c_float, _vp,
                                   _vp, _vp, _vp]),
+    "capnet_trunk_set_tail_balance": (_i, [_vp, _i]),
     "capnet_trunk_update_running": (_i, [_vp, _vp, C.POINTER(_vp), C.POINTER(_vp), C.c_float, _vp]),
     "capnet_pack_conv_weight": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "capnet_adaptive_pool_replicate": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),

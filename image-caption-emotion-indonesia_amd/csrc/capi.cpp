@@ -78,6 +78,9 @@ int capnet_trunk_forward(const capnet_trunk_t* t, const float* images_nchw,
                        bn_bias, bn_running_mean, bn_running_var, train, momentum, eps,
                        reinterpret_cast<float*>(workspace), out_pooled, out_map, S(stream));
 }
+int capnet_trunk_set_tail_balance(const capnet_trunk_t* t, int on) {
+  return trunk_set_tail_balance(reinterpret_cast<Trunk*>(const_cast<capnet_trunk_t*>(t)), on);
+}
 int capnet_trunk_update_running(const capnet_trunk_t* t, const void* workspace,
                                 float* const* bn_running_mean, float* const* bn_running_var,
                                 float momentum, capnet_stream_t stream) {

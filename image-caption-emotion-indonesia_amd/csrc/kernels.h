@@ -75,6 +75,7 @@ int trunk_conv_kmajor(const Trunk* t, int i);
 double trunk_flops(const Trunk* t);
 int trunk_set_timing(Trunk* t, int enable);
 int trunk_collect_timing(Trunk* t, double* conv_ms, long* conv_launches, double* conv_flops);
+int trunk_set_tail_balance(Trunk* t, int on);
 int trunk_update_running(Trunk* t, const float* workspace, float* const* bn_rmean, float* const* bn_rvar,
                          float momentum, hipStream_t stream);
 int trunk_forward(Trunk* t, const float* images_nchw, const float* const* w_packed,

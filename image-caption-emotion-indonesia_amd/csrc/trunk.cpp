@@ -39,6 +39,11 @@ struct Trunk {
   int final_side;
   // optional per-convolution hipEvent timing (bench.py roofline): pairs recorded on the launch
   // stream around every conv kernel while enabled, summed by trunk_collect_timing
+  // K-sliced tail balancing of the convs (conv_f32_v2.hip): pays when one pass has the chip to
+  // itself; with several passes in flight (TrunkPipeline) the other passes fill the idle CUs of a
+  // partially filled last round and the slabs + fix-up launches only cost (measured +2 % images/s
+  // without them), so the pipeline turns it off
+  bool tail_balance = true;
   bool timing = false;
   std::vector<hipEvent_t> ev;
   double timed_flops = 0;
@@ -132,6 +137,12 @@ int trunk_set_timing(Trunk* t, int enable) {
 
 // Synchronises on the recorded events; returns total conv-kernel ms, launches and flops since
 // the last collect.
+int trunk_set_tail_balance(Trunk* t, int on) {
+  CAPNET_REQUIRE(t != nullptr, "trunk_set_tail_balance: null");
+  t->tail_balance = on != 0;
+  return kOk;
+}
+
 int trunk_collect_timing(Trunk* t, double* conv_ms, long* conv_launches, double* conv_flops) {
   CAPNET_REQUIRE(t && conv_ms && conv_launches && conv_flops, "trunk_collect_timing: null");
   // Time during which at least one timed conv launch was running: the union of the [start, end]
@@ -225,7 +236,8 @@ int conv_bn(const Ctx& c, int i, const float* x, long sxb, long sxh, long sxw, l
                    "trunk: conv %d planned for the K-major kernel but its operands are not eligible", i);
     rc = conv2d_fwd_v2(x, sxb, sxh, sxw, c.w[i], d.Kw, y, in_scale, in_shift, relu_in,
                        c.train ? psum : nullptr, c.train ? psq : nullptr, c.t->B, d.H, d.W, d.Cin,
-                       d.Cout, d.k, d.k, d.stride, d.pad, tile, c.ws + c.t->off_slab, c.s);
+                       d.Cout, d.k, d.k, d.stride, d.pad, tile,
+                       c.t->tail_balance ? c.ws + c.t->off_slab : nullptr, c.s);
   } else {
     rc = conv2d_fwd(x, sxb, sxh, sxw, sxc, c.w[i], d.Kw, y, in_scale, in_shift, relu_in,
                     c.train ? psum : nullptr, c.train ? psq : nullptr, c.t->B, d.H, d.W, d.Cin,
@@ -263,7 +275,8 @@ int conv_folded(const Ctx& c, int i, const float* x, const float* res, int relu,
   }
   const int rc = conv2d_fwd_v2(x, sb, sh, sw, c.w[i], d.Kw, y, nullptr, nullptr, 0, nullptr, nullptr,
                                c.t->B, d.H, d.W, d.Cin, d.Cout, d.k, d.k, d.stride, d.pad, 0,
-                               c.ws + c.t->off_slab, c.s, c.scale(i), c.shift(i), res, relu);
+                               c.t->tail_balance ? c.ws + c.t->off_slab : nullptr, c.s, c.scale(i),
+                               c.shift(i), res, relu);
   if (c.t->timing) {
     CAPNET_HIP_CHECK(hipEventRecord(e1, c.s));
     c.t->ev.push_back(e0);

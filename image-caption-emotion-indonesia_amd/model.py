@@ -181,7 +181,8 @@ class _TrunkRunner:
             self.packed, self.packed_key = packed, key
         return self.packed
 
-    def forward(self, images, train, want_pooled, want_map, slot=0, defer_stats=False):
+    def forward(self, images, train, want_pooled, want_map, slot=0, defer_stats=False,
+                balance_tails=True):
         """defer_stats (train mode only): leave the running statistics alone and return a callable
         that applies this pass's update (capnet_trunk_update_running + num_batches_tracked) on the
         then-current stream; the caller decides when (TrunkPipeline orders passes with events)."""
@@ -195,6 +196,10 @@ class _TrunkRunner:
         packed = self._pack(plan, dev)
         side = plan["side"]
         ws = self._workspace(plan, slot, dev)
+        if plan.get("balance_tails", True) != bool(balance_tails):
+            check(_lib.lib().capnet_trunk_set_tail_balance(plan["handle"], int(bool(balance_tails))),
+                  "capnet_trunk_set_tail_balance")
+            plan["balance_tails"] = bool(balance_tails)
         pooled = torch.empty((b, 2048), dtype=torch.float32, device=dev) if want_pooled else None
         fmap = torch.empty((b, side, side, 2048), dtype=torch.float32, device=dev) if want_map else None
         bn0 = self.bns[0]
@@ -263,13 +268,14 @@ class EncoderCNN(nn.Module):
             self._runner[0] = _TrunkRunner(self.resnet)
         return self._runner[0]
 
-    def trunk_features(self, images, slot=0, defer_stats=False):
+    def trunk_features(self, images, slot=0, defer_stats=False, balance_tails=True):
         """children[:-1] of the ResNet under no_grad (model.py:23-25): pooled [B, 2048].
         slot / defer_stats: see _TrunkRunner.forward (used by capnet.train.TrunkPipeline); with
         defer_stats in train mode the result is (features, apply_running_stats)."""
         with torch.no_grad():
             out = self._trunk().forward(images, self.training, True, False, slot=slot,
-                                        defer_stats=defer_stats and self.training)
+                                        defer_stats=defer_stats and self.training,
+                                        balance_tails=balance_tails)
         features = out[0].reshape(out[0].size(0), -1)
         if defer_stats:
             return features, (out[2] if len(out) > 2 else None)

@@ -133,9 +133,11 @@ class TrunkPipeline(object):
         stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(stream):
             if self.attention:
-                feats, apply_stats = self.encoder(images, slot=slot, defer_stats=True)
+                feats, apply_stats = self.encoder(images, slot=slot, defer_stats=True,
+                                                  balance_tails=self.depth < 2)
             else:
-                feats, apply_stats = self.encoder.trunk_features(images, slot=slot, defer_stats=True)
+                feats, apply_stats = self.encoder.trunk_features(images, slot=slot, defer_stats=True,
+                                                                 balance_tails=self.depth < 2)
             ready = torch.cuda.Event()
             ready.record()
             if apply_stats is not None:

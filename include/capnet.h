@@ -104,6 +104,11 @@ int capnet_trunk_forward(const capnet_trunk_t* t, const float* images_nchw,
  * be in flight on different streams (different workspaces) while the running statistics are still
  * updated in pass order: the caller orders these calls with stream events
  * (capnet.train.TrunkPipeline). */
+/* Tail balancing of the convolutions (tiles past the last full round of 256 CUs are cut into K
+ * slices summed by a fix-up launch): on by default; pays for a single pass, costs when several
+ * passes share the chip (capnet.train.TrunkPipeline turns it off). Applies to later forwards. */
+int capnet_trunk_set_tail_balance(const capnet_trunk_t* t, int on);
+
 int capnet_trunk_update_running(const capnet_trunk_t* t, const void* workspace,
                                 float* const* bn_running_mean, float* const* bn_running_var,
                                 float momentum, capnet_stream_t stream);
