@@ -98,9 +98,7 @@ def test_three_train_steps_match_the_cpu_oracle(dev, kind):
     assert ref_losses[2] < ref_losses[0]      # the updates did something
 
 
-def test_pipelined_steps_equal_sequential_steps(dev):
-    """capnet.train.TrunkPipeline (step i's decoder overlapped with step i+1's trunk) must give the
-    numbers of the sequential loop: same losses step by step, same parameters at the end."""
+def _pipeline_vs_sequential(dev, tuning):
     from capnet.train import TrunkPipeline
     B, V, steps = 8, 1000, 5
     batches = [synthetic.make_batch(B, V, seed=s) for s in range(steps)]
@@ -127,7 +125,7 @@ def test_pipelined_steps_equal_sequential_steps(dev):
     ref_rm = enc.resnet[7][2].bn3.running_mean.clone()
 
     enc, dec, opt = build()
-    pipe = TrunkPipeline(enc, dec, opt, CrossEntropyLoss(), 0.5)
+    pipe = TrunkPipeline(enc, dec, opt, CrossEntropyLoss(), 0.5, shared_chip_tuning=tuning)
     dev_batches = [(i.to(dev), c.to(dev), l) for i, c, l in batches]
     d = pipe.depth
     assert d == 3 and steps > d
@@ -143,24 +141,44 @@ def test_pipelined_steps_equal_sequential_steps(dev):
     pipe.finish()
     torch.cuda.synchronize()
     got = [float(l.item()) for l in got]
-    print("sequential", seq, "pipelined", got)
+    print("tuning", tuning, "sequential", seq, "pipelined", got)
+    assert int(enc.resnet[1].num_batches_tracked) == steps
+    with pytest.raises(RuntimeError):
+        pipe.step(dev_batches[0][1], dev_batches[0][2])                # nothing prefetched
+    return seq, got, ref_params, dec.state_dict(), ref_rm, enc.resnet[7][2].bn3.running_mean
+
+
+def test_pipelined_steps_equal_sequential_steps(dev):
+    """capnet.train.TrunkPipeline with the sequential schedule's kernels (shared_chip_tuning=False):
+    three trunk passes in flight, the decoder half on a side stream -- and the numbers of the
+    sequential loop: same losses step by step, same parameters, same running statistics."""
+    seq, got, ref_params, params, ref_rm, rm = _pipeline_vs_sequential(dev, False)
     for a, b in zip(got, seq):
         assert abs(a - b) / abs(b) < 2e-6
-    for k, v in dec.state_dict().items():
-        d = (v - ref_params[k]).abs()
+    for k, v in params.items():
+        dlt = (v - ref_params[k]).abs()
         if k == "B.weight":
             # embedding gradients are scattered with float atomics (order varies run to run) and
             # Adam's first steps turn a +-1e-9 gradient into a +-lr update: a handful of elements
             # may differ by O(lr); everything else must agree
-            assert (d > 1e-6).float().mean().item() < 1e-3
+            assert (dlt > 1e-6).float().mean().item() < 1e-3
         else:
             # (the differing embedding rows feed the later steps, so the rest agrees closely, not bitwise)
-            assert d.max().item() <= 2e-3 * ref_params[k].abs().max().item() + 1e-7, k
-    # the trunk's running statistics saw the four passes in order (deferred, event-ordered updates)
-    assert torch.equal(enc.resnet[7][2].bn3.running_mean, ref_rm)
-    assert int(enc.resnet[1].num_batches_tracked) == steps
-    with pytest.raises(RuntimeError):
-        pipe.step(dev_batches[0][1], dev_batches[0][2])                # nothing prefetched
+            assert dlt.max().item() <= 2e-3 * ref_params[k].abs().max().item() + 1e-7, k
+    # the trunk's running statistics saw the passes in order (deferred, event-ordered updates)
+    assert torch.equal(rm, ref_rm)
+
+
+def test_pipelined_steps_with_shared_chip_tuning_stay_close(dev):
+    """Default pipeline: no tail balancing and the 128x64 tile on the large layers while passes
+    share the chip. Only the order of fp32 additions changes (BatchNorm partial sums), which an
+    8-image batch statistic turns into a ~3e-5 difference of the first loss; Adam's sign-like first
+    updates then let the two runs drift apart slowly."""
+    seq, got, ref_params, params, ref_rm, rm = _pipeline_vs_sequential(dev, True)
+    assert abs(got[0] - seq[0]) / abs(seq[0]) < 1e-4
+    for a, b in zip(got, seq):
+        assert abs(a - b) / abs(b) < 2e-3
+    assert (rm - ref_rm).abs().max().item() <= 5e-3 * ref_rm.abs().max().item()
 
 
 def test_training_loops_run_pipelined_and_sequential(dev, capsys):
@@ -191,6 +209,6 @@ def test_training_loops_run_pipelined_and_sequential(dev, capsys):
     fac_s, emo_s = run(False)
     out = capsys.readouterr().out
     assert "[FAC]" in out and "[HAP]" in out and "[SAD]" in out
-    assert abs(fac_p - fac_s) / fac_s < 1e-5
+    assert abs(fac_p - fac_s) / fac_s < 2e-3
     for a, b in zip(emo_p, emo_s):
-        assert abs(a - b) / b < 1e-5
+        assert abs(a - b) / b < 2e-3
