@@ -181,6 +181,21 @@ class _TrunkRunner:
             self.packed, self.packed_key = packed, key
         return self.packed
 
+    def _tables(self, packed):
+        """ctypes pointer tables of the C call (packed weights, BN weight / bias / running mean /
+        running var), rebuilt only when a tensor moved: building them is ~1 ms of host time per
+        pass otherwise."""
+        # (module.to() / re-packing replace the tensors; load_state_dict copies in place)
+        key = (id(packed), self.bns[0].weight.data_ptr(), self.bns[-1].running_var.data_ptr(),
+               self.bns[len(self.bns) // 2].running_mean.data_ptr())
+        if getattr(self, "_table_key", None) != key:
+            self._table_val = (ptr_array(packed), ptr_array([bn.weight for bn in self.bns]),
+                               ptr_array([bn.bias for bn in self.bns]),
+                               ptr_array([bn.running_mean for bn in self.bns]),
+                               ptr_array([bn.running_var for bn in self.bns]))
+            self._table_key = key
+        return self._table_val
+
     def forward(self, images, train, want_pooled, want_map, slot=0, defer_stats=False,
                 balance_tails=True):
         """defer_stats (train mode only): leave the running statistics alone and return a callable
@@ -203,18 +218,15 @@ class _TrunkRunner:
         pooled = torch.empty((b, 2048), dtype=torch.float32, device=dev) if want_pooled else None
         fmap = torch.empty((b, side, side, 2048), dtype=torch.float32, device=dev) if want_map else None
         bn0 = self.bns[0]
+        tables = self._tables(packed)
         check(_lib.lib().capnet_trunk_forward(
-            plan["handle"], ptr(images), ptr_array(packed),
-            ptr_array([bn.weight for bn in self.bns]), ptr_array([bn.bias for bn in self.bns]),
-            ptr_array([bn.running_mean for bn in self.bns]),
-            ptr_array([bn.running_var for bn in self.bns]),
+            plan["handle"], ptr(images), tables[0], tables[1], tables[2], tables[3], tables[4],
             (2 if defer_stats else 1) if train else 0, bn0.momentum, bn0.eps,
             ptr(ws), ptr(pooled), ptr(fmap), current_stream()), "capnet_trunk_forward")
         if train and defer_stats:
             def apply_running_stats():
                 check(_lib.lib().capnet_trunk_update_running(
-                    plan["handle"], ptr(ws), ptr_array([bn.running_mean for bn in self.bns]),
-                    ptr_array([bn.running_var for bn in self.bns]), bn0.momentum, current_stream()),
+                    plan["handle"], ptr(ws), tables[3], tables[4], bn0.momentum, current_stream()),
                     "capnet_trunk_update_running")
                 torch._foreach_add_([bn.num_batches_tracked for bn in self.bns], 1)
             return pooled, fmap, apply_running_stats
@@ -280,6 +292,12 @@ class EncoderCNN(nn.Module):
         if defer_stats:
             return features, (out[2] if len(out) > 2 else None)
         return features
+
+    def zero_grad(self, set_to_none=True):
+        """The trunk runs under no_grad and never holds gradients: visit only the head (walking
+        the 465 trunk parameters costs more host time per step than the whole decoder launch)."""
+        self.linear.zero_grad(set_to_none=set_to_none)
+        self.bn.zero_grad(set_to_none=set_to_none)
 
     def forward(self, images):
         features = self.trunk_features(images)

@@ -42,6 +42,10 @@ class EncoderCNN(nn.Module):
             out = self._pool(fmap)
         return (out, apply_fn) if defer_stats else out
 
+    def zero_grad(self, set_to_none=True):
+        """No trainable parameter and no gradient anywhere (the trunk runs under no_grad)."""
+        return None
+
     def _pool(self, fmap):
         """AdaptiveAvgPool2d(encoded_image_size) of the 7x7 map: an exact replication."""
         b, side = fmap.shape[0], fmap.shape[1]
