@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--no-pipeline", action="store_true",
                     help="run trunk and decoder of a step back to back on one stream instead of "
                          "overlapping step i's decoder with step i+1's trunk (capnet.train.TrunkPipeline)")
+    ap.add_argument("--graph-trunk", action="store_true",
+                    help="replay the trunk passes from hipGraphs (only without conv events)")
     ap.add_argument("--pipeline-depth", type=int, default=3,
                     help="trunk passes in flight ahead of the decoder")
     ap.add_argument("--no-lstm-roofline", action="store_true",
@@ -199,7 +201,7 @@ def main():
     pipe = None
     if not args.no_pipeline:
         pipe = TrunkPipeline(encoder, decoder, optimizer, criterion, 0.5, attention=args.decoder == "att",
-                             depth=args.pipeline_depth)
+                             depth=args.pipeline_depth, graph_trunk=args.graph_trunk)
         for _ in range(pipe.depth):
             pipe.prefetch(images)
 
@@ -231,7 +233,7 @@ def main():
     plan = runner._plan(B, 224, 224, dev)
     lib = capnet.lib()
     if not args.no_conv_events:
-        lib.capnet_trunk_set_timing(plan["handle"], 1)
+        runner.set_timing(plan, True)
     barrier()
     log("warm-up done, timing %d steps" % args.steps)
     t0 = time.perf_counter()
@@ -244,7 +246,7 @@ def main():
     elapsed = time.perf_counter() - t0
     log("host enqueue %.3f s of %.3f s" % (host_enqueue, elapsed))
     log("timed region: %.3f s" % elapsed)
-    lib.capnet_trunk_set_timing(plan["handle"], 0)
+    runner.set_timing(plan, False)
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if dist.is_initialized():
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
@@ -273,11 +275,11 @@ def main():
                 # little). For reference: the same kernels with nothing else running, 3 extra
                 # untimed trunk passes.
                 torch.cuda.synchronize()
-                lib.capnet_trunk_set_timing(plan["handle"], 1)
+                runner.set_timing(plan, True)
                 for _ in range(3):
                     encoder(images) if args.decoder == "att" else encoder.trunk_features(images)
                 torch.cuda.synchronize()
-                lib.capnet_trunk_set_timing(plan["handle"], 0)
+                runner.set_timing(plan, False)
                 capnet._lib.check(lib.capnet_trunk_collect_timing(plan["handle"], C.byref(ms), C.byref(n),
                                                                  C.byref(fl)))
                 if n.value > 0:

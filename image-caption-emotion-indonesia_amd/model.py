@@ -6,6 +6,7 @@ libcapnet_hip.so through capnet.ops. Differences from the reference are listed i
 """
 import ctypes as C
 import math
+import os
 import random
 import sys
 
@@ -136,6 +137,7 @@ class _TrunkRunner:
                 if blk.downsample is not None:
                     self.convs.append(blk.downsample[0]); self.bns.append(blk.downsample[1])
         self.plans = {}
+        self.timing = False
         self.packed = None
         self.packed_key = None
 
@@ -197,7 +199,7 @@ class _TrunkRunner:
         return self._table_val
 
     def forward(self, images, train, want_pooled, want_map, slot=0, defer_stats=False,
-                balance_tails=True):
+                balance_tails=True, graph=False):
         """defer_stats (train mode only): leave the running statistics alone and return a callable
         that applies this pass's update (capnet_trunk_update_running + num_batches_tracked) on the
         then-current stream; the caller decides when (TrunkPipeline orders passes with events)."""
@@ -215,17 +217,51 @@ class _TrunkRunner:
             check(_lib.lib().capnet_trunk_set_tail_balance(plan["handle"], int(bool(balance_tails))),
                   "capnet_trunk_set_tail_balance")
             plan["balance_tails"] = bool(balance_tails)
-        pooled = torch.empty((b, 2048), dtype=torch.float32, device=dev) if want_pooled else None
-        fmap = torch.empty((b, side, side, 2048), dtype=torch.float32, device=dev) if want_map else None
         bn0 = self.bns[0]
         tables = self._tables(packed)
-        check(_lib.lib().capnet_trunk_forward(
-            plan["handle"], ptr(images), tables[0], tables[1], tables[2], tables[3], tables[4],
-            (2 if defer_stats else 1) if train else 0, bn0.momentum, bn0.eps,
-            ptr(ws), ptr(pooled), ptr(fmap), current_stream()), "capnet_trunk_forward")
+        L = _lib.lib()
+
+        def launch(img, pooled, fmap):
+            check(L.capnet_trunk_forward(
+                plan["handle"], ptr(img), tables[0], tables[1], tables[2], tables[3], tables[4],
+                (2 if defer_stats else 1) if train else 0, bn0.momentum, bn0.eps,
+                ptr(ws), ptr(pooled), ptr(fmap), current_stream()), "capnet_trunk_forward")
+
+        def new_outputs():
+            p = torch.empty((b, 2048), dtype=torch.float32, device=dev) if want_pooled else None
+            f = torch.empty((b, side, side, 2048), dtype=torch.float32, device=dev) if want_map else None
+            return p, f
+
+        use_graph = (graph and train and defer_stats and not self.timing and
+                     os.environ.get("CAPNET_NO_GRAPH") != "1")
+        if use_graph:
+            # The pass is ~330 launches with fixed arguments: captured once per (slot, outputs,
+            # tile mode) into a hipGraph and replayed -- one launch call on the host instead of
+            # ~3.5 ms of them. Input and outputs are static buffers of the graph.
+            gkey = (slot, want_pooled, want_map, bool(balance_tails))
+            sig = (id(tables), images.dtype)
+            st = plan.setdefault("graphs", {}).get(gkey)
+            if st is None or st["sig"] != sig:
+                static_in = torch.empty_like(images)
+                sp, sf = new_outputs()
+                launch(static_in, sp, sf)      # eager warm-up on garbage: one-time attribute calls
+                g = torch.cuda.CUDAGraph()
+                # thread_local: other threads (an RCCL watchdog) may keep calling into HIP meanwhile
+                with torch.cuda.graph(g, stream=torch.cuda.current_stream(),
+                                      capture_error_mode="thread_local"):
+                    launch(static_in, sp, sf)
+                st = {"sig": sig, "graph": g, "in": static_in, "pooled": sp, "fmap": sf}
+                plan["graphs"][gkey] = st
+            st["in"].copy_(images, non_blocking=True)
+            st["graph"].replay()
+            pooled = st["pooled"].clone() if want_pooled else None
+            fmap = st["fmap"].clone() if want_map else None
+        else:
+            pooled, fmap = new_outputs()
+            launch(images, pooled, fmap)
         if train and defer_stats:
             def apply_running_stats():
-                check(_lib.lib().capnet_trunk_update_running(
+                check(L.capnet_trunk_update_running(
                     plan["handle"], ptr(ws), tables[3], tables[4], bn0.momentum, current_stream()),
                     "capnet_trunk_update_running")
                 torch._foreach_add_([bn.num_batches_tracked for bn in self.bns], 1)
@@ -233,6 +269,12 @@ class _TrunkRunner:
         if train:
             torch._foreach_add_([bn.num_batches_tracked for bn in self.bns], 1)
         return pooled, fmap
+
+    def set_timing(self, plan, on):
+        """Per-conv hipEvent timing (bench.py roofline); event records cannot ride in a replayed
+        graph, so timed passes are launched directly."""
+        self.timing = bool(on)
+        check(_lib.lib().capnet_trunk_set_timing(plan["handle"], int(bool(on))), "capnet_trunk_set_timing")
 
 
 class _BN1d(nn.Module):
@@ -280,14 +322,14 @@ class EncoderCNN(nn.Module):
             self._runner[0] = _TrunkRunner(self.resnet)
         return self._runner[0]
 
-    def trunk_features(self, images, slot=0, defer_stats=False, balance_tails=True):
+    def trunk_features(self, images, slot=0, defer_stats=False, balance_tails=True, graph=False):
         """children[:-1] of the ResNet under no_grad (model.py:23-25): pooled [B, 2048].
         slot / defer_stats: see _TrunkRunner.forward (used by capnet.train.TrunkPipeline); with
         defer_stats in train mode the result is (features, apply_running_stats)."""
         with torch.no_grad():
             out = self._trunk().forward(images, self.training, True, False, slot=slot,
                                         defer_stats=defer_stats and self.training,
-                                        balance_tails=balance_tails)
+                                        balance_tails=balance_tails, graph=graph)
         features = out[0].reshape(out[0].size(0), -1)
         if defer_stats:
             return features, (out[2] if len(out) > 2 else None)

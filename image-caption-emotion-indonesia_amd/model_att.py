@@ -30,13 +30,13 @@ class EncoderCNN(nn.Module):
             self._runner[0] = _TrunkRunner(self.resnet)
         return self._runner[0]
 
-    def forward(self, images, slot=0, defer_stats=False, balance_tails=True):
+    def forward(self, images, slot=0, defer_stats=False, balance_tails=True, graph=False):
         """slot / defer_stats: see _TrunkRunner.forward (capnet.train.TrunkPipeline); with
         defer_stats the result is (features, apply_running_stats or None)."""
         with torch.no_grad():
             res = self._trunk().forward(images, self.training, False, True, slot=slot,
                                         defer_stats=defer_stats and self.training,
-                                        balance_tails=balance_tails)
+                                        balance_tails=balance_tails, graph=graph)
             fmap = res[1]
             apply_fn = res[2] if len(res) > 2 else None
             out = self._pool(fmap)

@@ -108,7 +108,7 @@ class TrunkPipeline(object):
     """
 
     def __init__(self, encoder, decoder, optimizer, criterion, grad_clip, attention=False,
-                 alpha_c=1.0, depth=3, shared_chip_tuning=True):
+                 alpha_c=1.0, depth=3, shared_chip_tuning=True, graph_trunk=False):
         self.encoder, self.decoder, self.optimizer = encoder, decoder, optimizer
         self.criterion, self.grad_clip = criterion, grad_clip
         self.attention, self.alpha_c = attention, alpha_c
@@ -119,6 +119,11 @@ class TrunkPipeline(object):
         # so results differ from the sequential loop at rounding level; False keeps the sequential
         # schedule's kernels and reproduces its numbers exactly.
         self.balance_tails = not (shared_chip_tuning and self.depth >= 2)
+        # graph_trunk: replay each trunk pass (~330 launches, fixed arguments) from a hipGraph
+        # captured per slot. It removes ~3.5 ms of launch calls per pass from the host, but the step
+        # is bound by the GPU (the host runs ahead until the queues are full), so it measured no
+        # gain on one GPU: 4370 vs 4355 images/s; off by default.
+        self.graph_trunk = bool(graph_trunk)
         # The trainable half gets the HIGH-priority stream: its launches are small (a few
         # workgroups, microseconds) and form a long dependent chain, so they must be dispatched as
         # soon as they are ready; a convolution of the trunk has thousands of workgroups queued and
@@ -140,10 +145,10 @@ class TrunkPipeline(object):
         with torch.cuda.stream(stream):
             if self.attention:
                 feats, apply_stats = self.encoder(images, slot=slot, defer_stats=True,
-                                                  balance_tails=self.balance_tails)
+                                                  balance_tails=self.balance_tails, graph=self.graph_trunk)
             else:
                 feats, apply_stats = self.encoder.trunk_features(images, slot=slot, defer_stats=True,
-                                                                 balance_tails=self.balance_tails)
+                                                                 balance_tails=self.balance_tails, graph=self.graph_trunk)
             ready = torch.cuda.Event()
             ready.record()
             if apply_stats is not None:

@@ -98,7 +98,7 @@ def test_three_train_steps_match_the_cpu_oracle(dev, kind):
     assert ref_losses[2] < ref_losses[0]      # the updates did something
 
 
-def _pipeline_vs_sequential(dev, tuning):
+def _pipeline_vs_sequential(dev, tuning, graph=False):
     from capnet.train import TrunkPipeline
     B, V, steps = 8, 1000, 5
     batches = [synthetic.make_batch(B, V, seed=s) for s in range(steps)]
@@ -125,7 +125,8 @@ def _pipeline_vs_sequential(dev, tuning):
     ref_rm = enc.resnet[7][2].bn3.running_mean.clone()
 
     enc, dec, opt = build()
-    pipe = TrunkPipeline(enc, dec, opt, CrossEntropyLoss(), 0.5, shared_chip_tuning=tuning)
+    pipe = TrunkPipeline(enc, dec, opt, CrossEntropyLoss(), 0.5, shared_chip_tuning=tuning,
+                         graph_trunk=graph)
     dev_batches = [(i.to(dev), c.to(dev), l) for i, c, l in batches]
     d = pipe.depth
     assert d == 3 and steps > d
@@ -166,6 +167,14 @@ def test_pipelined_steps_equal_sequential_steps(dev):
             # (the differing embedding rows feed the later steps, so the rest agrees closely, not bitwise)
             assert dlt.max().item() <= 2e-3 * ref_params[k].abs().max().item() + 1e-7, k
     # the trunk's running statistics saw the passes in order (deferred, event-ordered updates)
+    assert torch.equal(rm, ref_rm)
+
+
+def test_pipelined_steps_with_graphed_trunk_equal_sequential_steps(dev):
+    """graph_trunk=True: every trunk pass replayed from a hipGraph captured per pipeline slot."""
+    seq, got, _, _, ref_rm, rm = _pipeline_vs_sequential(dev, False, graph=True)
+    for a, b in zip(got, seq):
+        assert abs(a - b) / abs(b) < 2e-6
     assert torch.equal(rm, ref_rm)
 
 
