@@ -269,17 +269,24 @@ int seq_backward(const SeqDims& d, const int* batch_sizes, const float* dH, cons
   CAPNET_HIP_CHECK(hipMemsetAsync(dh_rec, 0, (size_t)d.B * H * sizeof(float), s));
   CAPNET_HIP_CHECK(hipMemsetAsync(dc, 0, (size_t)d.B * H * sizeof(float), s));
 
+  int slabs = 0;   // > 0: dh of the following step is still in `skws` as K-chunk slabs
   for (int t = d.steps - 1; t >= 0; --t) {
     const int b = batch_sizes[t], r0 = off[t];
     const int b_next = (t + 1 < d.steps) ? batch_sizes[t + 1] : 0;
     RC(lstm_pointwise_bwd(sv + L.G + (size_t)r0 * 4 * H, 4 * H, sv + L.Cst + (size_t)r0 * H,
                           t > 0 ? sv + L.Cst + (size_t)off[t - 1] * H : nullptr,
-                          dH + (size_t)r0 * H, dh_rec, dc, dPre + (size_t)r0 * 4 * H, 4 * H, b, b_next, H,
-                          go.gi, go.gf, go.go, go.gg, go.tanh_out, s));
+                          dH + (size_t)r0 * H, slabs > 0 ? skws : dh_rec, dc, dPre + (size_t)r0 * 4 * H,
+                          4 * H, b, b_next, H, go.gi, go.gf, go.go, go.gg, go.tanh_out, s, slabs,
+                          (long)b_next * H));
+    slabs = 0;
     if (t > 0) {
-      // dh_{t-1}[0:b] = dPre_t . Wcat     (rows b..b_{t-1} of step t-1 have no successor)
-      RC(sgemm_splitk(false, false, b, H, 4 * H, dPre + (size_t)r0 * 4 * H, 4 * H, sv + L.Wcat, H,
-                      dh_rec, H, nullptr, 0, skws, kSplitKFloats, s));
+      // dh_{t-1}[0:b] = dPre_t . Wcat     (rows b..b_{t-1} of step t-1 have no successor);
+      // the K-chunk partials stay in slabs and are summed by the next gate kernel
+      RC(sgemm_splitk_slabs(false, b, H, 4 * H, dPre + (size_t)r0 * 4 * H, 4 * H, sv + L.Wcat, H, skws,
+                            kSplitKFloats, &slabs, s));
+      if (slabs == 0)
+        RC(sgemm_splitk(false, false, b, H, 4 * H, dPre + (size_t)r0 * 4 * H, 4 * H, sv + L.Wcat, H,
+                        dh_rec, H, nullptr, 0, skws, kSplitKFloats, s));
     }
   }
   // recurrent weight gradient over all steps at once: dWcat = dPre^T . h_{t-1}

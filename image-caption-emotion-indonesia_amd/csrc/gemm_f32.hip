@@ -382,6 +382,32 @@ int sgemm_splitk_batched(bool ta, bool tb, int M, int N, int K, const float* A, 
   return kOk;
 }
 
+// The K-chunk partial products only: slab[k][M][N], k < *n_slabs, left for the consumer to sum in
+// slab order (the recurrent backward step folds the sum into its gate kernel). *n_slabs = 0 when
+// the shape does not qualify (the caller then uses sgemm_splitk).
+int sgemm_splitk_slabs(bool tb, int M, int N, int K, const float* A, long lda, const float* B, long ldb,
+                       float* ws, size_t ws_floats, int* n_slabs, hipStream_t stream) {
+  *n_slabs = 0;
+  if (M <= 0 || N <= 0) return kOk;
+  const bool ok = ws && M <= 128 && K % 4 == 0 && lda % 4 == 0 && aligned16(A) && aligned16(B) &&
+                  ldb % 4 == 0 && (tb || N % 4 == 0) && N >= 4 && K >= 64;
+  if (!ok) return kOk;
+  const long tiles = (long)cdiv(M, 64) * cdiv(N, 64);
+  int kc = tiles * cdiv(K, 128) < 200 ? 64 : 128;
+  if ((size_t)cdiv(K, kc) * M * N > ws_floats) kc = 128;
+  if ((size_t)cdiv(K, kc) * M * N > ws_floats) return kOk;
+  if (kc == 64) {
+    if (tb) launch_skinny<64, true>(A, lda, B, ldb, ws, M, N, K, 1, 0, 0, stream);
+    else launch_skinny<64, false>(A, lda, B, ldb, ws, M, N, K, 1, 0, 0, stream);
+  } else {
+    if (tb) launch_skinny<128, true>(A, lda, B, ldb, ws, M, N, K, 1, 0, 0, stream);
+    else launch_skinny<128, false>(A, lda, B, ldb, ws, M, N, K, 1, 0, 0, stream);
+  }
+  CAPNET_LAUNCH_CHECK();
+  *n_slabs = cdiv(K, kc);
+  return kOk;
+}
+
 int sgemm_splitk(bool ta, bool tb, int M, int N, int K, const float* A, long lda, const float* B,
                  long ldb, float* C, long ldc, const float* bias, int accumulate, float* ws,
                  size_t ws_floats, hipStream_t stream) {

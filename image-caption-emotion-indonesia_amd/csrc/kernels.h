@@ -13,6 +13,8 @@ int sgemm(bool ta, bool tb, int M, int N, int K, const float* A, long lda, const
 int sgemm_splitk(bool ta, bool tb, int M, int N, int K, const float* A, long lda, const float* B,
                  long ldb, float* C, long ldc, const float* bias, int accumulate, float* ws,
                  size_t ws_floats, hipStream_t stream);
+int sgemm_splitk_slabs(bool tb, int M, int N, int K, const float* A, long lda, const float* B, long ldb,
+                       float* ws, size_t ws_floats, int* n_slabs, hipStream_t stream);
 int sgemm_splitk_batched(bool ta, bool tb, int M, int N, int K, const float* A, long lda,
                          const float* B, long ldb, float* C, long ldc, const float* bias,
                          int accumulate, int batch, long sA, long sB, long sC, long sBias, float* ws,
@@ -107,7 +109,7 @@ int lstm_pointwise_fwd(float* pre, long ldp, const float* c_prev, float* c_out, 
 int lstm_pointwise_bwd(const float* gates, long ldg, const float* c, const float* c_prev,
                        const float* dH, const float* dh_rec, float* dc_io, float* dpre, long ldq,
                        int b, int b_next, int H, int gi, int gf, int go, int gg, int tanh_out,
-                       hipStream_t stream);
+                       hipStream_t stream, int dh_slabs = 0, long dh_slab_stride = 0);
 int gather_prev_rows(const float* src, const int* idx, const float* first, const int* sample,
                      float* out, int rows, int C, hipStream_t stream);
 int argmax_rows(const float* x, int rows, int ld, int V, int* out, hipStream_t stream);

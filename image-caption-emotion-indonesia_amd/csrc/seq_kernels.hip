@@ -212,7 +212,8 @@ __global__ __launch_bounds__(256) void lstm_pointwise_bwd_kernel(
     const float* __restrict__ gates, long ldg, const float* __restrict__ c,
     const float* __restrict__ c_prev, const float* __restrict__ dH,
     const float* __restrict__ dh_rec, float* __restrict__ dc_io, float* __restrict__ dpre, long ldq,
-    int b, int b_next, int H, int gi, int gf, int go, int gg, int tanh_out) {
+    int b, int b_next, int H, int gi, int gf, int go, int gg, int tanh_out, int dh_slabs,
+    long dh_slab_stride) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= b * H) return;
   const int row = idx / H, j = idx - row * H;
@@ -223,7 +224,23 @@ __global__ __launch_bounds__(256) void lstm_pointwise_bwd_kernel(
   float dh = dH[(long)row * H + j];
   float dc = 0.f;
   if (row < b_next) {
-    dh += dh_rec[(long)row * H + j];
+    if (dh_slabs > 0) {
+      // dh_rec = sum of the K-chunk slabs of dG_{t+1} . W (sgemm_splitk_slabs), in slab order
+      const float* sp = dh_rec + (long)row * H + j;
+      float s = 0.f;
+      int k = 0;
+      for (; k + 8 <= dh_slabs; k += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = sp[(long)(k + u) * dh_slab_stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+      }
+      for (; k < dh_slabs; ++k) s += sp[(long)k * dh_slab_stride];
+      dh += s;
+    } else {
+      dh += dh_rec[(long)row * H + j];
+    }
     dc = dc_io[(long)row * H + j];
   }
   float d_o;
@@ -247,11 +264,11 @@ __global__ __launch_bounds__(256) void lstm_pointwise_bwd_kernel(
 int lstm_pointwise_bwd(const float* gates, long ldg, const float* c, const float* c_prev,
                        const float* dH, const float* dh_rec, float* dc_io, float* dpre, long ldq,
                        int b, int b_next, int H, int gi, int gf, int go, int gg, int tanh_out,
-                       hipStream_t stream) {
+                       hipStream_t stream, int dh_slabs, long dh_slab_stride) {
   if (b <= 0) return kOk;
   hipLaunchKernelGGL(lstm_pointwise_bwd_kernel, dim3(cdiv((long)b * H, 256)), dim3(256), 0, stream,
                      gates, ldg, c, c_prev, dH, dh_rec, dc_io, dpre, ldq, b, b_next, H, gi, gf, go,
-                     gg, tanh_out);
+                     gg, tanh_out, dh_slabs, dh_slab_stride);
   CAPNET_LAUNCH_CHECK();
   return kOk;
 }
