@@ -51,6 +51,11 @@ SIGNATURES = {
     "capnet_pack_conv_weight_kmajor": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "capnet_conv2d_fwd_kmajor": (_i, [_vp, _l, _l, _l, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _i,
                                       _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "capnet_pack_conv_weight_wino": (_i, [_vp, _vp, _i, _i, _vp]),
+    "capnet_conv_wino_weight_floats": (_sz, [_i, _i]),
+    "capnet_conv_wino_tiles_m": (_i, [_i, _i, _i]),
+    "capnet_conv2d_fwd_wino": (_i, [_vp, _l, _l, _l, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i,
+                                    _vp, _vp, _i, _vp]),
     "capnet_conv_kmajor_slab_floats": (_sz, [_i, _i, _i, _i]),
     "capnet_conv_kmajor_plan": (None, [_i, _i, _i, _i, _ip]),
     "capnet_conv_kmajor_tiles_m": (_i, [_i, _i, _i, _i]),

@@ -103,6 +103,20 @@ int capnet_conv2d_fwd_kmajor(const float* x, long sxb, long sxh, long sxw, const
   return conv2d_fwd_v2(x, sxb, sxh, sxw, w_kmajor, k_rows, y, in_scale, in_shift, relu_in, part_sum,
                        part_sq, B, H, W, Cin, Cout, KH, KW, stride, pad, tile, slabs, S(stream));
 }
+int capnet_pack_conv_weight_wino(const float* w_oihw, float* out, int Cout, int Cin,
+                                 capnet_stream_t stream) {
+  return pack_conv_weight_wino(w_oihw, out, Cout, Cin, S(stream));
+}
+size_t capnet_conv_wino_weight_floats(int Cin, int Cout) { return conv_wino_weight_floats(Cin, Cout); }
+int capnet_conv_wino_tiles_m(int B, int H, int W) { return conv_wino_tiles_m(B, H, W); }
+int capnet_conv2d_fwd_wino(const float* x, long sxb, long sxh, long sxw, const float* w_wino, float* y,
+                           const float* in_scale, const float* in_shift, int relu_in,
+                           float* part_sum, float* part_sq, int B, int H, int W, int Cin, int Cout,
+                           const float* out_scale, const float* out_shift, int relu_out,
+                           capnet_stream_t stream) {
+  return conv2d_fwd_wino(x, sxb, sxh, sxw, w_wino, y, in_scale, in_shift, relu_in, part_sum, part_sq, B,
+                         H, W, Cin, Cout, S(stream), out_scale, out_shift, relu_out);
+}
 size_t capnet_conv_kmajor_slab_floats(int M, int Cout, int k_rows, int tile) {
   return conv_v2_slab_floats(M, Cout, k_rows, tile);
 }

@@ -39,6 +39,16 @@ size_t conv_v2_slab_floats(int M, int Cout, int Kw, int tile);
 int conv_v2_auto_tile(int M, int Cout, int Kw);
 void conv_v2_plan(int M, int Cout, int Kw, int tile, int* out);
 int conv_tiles_m(int M, int tile);
+// conv_wino.hip (3x3 / stride 1 / pad 1 as Winograd F(2x2,3x3); weights packed by pack_conv_weight_wino)
+bool conv_wino_shape_ok(int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
+size_t conv_wino_weight_floats(int Cin, int Cout);
+int conv_wino_tiles_m(int Bn, int H, int W);
+int pack_conv_weight_wino(const float* w_oihw, float* out, int Cout, int Cin, hipStream_t stream);
+int conv2d_fwd_wino(const float* x, long sxb, long sxh, long sxw, const float* wp, float* y,
+                    const float* in_scale, const float* in_shift, int relu_in, float* part_sum,
+                    float* part_sq, int Bn, int H, int W, int Cin, int Cout, hipStream_t stream,
+                    const float* out_scale = nullptr, const float* out_shift = nullptr,
+                    int relu_out = 0);
 
 // bn_pool.hip
 int bn_finalize(const float* part_sum, const float* part_sq, int tiles, int C, long count,

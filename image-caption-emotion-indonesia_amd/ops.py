@@ -239,6 +239,20 @@ def pack_conv_weight(w_oihw, row_stride, kmajor=False):
     return out
 
 
+def pack_conv_weight_wino(w_oihw):
+    """OIHW 3x3 weights -> the Winograd F(2x2,3x3) image of capnet_conv2d_fwd_wino
+    ([Cin/8][Cout/64][16][64][8], U = G g G^T)."""
+    _need_cuda(w_oihw)
+    w = _c(w_oihw)
+    co, ci, kh, kw = w.shape
+    if (kh, kw) != (3, 3):
+        raise CapnetError("pack_conv_weight_wino: 3x3 weights only")
+    out = torch.empty(_lib.lib().capnet_conv_wino_weight_floats(ci, co), dtype=torch.float32, device=w.device)
+    check(_lib.lib().capnet_pack_conv_weight_wino(ptr(w), ptr(out), co, ci, current_stream()),
+          "capnet_pack_conv_weight_wino")
+    return out
+
+
 def clamp_adam(params, grads, exp_avg, exp_avg_sq, steps, lr, beta1, beta2, eps, clip,
                write_grad=True):
     """Fused element-wise clamp + Adam over a list of tensors (in place)."""

@@ -144,6 +144,23 @@ int capnet_conv2d_fwd_kmajor(const float* x, long sxb, long sxh, long sxw, const
                              int relu_in, float* part_sum, float* part_sq, int B, int H, int W,
                              int Cin, int Cout, int KH, int KW, int stride, int pad, int tile,
                              float* slabs, capnet_stream_t stream);
+/* 3x3 / stride 1 / pad 1 convolution as Winograd F(2x2,3x3) on the f32 matrix cores (the conv2
+ * of the bottlenecks outside the stride-2 blocks; call site of the arithmetic it replaces:
+ * torchvision resnet Bottleneck.conv2 via stylenet/model.py:15-18,24): 2.25x fewer multiplies
+ * than the direct sum, 4e-7 rms relative error against fp64. Needs even H and W, Cin % 8 == 0,
+ * Cout % 64 == 0, NHWC channel-contiguous input. Weights: capnet_pack_conv_weight_wino
+ * (capnet_conv_wino_weight_floats floats). Either raw output + capnet_conv_wino_tiles_m rows of
+ * part_sum / part_sq (train-mode BatchNorm statistics), or, with out_scale / out_shift given,
+ * y = act(conv * out_scale[n] + out_shift[n]) (folded inference BatchNorm, no statistics). */
+int capnet_pack_conv_weight_wino(const float* w_oihw, float* out, int Cout, int Cin,
+                                 capnet_stream_t stream);
+size_t capnet_conv_wino_weight_floats(int Cin, int Cout);
+int capnet_conv_wino_tiles_m(int B, int H, int W);
+int capnet_conv2d_fwd_wino(const float* x, long sxb, long sxh, long sxw, const float* w_wino, float* y,
+                           const float* in_scale, const float* in_shift, int relu_in,
+                           float* part_sum, float* part_sq, int B, int H, int W, int Cin, int Cout,
+                           const float* out_scale, const float* out_shift, int relu_out,
+                           capnet_stream_t stream);
 /* `slabs` (may be NULL = no tail balancing): scratch of capnet_conv_kmajor_slab_floats floats.
  * When the tile count is not a multiple of the 256 CUs, the tiles past the last full round are
  * cut into K-slices (fp32 partial slabs, summed in a fixed order by a fix-up launch) so that

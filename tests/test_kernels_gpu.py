@@ -137,6 +137,60 @@ def test_conv_kmajor_lds_dma_path(dev, tile, B, H, W, Cin, Cout, k, stride, pad,
     assert rel_err(psq.sum(0), (ref_nhwc ** 2).sum(0)) < 1e-5
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout,pre,epi", [
+    (2, 14, 14, 64, 64, True, False),
+    (3, 14, 14, 256, 256, True, False),      # 147 tiles: ragged last workgroup, 32 k-tiles
+    (1, 8, 6, 8, 64, False, False),          # one k-tile, 12 tiles, no prologue
+    (2, 28, 28, 128, 128, True, False),
+    (5, 2, 2, 24, 192, True, False),         # one tile per image: every patch is mostly padding
+    (2, 14, 14, 64, 128, False, True),       # folded-BN + ReLU epilogue (inference trunk)
+    (3, 10, 12, 40, 64, True, True),
+])
+def test_conv_winograd_3x3(dev, B, H, W, Cin, Cout, pre, epi):
+    """conv_wino.hip: F(2x2,3x3) with the BatchNorm+ReLU prologue, zero padding after the
+    activation, train-mode statistics or the folded inference epilogue. fp32 Winograd is ~2.4x
+    the rounding error of the direct fp32 sum (measured 5e-7 max relative); the bound is the one
+    the direct kernels are held to."""
+    g = torch.Generator().manual_seed(B + H + Cin + Cout + 7)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.1
+    scale = torch.rand(Cin, generator=g) - 0.3 if pre else None      # some negative scales
+    shift = torch.randn(Cin, generator=g) if pre else None
+    ref = _conv_ref(x, w, 1, 1, scale, shift, relu=pre)
+    osc = torch.rand(Cout, generator=g) + 0.5 if epi else None
+    osh = torch.randn(Cout, generator=g) if epi else None
+    if epi:
+        ref = (ref * osc.double().view(1, -1, 1, 1) + osh.double().view(1, -1, 1, 1)).clamp_min(0)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    wp = ops.pack_conv_weight_wino(w.to(dev))
+    M = B * H * W
+    y = torch.full((M, Cout), float("nan"), device=dev)
+    tiles = lib().capnet_conv_wino_tiles_m(B, H, W)
+    psum = torch.zeros(tiles, Cout, device=dev)
+    psq = torch.zeros(tiles, Cout, device=dev)
+    sd = scale.to(dev) if pre else None
+    hd = shift.to(dev) if pre else None
+    od = osc.to(dev) if epi else None
+    ohd = osh.to(dev) if epi else None
+    check(lib().capnet_conv2d_fwd_wino(ptr(xd), H * W * Cin, W * Cin, Cin, ptr(wp), ptr(y), ptr(sd), ptr(hd),
+                                       int(pre), None if epi else ptr(psum), None if epi else ptr(psq),
+                                       B, H, W, Cin, Cout, ptr(od), ptr(ohd), int(epi), current_stream()))
+    ref_nhwc = ref.permute(0, 2, 3, 1).reshape(M, Cout)
+    assert rel_err(y, ref_nhwc) < 3e-6
+    if not epi:
+        assert rel_err(psum.sum(0), ref_nhwc.sum(0)) < 1e-5
+        assert rel_err(psq.sum(0), (ref_nhwc ** 2).sum(0)) < 1e-5
+
+
+def test_conv_winograd_rejects_unsupported_shapes(dev):
+    x = torch.zeros(1, 7, 7, 64, device=dev)
+    wp = torch.zeros(16 * 64 * 64, device=dev)
+    y = torch.zeros(49, 64, device=dev)
+    rc = lib().capnet_conv2d_fwd_wino(ptr(x), 7 * 7 * 64, 7 * 64, 64, ptr(wp), ptr(y), None, None, 0, None,
+                                      None, 1, 7, 7, 64, 64, None, None, 0, current_stream())
+    assert rc != 0 and b"even" in lib().capnet_last_error()
+
+
 def test_conv_stem_generic_nchw(dev):
     B, H, W = 2, 64, 64
     g = torch.Generator().manual_seed(11)
