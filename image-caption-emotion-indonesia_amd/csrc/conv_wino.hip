@@ -23,11 +23,14 @@
 //   * MFMA: v_mfma_f32_16x16x4_f32; wave (mh, nw) owns 32 tiles x output channels 16nw..16nw+15
 //     for all 16 frequencies (128 accumulator registers; 2 waves per SIMD), so the output transform A^T M A runs
 //     in registers with no exchange, and the BatchNorm partial sums need two shuffles.
-//     Both LDS images keep the 8 k of a row contiguous; lane (i, kq) reads floats [2kq, 2kq+1]
-//     with one ds_read_b64 and feeds them to the two k-steps of the tile (any k <-> (step, kq)
-//     bijection is a valid reduction order as long as A and B use the same one).
+//     Both LDS images are stored per frequency and 16-row block in MFMA lane order
+//     ([k >> 1][row][k & 1]): lane (row i, kq) reads its two k with one ds_read_b64 and a wave
+//     reads 512 contiguous bytes (any k <-> (step, kq) bijection is a valid reduction order as
+//     long as A and B use the same one).
 // Same contract as conv2d_fwd_v2: raw NHWC output + per-workgroup column sums / sums of squares
 // (train-mode BatchNorm), or the folded-BN (+ReLU) inference epilogue.
+#include <cstdlib>
+#include <type_traits>
 #include "common.h"
 #include "mfma_core.h"
 #include "kernels.h"
@@ -42,7 +45,7 @@ constexpr int WBN = 64;              // output channels per workgroup
 constexpr int WBK = 8;               // input channels per k-tile
 constexpr int W_THREADS = 8 * WBT;   // one thread per (tile, patch row, channel quad)
 constexpr int W_WAVES = W_THREADS / 64;
-constexpr int W_FS_A = WBT * WBK + 4;  // floats per frequency plane of the A image (+4: the four
+constexpr int W_FS_A = WBT * WBK + 2;  // floats per frequency plane of the A image (+2: the four
                                        // patch-row lanes of a quad write to different banks)
 constexpr int W_FS_B = WBN * WBK;
 constexpr int W_A_ST = 16 * W_FS_A;  // floats per A stage
@@ -103,7 +106,10 @@ __device__ __forceinline__ float w_quad_other(float v) {
       float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x5A, 0xF, 0xF, true));
 }
 
-template <bool PRE, bool EPI>
+// ABL: compile-time ablation mask for tools/conv_bench.py (CAPNET_WINO_ABLATE), 0 in the product:
+// 1 no ds_read + MFMA, 2 no transform / LDS store, 4 no weight DMA, 8 no activation loads,
+// 16 MFMAs without their LDS reads, 32 no barrier in the k-loop
+template <bool PRE, bool EPI, int ABL = 0>
 __global__ __launch_bounds__(W_THREADS) void conv_wino_kernel(WinoArgs g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -143,36 +149,50 @@ __global__ __launch_bounds__(W_THREADS) void conv_wino_kernel(WinoArgs g) {
   }
   // column transform: V[r] = R_r + sgn * R_other (row 3 negated, see the header)
   const float sgn = (r == 1) ? 1.f : -1.f;
-  const int awr = (4 * r) * W_FS_A + tl * WBK + 4 * q;  // A store index (frequency 4r + j: + j*FS_A)
+  // A image: [frequency][16-tile block][kq = k >> 1][tile in block][k & 1], the order in which
+  // the MFMA lanes (lane = 16 kq + tile) read it: one contiguous 512 B per ds_read_b64 (a
+  // [tile][k] image costs a 4-way bank conflict per read: measured 83 vs 55 us of pure MFMA time)
+  const int awr = (4 * r) * W_FS_A + (tl >> 4) * 128 + (2 * q * 16 + (tl & 15)) * 2;  // + j*FS_A; k pair 2q+1: + 32
 
   const unsigned lds_b0 = __builtin_amdgcn_readfirstlane(
       (unsigned)(size_t)(__attribute__((address_space(3))) float*)(lds + 2 * W_A_ST));
   const float* wblk = g.wp + (size_t)tn * W_B_ST;          // + kt * tiles_n * W_B_ST
   const size_t wstep = (size_t)g.tiles_n * W_B_ST;
 
+  // ---- pipeline pieces. Everything that is not an MFMA is cut into small pieces and placed
+  // BETWEEN the MFMA groups of the k-loop (one piece per frequency step). All eight waves of a
+  // workgroup run in lockstep behind the per-k-tile barrier; with the loads issued as one burst
+  // after it and the transform as one block in front of it, the matrix pipe idled while every
+  // wave sat in the same VMEM / VALU / LDS-write phase (measured: 79 us of MFMA + LDS reads grew
+  // to 104 us, and removing the *waits* changed nothing -- it is the issue phases themselves).
+  constexpr int DPW = 32 / W_WAVES;  // weight DMA instructions (1 KB each) per wave and k-tile
   w_f32x4 av[4], scv, shv;
-  auto issue = [&](int stage, int kt) {
-    // 32 KB of transformed weights: 32 DMA instructions of 1 KB, shared by the waves
-    constexpr int DPW = 32 / W_WAVES;
-    const float* bs = wblk + (size_t)kt * wstep + wave * (DPW * 256);
+  float d[4][4];  // [pixel s][channel] of the tile being transformed
+  auto clampk = [&](int kt) { return kt < nk ? kt : nk - 1; };  // past the end: reload the last tile
+  auto dma_b = [&](int stage, int kt, int j) {
+    if (ABL & 4) return;
+    const float* bs = wblk + (size_t)clampk(kt) * wstep + wave * (DPW * 256);
     const unsigned bdst = lds_b0 + (unsigned)(stage * W_B_ST + wave * (DPW * 256)) * 4u;
-#pragma unroll
-    for (int j = 0; j < DPW; ++j) w_glds16(bs + j * 256, lane * 16, bdst + (unsigned)(j * 256) * 4u);
-    const float* xb = g.x + kt * WBK;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) w_gload16(av[s], xb, voff[s]);
-    if (PRE) {
-      w_gload16(scv, g.in_scale + kt * WBK, (unsigned)(16 * q));
-      w_gload16(shv, g.in_shift + kt * WBK, (unsigned)(16 * q));
-    }
+    w_glds16(bs + j * 256, lane * 16, bdst + (unsigned)(j * 256) * 4u);
   };
-  auto store = [&](int stage) {
+  auto load_a = [&](int kt, int i) {   // piece i of 0..5
+    if (ABL & 8) return;
+    const int kc = clampk(kt) * WBK;
+    if (i < 4) w_gload16(av[i], g.x + kc, voff[i]);
+    else if (PRE && i == 4) w_gload16(scv, g.in_scale + kc, (unsigned)(16 * q));
+    else if (PRE && i == 5) w_gload16(shv, g.in_shift + kc, (unsigned)(16 * q));
+  };
+  constexpr int NLA = PRE ? 6 : 4;     // VMEM loads of one tile's activations per thread
+  // the activations of the next tile have landed once at most `keep` younger VMEM ops are in flight
+  auto fold = [&](auto keep) {
+    if (ABL & 2) return;
+    constexpr int KEEP = decltype(keep)::value;
     if (PRE)
-      asm volatile("s_waitcnt vmcnt(0)"
-                   : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(av[3]), "+v"(scv), "+v"(shv)::"memory");
+      asm volatile("s_waitcnt vmcnt(%6)"
+                   : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(av[3]), "+v"(scv), "+v"(shv)
+                   : "n"(KEEP) : "memory");
     else
-      asm volatile("s_waitcnt vmcnt(0)" : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(av[3])::"memory");
-    float d[4][4];  // [pixel s][channel]
+      asm volatile("s_waitcnt vmcnt(%4)" : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(av[3]) : "n"(KEEP) : "memory");
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -181,21 +201,22 @@ __global__ __launch_bounds__(W_THREADS) void conv_wino_kernel(WinoArgs g) {
         if (PRE) v = fmaf(v, scv[c], shv[c]);
         d[s][c] = __builtin_amdgcn_fmed3f(v, lw[s], hi[s]);
       }
-    float* dst = lds + stage * W_A_ST + awr;
+  };
+  auto transform = [&](int stage, int j) {   // frequency column j of this thread's patch row
+    if (ABL & 2) return;
+    float* dst = lds + stage * W_A_ST + awr + j * W_FS_A;
+    w_f32x4 o;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      w_f32x4 o;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        // row transform B^T along the patch row
-        const float rj = j == 0 ? d[0][c] - d[2][c]
-                       : j == 1 ? d[1][c] + d[2][c]
-                       : j == 2 ? d[2][c] - d[1][c]
-                                : d[1][c] - d[3][c];
-        o[c] = fmaf(w_quad_other(rj), sgn, rj);
-      }
-      *reinterpret_cast<w_f32x4*>(dst + j * W_FS_A) = o;
+    for (int c = 0; c < 4; ++c) {
+      // row transform B^T along the patch row, then the column transform through the quad
+      const float rj = j == 0 ? d[0][c] - d[2][c]
+                     : j == 1 ? d[1][c] + d[2][c]
+                     : j == 2 ? d[2][c] - d[1][c]
+                              : d[1][c] - d[3][c];
+      o[c] = fmaf(w_quad_other(rj), sgn, rj);
     }
+    *reinterpret_cast<w_f32x2*>(dst) = w_f32x2{o[0], o[1]};
+    *reinterpret_cast<w_f32x2*>(dst + 32) = w_f32x2{o[2], o[3]};
   };
 
   w_f32x4 acc[16][2];
@@ -207,46 +228,71 @@ __global__ __launch_bounds__(W_THREADS) void conv_wino_kernel(WinoArgs g) {
   // wave -> (tile half mh: tiles 32 mh .. 32 mh + 31, channel group nw: channels 16 nw .. + 15)
   const int li = lane & 15, kq = lane >> 4;
   const int mh = wave >> 2, nw = wave & 3;
-  const int ard = (32 * mh + li) * WBK + 2 * kq;                       // + f*FS_A + mb*16*WBK
-  const int brd = 2 * W_A_ST + (16 * nw + li) * WBK + 2 * kq;          // + f*FS_B
-  auto compute = [&](int stage) {
-    const float* As = lds + stage * W_A_ST + ard;
-    const float* Bs = lds + stage * W_B_ST + brd;
-    w_f32x2 a0[2], a1[2], b[2];
-    a0[0] = *reinterpret_cast<const w_f32x2*>(As);
-    a1[0] = *reinterpret_cast<const w_f32x2*>(As + 16 * WBK);
-    b[0] = *reinterpret_cast<const w_f32x2*>(Bs);
+  const int ard = 2 * mh * 128 + 2 * lane;                             // + f*FS_A + mb*128
+  const int brd = 2 * W_A_ST + nw * 128 + 2 * lane;                    // + f*FS_B
+  using K0 = std::integral_constant<int, 0>;
+  using KD = std::integral_constant<int, DPW>;
+
+  // prologue: tile 0 staged, the activations of tile 1 in flight
+#pragma unroll
+  for (int j = 0; j < DPW; ++j) dma_b(0, 0, j);
+#pragma unroll
+  for (int i = 0; i < NLA; ++i) load_a(0, i);
+  fold(K0{});
+#pragma unroll
+  for (int j = 0; j < 4; ++j) transform(0, j);
+#pragma unroll
+  for (int i = 0; i < NLA; ++i) load_a(1, i);
+  __syncthreads();
+
+  // iteration kt: MFMAs of tile kt (stage cur); between them the weight DMA of tile kt+1, the
+  // transform of tile kt+1 (activations requested one iteration ago) and the activation loads of
+  // tile kt+2. ONE instance of the body (run-time stage offsets): unrolled over the stages hipcc
+  // gave the two copies different accumulator homes and moved 72 accumulators per iteration.
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1, nxt = cur ^ 1;
+    const float* As = lds + cur * W_A_ST + ard;
+    const float* Bs = lds + cur * W_B_ST + brd;
+    // fragments of frequency f+2 are requested while the MFMAs of f run (three register sets)
+    w_f32x2 a0[3], a1[3], b[3];
+    if (!(ABL & 1)) {
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        a0[f] = *reinterpret_cast<const w_f32x2*>(As + f * W_FS_A);
+        a1[f] = *reinterpret_cast<const w_f32x2*>(As + f * W_FS_A + 128);
+        b[f] = *reinterpret_cast<const w_f32x2*>(Bs + f * W_FS_B);
+      }
+    }
 #pragma unroll
     for (int f = 0; f < 16; ++f) {
-      const int cur = f & 1, nxt = cur ^ 1;
-      if (f + 1 < 16) {
-        a0[nxt] = *reinterpret_cast<const w_f32x2*>(As + (f + 1) * W_FS_A);
-        a1[nxt] = *reinterpret_cast<const w_f32x2*>(As + (f + 1) * W_FS_A + 16 * WBK);
-        b[nxt] = *reinterpret_cast<const w_f32x2*>(Bs + (f + 1) * W_FS_B);
+      const int c3 = f % 3, n3 = (f + 2) % 3;
+      if (!(ABL & 1) && f + 2 < 16) {
+        a0[n3] = *reinterpret_cast<const w_f32x2*>(As + (f + 2) * W_FS_A);
+        a1[n3] = *reinterpret_cast<const w_f32x2*>(As + (f + 2) * W_FS_A + 128);
+        b[n3] = *reinterpret_cast<const w_f32x2*>(Bs + (f + 2) * W_FS_B);
+      }
+      // one piece of side work per frequency step (VMEM ops in this order: DMA, then loads)
+      if (f < DPW) dma_b(nxt, kt + 1, f);
+      if (f == DPW) fold(KD{});                       // younger than tile kt+1's loads: the DMAs
+      if (f > DPW && f <= DPW + 4) transform(nxt, f - DPW - 1);
+      // the loads of tile kt+2 reuse the registers fold() has just read: issued right behind it,
+      // a whole iteration before their own fold (10 steps ahead left ~10 us of exposed latency)
+      if (f >= DPW && f < DPW + NLA) load_a(kt + 2, f - DPW);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(ABL & 1)) {
+        acc[f][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[c3].x, b[c3].x, acc[f][0], 0, 0, 0);
+        acc[f][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[c3].x, b[c3].x, acc[f][1], 0, 0, 0);
+        acc[f][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[c3].y, b[c3].y, acc[f][0], 0, 0, 0);
+        acc[f][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[c3].y, b[c3].y, acc[f][1], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
-      acc[f][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[cur].x, b[cur].x, acc[f][0], 0, 0, 0);
-      acc[f][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[cur].x, b[cur].x, acc[f][1], 0, 0, 0);
-      acc[f][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[cur].y, b[cur].y, acc[f][0], 0, 0, 0);
-      acc[f][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[cur].y, b[cur].y, acc[f][1], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
     }
-  };
-
-  // ONE instance of the loop body (stage offsets are run-time values): with the body unrolled
-  // over the two stages hipcc gave the two copies different accumulator homes (AGPR / VGPR) and
-  // moved 72 accumulators back and forth every iteration
-  issue(0, 0);
-  store(0);
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    const bool more = kt + 1 < nk;
-    if (more) issue(cur ^ 1, kt + 1);
-    compute(cur);
-    if (more) store(cur ^ 1);
-    __syncthreads();
+    // the weight DMA of tile kt+1 has landed (only the NLA loads of tile kt+2 are younger)
+    if (NLA == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if (!(ABL & 32)) __syncthreads();
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped re-loads of the last iterations
 
   // ---- output transform + store; D layout of the 16x16 tile: column = lane & 15, rows
   // 4 * (lane >> 4) + e ----
@@ -311,7 +357,8 @@ __global__ __launch_bounds__(W_THREADS) void conv_wino_kernel(WinoArgs g) {
 }
 
 // U = G g G^T per (cout, cin), row 3 negated (see the kernel), written as
-// [k-tile = c/8][n-tile = n/64][frequency 4i+j][n % 64][c % 8]
+// [k-tile = c/8][n-tile = n/64][frequency 4i+j][16-channel block][(c % 8) >> 1][n % 16][c & 1]
+// (per frequency and block the order in which the MFMA lanes read it, see the A image)
 __global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict__ w, float* __restrict__ out,
                                                         int Cout, int Cin) {
   const long total = (long)Cout * Cin;
@@ -329,7 +376,8 @@ __global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict_
       t[2][b] = 0.5 * (gg[0][b] - gg[1][b] + gg[2][b]);
       t[3][b] = gg[2][b];
     }
-    float* dst = out + ((size_t)(c / WBK) * tiles_n + n / WBN) * W_B_ST + (size_t)(n % WBN) * WBK + c % WBK;
+    float* dst = out + ((size_t)(c / WBK) * tiles_n + n / WBN) * W_B_ST + (size_t)((n % WBN) / 16) * 128 +
+                 (((c % WBK) >> 1) * 16 + n % 16) * 2 + (c & 1);
     for (int a = 0; a < 4; ++a) {
       const double u0 = t[a][0];
       const double u1 = 0.5 * (t[a][0] + t[a][1] + t[a][2]);
@@ -414,6 +462,25 @@ int conv2d_fwd_wino(const float* x, long sxb, long sxh, long sxw, const float* w
     attr_set[variant] = true;
   }
   const dim3 grid((unsigned)wgs), block(W_THREADS);
+  if (const char* e = getenv("CAPNET_WINO_ABLATE")) {   // diagnostics (tools/conv_bench.py): wrong results
+    const int abl = atoi(e);
+    CAPNET_REQUIRE(variant == 1, "CAPNET_WINO_ABLATE: prologue variant only");
+#define CAPNET_WINO_ABL(A)                                                                              \
+  case A: {                                                                                             \
+    CAPNET_HIP_CHECK(hipFuncSetAttribute((const void*)conv_wino_kernel<true, false, A>,                 \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));  \
+    hipLaunchKernelGGL((conv_wino_kernel<true, false, A>), grid, block, lds_bytes, stream, g);          \
+    CAPNET_LAUNCH_CHECK();                                                                              \
+    return kOk;                                                                                         \
+  }
+    switch (abl) {
+      CAPNET_WINO_ABL(14) CAPNET_WINO_ABL(30) CAPNET_WINO_ABL(46) CAPNET_WINO_ABL(62) CAPNET_WINO_ABL(2)
+      CAPNET_WINO_ABL(12) CAPNET_WINO_ABL(1) CAPNET_WINO_ABL(32) CAPNET_WINO_ABL(66) CAPNET_WINO_ABL(6)
+      CAPNET_WINO_ABL(10) CAPNET_WINO_ABL(70) CAPNET_WINO_ABL(74)
+      default: break;
+    }
+#undef CAPNET_WINO_ABL
+  }
   switch (variant) {
     case 0: hipLaunchKernelGGL((conv_wino_kernel<false, false>), grid, block, lds_bytes, stream, g); break;
     case 1: hipLaunchKernelGGL((conv_wino_kernel<true, false>), grid, block, lds_bytes, stream, g); break;

@@ -13,6 +13,7 @@
 //     --[bn2+relu on load] conv3--> Y3 raw (+stats);  [X --convD--> D raw (+stats)]
 //   OUT = relu(bn3(Y3) + (bnD(D) | X))         (bn_add_relu)
 #include <algorithm>
+#include <cstdlib>
 #include <utility>
 #include <vector>
 
@@ -27,6 +28,7 @@ struct TrunkConv {
   int OH, OW;  // output spatial size
   int Kw;      // packed K extent (rows of the K-major image / row stride of the row-major one)
   bool kmajor; // weights packed [Kw][Cout] for conv_f32_v2 (else [Cout][Kw] for conv_f32)
+  bool wino;   // 3x3 / stride 1 on an even map: Winograd F(2x2,3x3) (conv_wino.hip), its own weight image
 };
 
 struct Trunk {
@@ -57,6 +59,9 @@ int trunk_create(int B, int H, int W, Trunk** out) {
                  "trunk_create: batch %d image %dx%d (sides must be multiples of 32)", B, H, W);
   Trunk* t = new Trunk();
   t->B = B; t->H = H; t->W = W;
+  // CAPNET_NO_WINOGRAD=1: every 3x3 through the direct implicit-GEMM kernel (A/B runs, diagnostics)
+  const char* now = getenv("CAPNET_NO_WINOGRAD");
+  const bool use_wino = !(now && now[0] == '1');
   auto add = [&](int cin, int cout, int k, int stride, int pad, int h, int w) {
     TrunkConv c;
     c.Cin = cin; c.Cout = cout; c.k = k; c.stride = stride; c.pad = pad; c.H = h; c.W = w;
@@ -64,6 +69,7 @@ int trunk_create(int B, int H, int W, Trunk** out) {
     c.OW = (w + 2 * pad - k) / stride + 1;
     c.Kw = round_up(k * k * cin, 16);
     c.kmajor = (cin % 16 == 0) && (cout % 64 == 0);
+    c.wino = use_wino && c.kmajor && conv_wino_shape_ok(h, w, cin, cout, k, k, stride, pad);
     t->convs.push_back(c);
     return c;
   };
@@ -109,6 +115,7 @@ int trunk_create(int B, int H, int W, Trunk** out) {
     const long M = (long)B * c.OH * c.OW;
     const int tile = c.kmajor ? conv_v2_auto_tile((int)M, c.Cout, c.Kw) : conv_auto_tile((int)M, c.Cout);
     max_part = std::max(max_part, (size_t)conv_tiles_m((int)M, tile) * c.Cout);
+    if (c.wino) max_part = std::max(max_part, (size_t)conv_wino_tiles_m(B, c.H, c.W) * c.Cout);
   }
   t->off_part = take(2 * max_part);
   size_t max_slab = 0;
@@ -188,7 +195,8 @@ int trunk_conv_shape(const Trunk* t, int i, int* cout, int* cin, int* k, int* st
 }
 
 int trunk_conv_kmajor(const Trunk* t, int i) {
-  return (i >= 0 && i < (int)t->convs.size() && t->convs[i].kmajor) ? 1 : 0;
+  if (i < 0 || i >= (int)t->convs.size()) return 0;
+  return t->convs[i].wino ? 2 : (t->convs[i].kmajor ? 1 : 0);
 }
 
 double trunk_flops(const Trunk* t) {
@@ -227,8 +235,10 @@ int conv_bn(const Ctx& c, int i, const float* x, long sxb, long sxh, long sxw, l
   // MFMA) wins on the layers with many output rows -- measured +2 % images/s for M >= 5000
   int tile = d.kmajor ? conv_v2_auto_tile((int)M, d.Cout, d.Kw) : conv_auto_tile((int)M, d.Cout);
   if (d.kmajor && !c.t->tail_balance && M >= 5000) tile = 12864;
+  // rows of the statistics partials this conv writes
+  const int prows = d.wino ? conv_wino_tiles_m(c.t->B, d.H, d.W) : conv_tiles_m((int)M, tile);
   float* psum = c.ws + c.t->off_part;
-  float* psq = psum + (size_t)conv_tiles_m((int)M, tile) * d.Cout;
+  float* psq = psum + (size_t)prows * d.Cout;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (c.t->timing) {
     CAPNET_HIP_CHECK(hipEventCreate(&e0));
@@ -236,7 +246,11 @@ int conv_bn(const Ctx& c, int i, const float* x, long sxb, long sxh, long sxw, l
     CAPNET_HIP_CHECK(hipEventRecord(e0, c.s));
   }
   int rc;
-  if (d.kmajor) {
+  if (d.wino) {
+    CAPNET_REQUIRE(sxc == 1, "trunk: conv %d planned for the Winograd kernel needs channel-contiguous input", i);
+    rc = conv2d_fwd_wino(x, sxb, sxh, sxw, c.w[i], y, in_scale, in_shift, relu_in, c.train ? psum : nullptr,
+                         c.train ? psq : nullptr, c.t->B, d.H, d.W, d.Cin, d.Cout, c.s);
+  } else if (d.kmajor) {
     CAPNET_REQUIRE(conv_v2_eligible(x, sxb, sxh, sxw, sxc, c.t->B, d.Cin, d.Cout, in_scale, in_shift),
                    "trunk: conv %d planned for the K-major kernel but its operands are not eligible", i);
     rc = conv2d_fwd_v2(x, sxb, sxh, sxw, c.w[i], d.Kw, y, in_scale, in_shift, relu_in,
@@ -256,11 +270,11 @@ int conv_bn(const Ctx& c, int i, const float* x, long sxb, long sxh, long sxw, l
   }
   if (rc) return rc;
   if (c.train == 2)   // running statistics deferred to trunk_update_running
-    return bn_finalize(psum, psq, conv_tiles_m((int)M, tile), d.Cout, M, c.gamma[i], c.beta[i],
+    return bn_finalize(psum, psq, prows, d.Cout, M, c.gamma[i], c.beta[i],
                        nullptr, nullptr, c.momentum, c.eps, c.scale(i), c.shift(i), c.s, c.bmean(i),
                        c.bvar(i));
   if (c.train)
-    return bn_finalize(psum, psq, conv_tiles_m((int)M, tile), d.Cout, M, c.gamma[i], c.beta[i],
+    return bn_finalize(psum, psq, prows, d.Cout, M, c.gamma[i], c.beta[i],
                        c.rmean[i], c.rvar[i], c.momentum, c.eps, c.scale(i), c.shift(i), c.s);
   return bn_eval_scale_shift(c.gamma[i], c.beta[i], c.rmean[i], c.rvar[i], c.eps, d.Cout,
                              c.scale(i), c.shift(i), c.s);
@@ -278,10 +292,17 @@ int conv_folded(const Ctx& c, int i, const float* x, const float* res, int relu,
     CAPNET_HIP_CHECK(hipEventCreate(&e1));
     CAPNET_HIP_CHECK(hipEventRecord(e0, c.s));
   }
-  const int rc = conv2d_fwd_v2(x, sb, sh, sw, c.w[i], d.Kw, y, nullptr, nullptr, 0, nullptr, nullptr,
-                               c.t->B, d.H, d.W, d.Cin, d.Cout, d.k, d.k, d.stride, d.pad, 0,
-                               c.t->tail_balance ? c.ws + c.t->off_slab : nullptr, c.s, c.scale(i),
-                               c.shift(i), res, relu);
+  int rc;
+  if (d.wino) {
+    CAPNET_REQUIRE(res == nullptr, "trunk: conv %d (Winograd) has no residual input", i);
+    rc = conv2d_fwd_wino(x, sb, sh, sw, c.w[i], y, nullptr, nullptr, 0, nullptr, nullptr, c.t->B, d.H, d.W,
+                         d.Cin, d.Cout, c.s, c.scale(i), c.shift(i), relu);
+  } else {
+    rc = conv2d_fwd_v2(x, sb, sh, sw, c.w[i], d.Kw, y, nullptr, nullptr, 0, nullptr, nullptr,
+                       c.t->B, d.H, d.W, d.Cin, d.Cout, d.k, d.k, d.stride, d.pad, 0,
+                       c.t->tail_balance ? c.ws + c.t->off_slab : nullptr, c.s, c.scale(i),
+                       c.shift(i), res, relu);
+  }
   if (c.t->timing) {
     CAPNET_HIP_CHECK(hipEventRecord(e1, c.s));
     c.t->ev.push_back(e0);

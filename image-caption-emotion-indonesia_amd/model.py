@@ -178,8 +178,11 @@ class _TrunkRunner:
                 if tuple(c.weight.shape) != (cout, cin, k, k) or c.stride != stride:
                     raise CapnetError("conv %d: module shape %s does not match the plan" %
                                       (i, tuple(c.weight.shape)))
-                kmajor = bool(L.capnet_trunk_conv_kmajor(plan["handle"], i))
-                packed.append(ops.pack_conv_weight(c.weight.detach(), kw, kmajor=kmajor))
+                kind = L.capnet_trunk_conv_kmajor(plan["handle"], i)   # 0 rows, 1 K-major, 2 Winograd
+                if kind == 2:
+                    packed.append(ops.pack_conv_weight_wino(c.weight.detach()))
+                else:
+                    packed.append(ops.pack_conv_weight(c.weight.detach(), kw, kmajor=kind == 1))
             self.packed, self.packed_key = packed, key
         return self.packed
 

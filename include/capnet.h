@@ -119,7 +119,9 @@ int capnet_trunk_set_timing(capnet_trunk_t* t, int enable);
 int capnet_trunk_collect_timing(capnet_trunk_t* t, double* conv_ms, long* conv_launches,
                                 double* conv_flops);
 /* Weight image convolution i expects: 0 = rows [Cout][row_stride] (capnet_pack_conv_weight),
- * 1 = K-major [row_stride][Cout] (capnet_pack_conv_weight_kmajor; streamed to LDS by LDS-DMA). */
+ * 1 = K-major [row_stride][Cout] (capnet_pack_conv_weight_kmajor; streamed to LDS by LDS-DMA),
+ * 2 = Winograd F(2x2,3x3) (capnet_pack_conv_weight_wino: the 3x3 / stride-1 convolutions on even
+ * maps, unless the trunk was created with CAPNET_NO_WINOGRAD=1 in the environment). */
 int capnet_trunk_conv_kmajor(const capnet_trunk_t* t, int i);
 int capnet_pack_conv_weight_kmajor(const float* w_oihw, float* out, int Cout, int Cin, int KH,
                                    int KW, int k_rows, capnet_stream_t stream);
