@@ -45,8 +45,7 @@ constexpr int WBN = 64;              // output channels per workgroup
 constexpr int WBK = 8;               // input channels per k-tile
 constexpr int W_THREADS = 8 * WBT;   // one thread per (tile, patch row, channel quad)
 constexpr int W_WAVES = W_THREADS / 64;
-constexpr int W_FS_A = WBT * WBK + 2;  // floats per frequency plane of the A image (+2: the four
-                                       // patch-row lanes of a quad write to different banks)
+constexpr int W_FS_A = WBT * WBK;     // floats per frequency plane of the A image
 constexpr int W_FS_B = WBN * WBK;
 constexpr int W_A_ST = 16 * W_FS_A;  // floats per A stage
 constexpr int W_B_ST = 16 * W_FS_B;
@@ -100,15 +99,10 @@ __device__ __forceinline__ void w_gload16(w_f32x4& dst, const float* sbase, unsi
   asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff_bytes), "s"(sbase) : "memory");
 }
 
-// quad_perm [2,2,1,1]: lanes 0,1 of a quad read lane 2, lanes 2,3 read lane 1
-__device__ __forceinline__ float w_quad_other(float v) {
-  return __builtin_bit_cast(
-      float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x5A, 0xF, 0xF, true));
-}
-
 // ABL: compile-time ablation mask for tools/conv_bench.py (CAPNET_WINO_ABLATE), 0 in the product:
 // 1 no ds_read + MFMA, 2 no transform / LDS store, 4 no weight DMA, 8 no activation loads,
-// 16 MFMAs without their LDS reads, 32 no barrier in the k-loop
+// 16 MFMAs without their LDS reads, 32 no barrier in the k-loop, 128 no wait for the weight DMA,
+// 256 no wait for the activation loads
 template <bool PRE, bool EPI, int ABL = 0>
 __global__ __launch_bounds__(W_THREADS) void conv_wino_kernel(WinoArgs g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -152,10 +146,14 @@ __global__ __launch_bounds__(W_THREADS) void conv_wino_kernel(WinoArgs g) {
   // A image: [frequency][16-tile block][kq = k >> 1][tile in block][k & 1], the order in which
   // the MFMA lanes (lane = 16 kq + tile) read it: one contiguous 512 B per ds_read_b64 (a
   // [tile][k] image costs a 4-way bank conflict per read: measured 83 vs 55 us of pure MFMA time)
-  const int awr = (4 * r) * W_FS_A + (tl >> 4) * 128 + (2 * q * 16 + (tl & 15)) * 2;  // + j*FS_A; k pair 2q+1: + 32
+  // Inside a 16-tile row the tiles of frequency row i = f >> 2 are rotated by 4i: the four patch-
+  // row lanes of a quad (which write the four frequency rows) then hit different banks, and the
+  // planes can stay 2 KB apart, so every fragment read is one base register + an immediate.
+  const int awr = (4 * r) * W_FS_A + (tl >> 4) * 128 + (2 * q * 16 + ((tl + 4 * r) & 15)) * 2;  // + j*FS_A; k pair 2q+1: + 32
 
   const unsigned lds_b0 = __builtin_amdgcn_readfirstlane(
-      (unsigned)(size_t)(__attribute__((address_space(3))) float*)(lds + 2 * W_A_ST));
+      (unsigned)(size_t)(__attribute__((address_space(3))) float*)(lds));   // B stages first: their
+  // ds_read_b64 immediates (16 bit) then reach every plane; the A reads use the 512-B-unit offsets of ds_read2st64
   const float* wblk = g.wp + (size_t)tn * W_B_ST;          // + kt * tiles_n * W_B_ST
   const size_t wstep = (size_t)g.tiles_n * W_B_ST;
 
@@ -186,7 +184,7 @@ __global__ __launch_bounds__(W_THREADS) void conv_wino_kernel(WinoArgs g) {
   // the activations of the next tile have landed once at most `keep` younger VMEM ops are in flight
   auto fold = [&](auto keep) {
     if (ABL & 2) return;
-    constexpr int KEEP = decltype(keep)::value;
+    constexpr int KEEP = (ABL & 256) ? 63 : decltype(keep)::value;
     if (PRE)
       asm volatile("s_waitcnt vmcnt(%6)"
                    : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(av[3]), "+v"(scv), "+v"(shv)
@@ -204,17 +202,26 @@ __global__ __launch_bounds__(W_THREADS) void conv_wino_kernel(WinoArgs g) {
   };
   auto transform = [&](int stage, int j) {   // frequency column j of this thread's patch row
     if (ABL & 2) return;
-    float* dst = lds + stage * W_A_ST + awr + j * W_FS_A;
+    float* dst = lds + 2 * W_B_ST + stage * W_A_ST + awr + j * W_FS_A;
     w_f32x4 o;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      // row transform B^T along the patch row, then the column transform through the quad
-      const float rj = j == 0 ? d[0][c] - d[2][c]
-                     : j == 1 ? d[1][c] + d[2][c]
-                     : j == 2 ? d[2][c] - d[1][c]
-                              : d[1][c] - d[3][c];
-      o[c] = fmaf(w_quad_other(rj), sgn, rj);
-    }
+    for (int c = 0; c < 4; ++c)   // row transform B^T along the patch row
+      o[c] = j == 0 ? d[0][c] - d[2][c]
+           : j == 1 ? d[1][c] + d[2][c]
+           : j == 2 ? d[2][c] - d[1][c]
+                    : d[1][c] - d[3][c];
+    // column transform through the quad: o += sgn * o[lane of the other row], ONE VALU each
+    // (v_fmac with a DPP source, quad_perm [2,2,1,1]: lanes 0,1 of a quad read lane 2, lanes 2,3
+    // read lane 1; hipcc emits v_mov_dpp + v_fma for the builtin). s_nop 1: the two wait states a
+    // DPP read needs after a VALU write of the same register.
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_fmac_f32_dpp %0, %0, %4 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %1, %1, %4 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %2, %2, %4 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %3, %3, %4 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf"
+        : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3])
+        : "v"(sgn));
     *reinterpret_cast<w_f32x2*>(dst) = w_f32x2{o[0], o[1]};
     *reinterpret_cast<w_f32x2*>(dst + 32) = w_f32x2{o[2], o[3]};
   };
@@ -228,8 +235,10 @@ __global__ __launch_bounds__(W_THREADS) void conv_wino_kernel(WinoArgs g) {
   // wave -> (tile half mh: tiles 32 mh .. 32 mh + 31, channel group nw: channels 16 nw .. + 15)
   const int li = lane & 15, kq = lane >> 4;
   const int mh = wave >> 2, nw = wave & 3;
-  const int ard = 2 * mh * 128 + 2 * lane;                             // + f*FS_A + mb*128
-  const int brd = 2 * W_A_ST + nw * 128 + 2 * lane;                    // + f*FS_B
+  int ard[4];                                                          // + f*FS_A + mb*128
+#pragma unroll
+  for (int i = 0; i < 4; ++i) ard[i] = 2 * mh * 128 + kq * 32 + ((li + 4 * i) & 15) * 2;
+  const int brd = nw * 128 + 2 * lane;                                 // + f*FS_B
   using K0 = std::integral_constant<int, 0>;
   using KD = std::integral_constant<int, DPW>;
 
@@ -251,15 +260,17 @@ __global__ __launch_bounds__(W_THREADS) void conv_wino_kernel(WinoArgs g) {
   // gave the two copies different accumulator homes and moved 72 accumulators per iteration.
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1, nxt = cur ^ 1;
-    const float* As = lds + cur * W_A_ST + ard;
+    const float* As4[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) As4[i] = lds + 2 * W_B_ST + cur * W_A_ST + ard[i];
     const float* Bs = lds + cur * W_B_ST + brd;
     // fragments of frequency f+2 are requested while the MFMAs of f run (three register sets)
     w_f32x2 a0[3], a1[3], b[3];
     if (!(ABL & 1)) {
 #pragma unroll
       for (int f = 0; f < 2; ++f) {
-        a0[f] = *reinterpret_cast<const w_f32x2*>(As + f * W_FS_A);
-        a1[f] = *reinterpret_cast<const w_f32x2*>(As + f * W_FS_A + 128);
+        a0[f] = *reinterpret_cast<const w_f32x2*>(As4[f >> 2] + f * W_FS_A);
+        a1[f] = *reinterpret_cast<const w_f32x2*>(As4[f >> 2] + f * W_FS_A + 128);
         b[f] = *reinterpret_cast<const w_f32x2*>(Bs + f * W_FS_B);
       }
     }
@@ -267,8 +278,8 @@ __global__ __launch_bounds__(W_THREADS) void conv_wino_kernel(WinoArgs g) {
     for (int f = 0; f < 16; ++f) {
       const int c3 = f % 3, n3 = (f + 2) % 3;
       if (!(ABL & 1) && f + 2 < 16) {
-        a0[n3] = *reinterpret_cast<const w_f32x2*>(As + (f + 2) * W_FS_A);
-        a1[n3] = *reinterpret_cast<const w_f32x2*>(As + (f + 2) * W_FS_A + 128);
+        a0[n3] = *reinterpret_cast<const w_f32x2*>(As4[(f + 2) >> 2] + (f + 2) * W_FS_A);
+        a1[n3] = *reinterpret_cast<const w_f32x2*>(As4[(f + 2) >> 2] + (f + 2) * W_FS_A + 128);
         b[n3] = *reinterpret_cast<const w_f32x2*>(Bs + (f + 2) * W_FS_B);
       }
       // one piece of side work per frequency step (VMEM ops in this order: DMA, then loads)
@@ -288,8 +299,10 @@ __global__ __launch_bounds__(W_THREADS) void conv_wino_kernel(WinoArgs g) {
       __builtin_amdgcn_sched_barrier(0);
     }
     // the weight DMA of tile kt+1 has landed (only the NLA loads of tile kt+2 are younger)
-    if (NLA == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if (!(ABL & 128)) {
+      if (NLA == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    }
     if (!(ABL & 32)) __syncthreads();
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped re-loads of the last iterations
@@ -337,9 +350,10 @@ __global__ __launch_bounds__(W_THREADS) void conv_wino_kernel(WinoArgs g) {
             cq = fmaf(y0, y0, cq);
             cq = fmaf(y1, y1, cq);
           }
-          const long px = ((long)b * g.H + 2 * th + a) * g.W + 2 * tw;
-          g.y[px * g.N + n] = y0;
-          g.y[(px + 1) * g.N + n] = y1;
+          // 32-bit byte offsets from one scalar base (the launcher checks 4*M*N < 4 GB)
+          const unsigned off = ((unsigned)((b * g.H + 2 * th + a) * g.W + 2 * tw) * (unsigned)g.N + (unsigned)n) * 4u;
+          asm volatile("global_store_dword %0, %1, %2" ::"v"(off), "v"(y0), "s"(g.y) : "memory");
+          asm volatile("global_store_dword %0, %1, %2" ::"v"(off + (unsigned)g.N * 4u), "v"(y1), "s"(g.y) : "memory");
         }
       }
     }
@@ -441,6 +455,7 @@ int conv2d_fwd_wino(const float* x, long sxb, long sxh, long sxw, const float* w
   g.TH = H / 2; g.TW = W / 2;
   const long T = (long)Bn * g.TH * g.TW;
   CAPNET_REQUIRE(T < (1L << 24), "conv2d_fwd_wino: too many tiles (%ld)", T);
+  CAPNET_REQUIRE((long)Bn * H * W * Cout * 4 < (1L << 32), "conv2d_fwd_wino: output larger than 4 GB");
   g.T = (int)T;
   g.tiles_m = cdiv(T, WBT);
   g.tiles_n = Cout / WBN;
@@ -476,7 +491,8 @@ int conv2d_fwd_wino(const float* x, long sxb, long sxh, long sxw, const float* w
     switch (abl) {
       CAPNET_WINO_ABL(14) CAPNET_WINO_ABL(30) CAPNET_WINO_ABL(46) CAPNET_WINO_ABL(62) CAPNET_WINO_ABL(2)
       CAPNET_WINO_ABL(12) CAPNET_WINO_ABL(1) CAPNET_WINO_ABL(32) CAPNET_WINO_ABL(66) CAPNET_WINO_ABL(6)
-      CAPNET_WINO_ABL(10) CAPNET_WINO_ABL(70) CAPNET_WINO_ABL(74)
+      CAPNET_WINO_ABL(10) CAPNET_WINO_ABL(70) CAPNET_WINO_ABL(74) CAPNET_WINO_ABL(128) CAPNET_WINO_ABL(256)
+      CAPNET_WINO_ABL(384) CAPNET_WINO_ABL(416)
       default: break;
     }
 #undef CAPNET_WINO_ABL
