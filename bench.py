@@ -260,8 +260,12 @@ def main():
         if n.value > 0:
             achieved = fl.value / (ms.value * 1e-3) / 1e12
             roofline = {"bound": "mfma",
-                        "kernel": "conv_f32_v2_kernel (implicit-GEMM conv, v_mfma_f32_32x32x2_f32; each "
-                                  "launch = the conv, its tail fix-up if any; the 7x7 stem is conv_f32_kernel)",
+                        "kernel": "the trunk's 155 conv launches: conv_f32_v2_kernel (implicit GEMM, "
+                                  "v_mfma_f32_32x32x2_f32) for the 1x1 / strided convs, conv_wino_kernel "
+                                  "(Winograd F(2x2,3x3), v_mfma_f32_16x16x4_f32) for the 45 stride-1 3x3 convs, "
+                                  "conv_f32_kernel for the 7x7 stem; a launch includes its tail fix-up if any",
+                        "flops": "ALGORITHMIC: 2*M*Cout*KH*KW*Cin of the direct sum (SURVEY 8d: 23.02 GFLOP per image); "
+                                 "the Winograd launches execute 2.25x fewer multiplies than counted",
                         "how": "HIP events around every conv launch of the timed region, on its launch stream; "
                                "duration = time with at least one conv launch running (union of the "
                                "intervals: two trunk passes are in flight, their launches overlap)",
