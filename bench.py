@@ -273,6 +273,17 @@ def main():
                         "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": pmc_traffic(),
                         "launches": n.value, "avg_launch_us": round(ms.value * 1e3 / n.value, 2),
                         "flops_per_launch": fl.value / n.value}
+            # multiplies actually issued: the Winograd launches (weight image kind 2) do 16 per 2x2
+            # outputs and input channel instead of 36
+            algo = execd = 0.0
+            for i in range(lib.capnet_trunk_num_convs(plan["handle"])):
+                fi = lib.capnet_trunk_conv_flops(plan["handle"], i)
+                algo += fi
+                execd += fi / (2.25 if lib.capnet_trunk_conv_kmajor(plan["handle"], i) == 2 else 1.0)
+            roofline["executed"] = {"achieved": round(achieved * execd / algo, 2),
+                                    "frac": round(achieved * execd / algo / MFMA_F32_PEAK_TFLOPS, 4),
+                                    "note": "MFMA flops issued per second (Winograd layers counted at 16/36 of "
+                                            "their direct-sum flops): what the matrix pipe itself sustains"}
             if pipe is not None:
                 # In the timed region the convolutions share the chip with the previous batch's
                 # decoder (that is where the throughput comes from, and it lengthens each conv a

@@ -37,6 +37,7 @@ SIGNATURES = {
     "capnet_trunk_num_convs": (_i, [_vp]),
     "capnet_trunk_final_side": (_i, [_vp]),
     "capnet_trunk_flops": (C.c_double, [_vp]),
+    "capnet_trunk_conv_flops": (C.c_double, [_vp, _i]),
     "capnet_trunk_conv_shape": (_i, [_vp, _i, _ip, _ip, _ip, _ip, _ip]),
     "capnet_trunk_forward": (_i, [_vp, _vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp),
                                   C.POINTER(_vp), C.POINTER(_vp), _i, C.c_float, C.c_float, _vp,

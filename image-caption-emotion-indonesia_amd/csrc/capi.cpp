@@ -88,6 +88,9 @@ int capnet_trunk_update_running(const capnet_trunk_t* t, const void* workspace,
                               reinterpret_cast<const float*>(workspace), bn_running_mean, bn_running_var,
                               momentum, S(stream));
 }
+double capnet_trunk_conv_flops(const capnet_trunk_t* t, int i) {
+  return trunk_conv_flops(reinterpret_cast<const Trunk*>(t), i);
+}
 int capnet_trunk_conv_kmajor(const capnet_trunk_t* t, int i) {
   return trunk_conv_kmajor(reinterpret_cast<const Trunk*>(t), i);
 }

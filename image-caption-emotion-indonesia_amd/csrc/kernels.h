@@ -85,6 +85,7 @@ int trunk_final_side(const Trunk* t);
 int trunk_conv_shape(const Trunk* t, int i, int* cout, int* cin, int* k, int* stride, int* kw);
 int trunk_conv_kmajor(const Trunk* t, int i);
 double trunk_flops(const Trunk* t);
+double trunk_conv_flops(const Trunk* t, int i);
 int trunk_set_timing(Trunk* t, int enable);
 int trunk_collect_timing(Trunk* t, double* conv_ms, long* conv_launches, double* conv_flops);
 int trunk_set_tail_balance(Trunk* t, int on);

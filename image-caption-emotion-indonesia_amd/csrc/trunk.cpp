@@ -199,6 +199,12 @@ int trunk_conv_kmajor(const Trunk* t, int i) {
   return t->convs[i].wino ? 2 : (t->convs[i].kmajor ? 1 : 0);
 }
 
+double trunk_conv_flops(const Trunk* t, int i) {
+  if (i < 0 || i >= (int)t->convs.size()) return 0.0;
+  const TrunkConv& c = t->convs[i];
+  return 2.0 * t->B * c.OH * c.OW * (double)c.Cout * c.k * c.k * c.Cin;
+}
+
 double trunk_flops(const Trunk* t) {
   double f = 0;
   for (auto& c : t->convs)

@@ -87,6 +87,7 @@ size_t capnet_trunk_workspace_bytes(const capnet_trunk_t* t);
 int capnet_trunk_num_convs(const capnet_trunk_t* t);
 int capnet_trunk_final_side(const capnet_trunk_t* t);
 double capnet_trunk_flops(const capnet_trunk_t* t); /* 2*MACs of all convolutions, this batch */
+double capnet_trunk_conv_flops(const capnet_trunk_t* t, int i); /* 2*MACs of convolution i (direct sum) */
 int capnet_trunk_conv_shape(const capnet_trunk_t* t, int i, int* cout, int* cin, int* ksize,
                             int* stride, int* row_stride);
 /* w_packed / bn_* : HOST arrays of num_convs DEVICE pointers. out_pooled and/or out_map may

@@ -31,8 +31,22 @@ def main():
     root = sys.argv[1]
     fetch = collect(os.path.join(root, "fetch"), "FETCH_SIZE")
     write = collect(os.path.join(root, "write"), "WRITE_SIZE")
-    conv = lambda n: "conv_f32" in n or "conv_tail_fixup" in n
-    launches = sum(v[0] for k, v in fetch.items() if "conv_f32" in k)     # fix-ups belong to a conv
+    if len(sys.argv) > 2 and sys.argv[2] == "--per-kernel":
+        # raw per-kernel sums (profiles/round1_pmc_per_kernel.csv)
+        print("# rocprofv3 --kernel-trace --pmc FETCH_SIZE (pass 1) / WRITE_SIZE (pass 2) -- python3 bench.py "
+              "--steps 2 --warmup 1 --no-cpu-baseline --no-conv-events --no-lstm-roofline")
+        print("# raw counter sums in KB over the run (pipelined: 3 + 3 trunk passes, 3 decoder steps); FETCH_SIZE "
+              "must be doubled on gfx950 (MI355X_MICROARCH.md, HBM section)")
+        print("kernel,dispatches,fetch_size_kb_raw,write_size_kb")
+        for k, v in sorted(fetch.items(), key=lambda kv: -(2 * kv[1][1] + write.get(kv[0], [0, 0])[1]))[:14]:
+            print("%s,%d,%.0f,%.0f" % (k.replace(",", ";"), v[0], v[1], write.get(k, [0, 0])[1]))
+        return
+    conv = lambda n: "conv_f32" in n or "conv_wino" in n or "conv_tail_fixup" in n
+    launches = sum(v[0] for k, v in fetch.items() if "conv_f32" in k or "conv_wino" in k)   # fix-ups belong to a conv
+    wino = lambda n: "conv_wino" in n
+    wino_n = sum(v[0] for k, v in fetch.items() if wino(k))
+    wino_bytes = (2.0 * sum(v[1] for k, v in fetch.items() if wino(k)) +
+                  sum(v[1] for k, v in write.items() if wino(k))) * 1024.0
     fetch_kb = sum(v[1] for k, v in fetch.items() if conv(k))
     write_kb = sum(v[1] for k, v in write.items() if conv(k))
     ls = lambda n: "lstm_step_fused_kernel" in n
@@ -47,6 +61,8 @@ def main():
         "write_size_kb": write_kb,
         "conv_bytes_per_launch": round((2.0 * fetch_kb + write_kb) * 1024.0 / max(launches, 1)),
         "algorithmic_bytes_per_launch": round((232e6 + 2 * 90e6 * 64) / 155),
+        "winograd_launches": wino_n,
+        "winograd_bytes_per_launch": round(wino_bytes / max(wino_n, 1)),
         "lstm_step_launches": ls_n,
         "lstm_step_bytes_per_launch": round(ls_bytes / max(ls_n, 1)),
         "note": "FETCH_SIZE doubled (gfx950 tallies 128-B read requests at 64 B); per conv launch incl. "
