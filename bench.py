@@ -139,6 +139,12 @@ def cpu_baseline(args, steps):
 
 def main():
     args = parse()
+    # stdout carries exactly ONE line (the JSON): RCCL prints a version banner to fd 1 when the
+    # process group comes up, so everything else this process (and its libraries) writes to stdout
+    # goes to stderr, and the JSON line is written to the saved descriptor at the end.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -434,7 +440,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args, args.cpu_steps)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    os.close(json_fd)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
