@@ -182,6 +182,39 @@ def test_conv_winograd_3x3(dev, B, H, W, Cin, Cout, pre, epi):
         assert rel_err(psq.sum(0), (ref_nhwc ** 2).sum(0)) < 1e-5
 
 
+@pytest.mark.parametrize("H,C", [(56, 64), (28, 128), (14, 256)])
+def test_conv_winograd_full_size_against_direct_kernel(dev, H, C):
+    """BASELINE configs[1] sizes (batch 64): the three stride-1 3x3 shapes of the trunk through the
+    Winograd kernel and through the direct implicit-GEMM kernel, same inputs, same folded
+    BatchNorm + ReLU; outputs and statistics must agree (no CPU reference finishes these sizes in
+    seconds, so the two independent GPU kernels check each other)."""
+    B = 64
+    g = torch.Generator().manual_seed(H + C)
+    x = torch.randn(B, H, H, C, generator=g).to(dev)
+    w = (torch.randn(C, C, 3, 3, generator=g) * (2.0 / (9 * C)) ** 0.5).to(dev)
+    sc = (torch.rand(C, generator=g) + 0.5).to(dev)
+    sh = torch.randn(C, generator=g).to(dev)
+    M = B * H * H
+    ww = ops.pack_conv_weight_wino(w)
+    yw = torch.empty(M, C, device=dev)
+    tw = lib().capnet_conv_wino_tiles_m(B, H, H)
+    psw, pqw = torch.zeros(tw, C, device=dev), torch.zeros(tw, C, device=dev)
+    check(lib().capnet_conv2d_fwd_wino(ptr(x), H * H * C, H * C, C, ptr(ww), ptr(yw), ptr(sc), ptr(sh), 1,
+                                       ptr(psw), ptr(pqw), B, H, H, C, C, None, None, 0, current_stream()))
+    Kw = 9 * C
+    wk = ops.pack_conv_weight(w, Kw, kmajor=True)
+    yd = torch.empty(M, C, device=dev)
+    td = lib().capnet_conv_kmajor_tiles_m(M, C, Kw, 0)
+    psd, pqd = torch.zeros(td, C, device=dev), torch.zeros(td, C, device=dev)
+    slabs = torch.empty(max(1, lib().capnet_conv_kmajor_slab_floats(M, C, Kw, 0)), device=dev)
+    check(lib().capnet_conv2d_fwd_kmajor(ptr(x), H * H * C, H * C, C, ptr(wk), Kw, ptr(yd), ptr(sc), ptr(sh), 1,
+                                         ptr(psd), ptr(pqd), B, H, H, C, C, 3, 3, 1, 1, 0, ptr(slabs),
+                                         current_stream()))
+    assert rel_err(yw, yd) < 3e-6
+    assert rel_err(psw.double().sum(0), psd.double().sum(0)) < 1e-5
+    assert rel_err(pqw.double().sum(0), pqd.double().sum(0)) < 1e-5
+
+
 def test_conv_winograd_rejects_unsupported_shapes(dev):
     x = torch.zeros(1, 7, 7, 64, device=dev)
     wp = torch.zeros(16 * 64 * 64, device=dev)
