@@ -154,15 +154,23 @@ def main():
                              % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no GPU visible); there is no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # CAPNET_REHEARSE_ONE_GPU=1: every rank on device 0 with the gloo backend -- a multi-rank
+    # rehearsal of this script's sharding / scaling / barrier logic on a one-GPU box (RCCL refuses
+    # two ranks on one device). Not a measurement.
+    rehearse = os.environ.get("CAPNET_REHEARSE_ONE_GPU") == "1"
+    dev_index = 0 if rehearse else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         # the ranks share the host: keep torch's CPU pool small (the step runs no CPU operator)
         torch.set_num_threads(max(1, min(4, host_cores())))
     import torch.distributed as dist
     if world > 1 or os.environ.get("CAPNET_FORCE_ALLREDUCE") == "1":
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     import capnet
     from capnet import ops, synthetic

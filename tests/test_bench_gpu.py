@@ -1,0 +1,44 @@
+"""bench.py end to end: the one-line JSON contract on one rank, and a two-rank rehearsal of the
+multi-GPU launch (`torch.distributed.run`, rank-local shards, loss scaling, barrier / max-over-ranks
+timing) with both ranks on this box's single GPU over gloo -- RCCL refuses two ranks on one device,
+so the collective itself is covered by CAPNET_FORCE_ALLREDUCE (tests/test_step_gpu.py) and the CPU
+gloo tests (tests/test_parallel_cpu.py). Children are separate processes; nothing is exec-replaced."""
+import json
+import math
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(cmd, env_extra, timeout=600):
+    env = dict(os.environ)
+    env.update(env_extra)
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, "stdout must carry exactly one line, got %d: %r" % (len(lines), p.stdout[:400])
+    return json.loads(lines[0])
+
+
+def test_bench_prints_one_json_line():
+    d = _run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"], {})
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["unit"] == "images/sec" and d["scaling"] == "weak"
+    assert d["value"] > 0 and math.isfinite(d["loss_last"]) and d["dtype"] == "f32"
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and 0 < r["frac"] < 1.5 and 0 < r["executed"]["frac"] < 1
+    assert d["roofline_lstm_step"]["bound"] == "hbm"
+
+
+def test_two_rank_rehearsal_on_one_gpu():
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29541", "bench.py", "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--no-cpu-baseline", "--no-lstm-roofline"]
+    d = _run(cmd, {"CAPNET_REHEARSE_ONE_GPU": "1", "MASTER_ADDR": "127.0.0.1"})
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 128 and d["config"]["parallelism"] == "dp2"
+    assert d["value"] > 0 and math.isfinite(d["loss_first"]) and math.isfinite(d["loss_last"])
+    assert d["cpu_baseline"] is None
