@@ -489,10 +489,10 @@ int conv2d_fwd_wino(const float* x, long sxb, long sxh, long sxw, const float* w
     return kOk;                                                                                         \
   }
     switch (abl) {
-      CAPNET_WINO_ABL(14) CAPNET_WINO_ABL(30) CAPNET_WINO_ABL(46) CAPNET_WINO_ABL(62) CAPNET_WINO_ABL(2)
-      CAPNET_WINO_ABL(12) CAPNET_WINO_ABL(1) CAPNET_WINO_ABL(32) CAPNET_WINO_ABL(66) CAPNET_WINO_ABL(6)
-      CAPNET_WINO_ABL(10) CAPNET_WINO_ABL(70) CAPNET_WINO_ABL(74) CAPNET_WINO_ABL(128) CAPNET_WINO_ABL(256)
-      CAPNET_WINO_ABL(384) CAPNET_WINO_ABL(416)
+      // MFMA + LDS reads; MFMAs alone (with / without the barrier); no transform; no loads; no MFMA;
+      // no waits at all (results are wrong in every one of them)
+      CAPNET_WINO_ABL(14) CAPNET_WINO_ABL(30) CAPNET_WINO_ABL(62) CAPNET_WINO_ABL(2) CAPNET_WINO_ABL(12)
+      CAPNET_WINO_ABL(1) CAPNET_WINO_ABL(384)
       default: break;
     }
 #undef CAPNET_WINO_ABL
