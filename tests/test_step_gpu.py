@@ -35,9 +35,11 @@ def _encoder_state(enc):
     return new
 
 
-@pytest.mark.parametrize("kind", ["nic", "factored"])
-def test_three_train_steps_match_the_cpu_oracle(dev, kind):
-    B, V, lr, clip, steps = 8, 8192, 2e-3, 0.5, 3
+@pytest.mark.parametrize("kind,B,steps", [("nic", 8, 3), ("factored", 8, 3), ("factored", 64, 2)])
+def test_three_train_steps_match_the_cpu_oracle(dev, kind, B, steps):
+    """(factored, 64, 2) is BASELINE configs[1] at its full size: batch 64, V = 8192, two steps (the
+    second loss also checks the update); ~10 s of CPU oracle on 16 threads."""
+    V, lr, clip = 8192, 2e-3, 0.5
     torch.set_num_threads(16)
     enc = EncoderCNN(300)
     est = _encoder_state(enc)
@@ -95,7 +97,7 @@ def test_three_train_steps_match_the_cpu_oracle(dev, kind):
     print(kind, "oracle", ref_losses, "gpu", got)
     for a, b in zip(got, ref_losses):
         assert abs(a - b) / abs(b) < 1e-4, (got, ref_losses)
-    assert ref_losses[2] < ref_losses[0]      # the updates did something
+    assert ref_losses[-1] < ref_losses[0]     # the updates did something
 
 
 def _pipeline_vs_sequential(dev, tuning, graph=False):
