@@ -215,6 +215,29 @@ def test_conv_winograd_full_size_against_direct_kernel(dev, H, C):
     assert rel_err(pqw.double().sum(0), pqd.double().sum(0)) < 1e-5
 
 
+def test_conv_winograd_strided_input_view(dev):
+    """The ABI takes the input's batch / row / pixel strides: a channel slice of a wider NHWC tensor
+    (pixel stride Cin + 16, first channel 16: 64-B offset) must give the same result as its dense copy."""
+    B, H, W, Cin, Cout = 2, 6, 8, 32, 64
+    g = torch.Generator().manual_seed(11)
+    wide = torch.randn(B, H, W, Cin + 16, generator=g).to(dev)
+    xs = wide[..., 16:]                                   # view, strides (H*W*(Cin+16), W*(Cin+16), Cin+16, 1)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * 0.1).to(dev)
+    wp = ops.pack_conv_weight_wino(w)
+    M = B * H * W
+    outs = []
+    for x in (xs, xs.contiguous()):
+        y = torch.full((M, Cout), float("nan"), device=dev)
+        sb, sh, sw, sc = x.stride()
+        assert sc == 1
+        check(lib().capnet_conv2d_fwd_wino(x.data_ptr(), sb, sh, sw, ptr(wp), ptr(y), None, None, 0, None, None,
+                                           B, H, W, Cin, Cout, None, None, 0, current_stream()))
+        outs.append(y)
+    assert torch.equal(outs[0], outs[1])
+    ref = _conv_ref(xs.permute(0, 3, 1, 2).cpu(), w.cpu(), 1, 1).permute(0, 2, 3, 1).reshape(M, Cout)
+    assert rel_err(outs[0], ref) < 3e-6
+
+
 def test_conv_winograd_rejects_unsupported_shapes(dev):
     x = torch.zeros(1, 7, 7, 64, device=dev)
     wp = torch.zeros(16 * 64 * 64, device=dev)
