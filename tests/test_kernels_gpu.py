@@ -215,6 +215,50 @@ def test_conv_winograd_full_size_against_direct_kernel(dev, H, C):
     assert rel_err(pqw.double().sum(0), pqd.double().sum(0)) < 1e-5
 
 
+def test_conv_winograd_random_shape_sweep(dev):
+    """24 seeded random shapes (batch 1-5, even sides 2-22, Cin in multiples of 8, Cout in multiples of
+    64, with / without the prologue, statistics or the folded epilogue): ragged last workgroups, one-
+    tile images, single k-tiles, odd k-tile counts."""
+    import random as _r
+    rng = _r.Random(1234)
+    worst = 0.0
+    for case in range(24):
+        B = rng.randint(1, 5)
+        H, W = 2 * rng.randint(1, 11), 2 * rng.randint(1, 11)
+        Cin = 8 * rng.choice([1, 2, 3, 5, 8, 9])
+        Cout = 64 * rng.choice([1, 2, 3])
+        pre, epi = rng.random() < 0.6, rng.random() < 0.3
+        g = torch.Generator().manual_seed(1000 + case)
+        x = torch.randn(B, Cin, H, W, generator=g)
+        w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.1
+        scale = torch.rand(Cin, generator=g) - 0.3 if pre else None
+        shift = torch.randn(Cin, generator=g) if pre else None
+        ref = _conv_ref(x, w, 1, 1, scale, shift, relu=pre)
+        osc = torch.rand(Cout, generator=g) + 0.5 if epi else None
+        osh = torch.randn(Cout, generator=g) if epi else None
+        if epi:
+            ref = (ref * osc.double().view(1, -1, 1, 1) + osh.double().view(1, -1, 1, 1)).clamp_min(0)
+        M = B * H * W
+        ref = ref.permute(0, 2, 3, 1).reshape(M, Cout)
+        xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+        wp = ops.pack_conv_weight_wino(w.to(dev))
+        y = torch.full((M, Cout), float("nan"), device=dev)
+        tiles = lib().capnet_conv_wino_tiles_m(B, H, W)
+        psum, psq = torch.zeros(tiles, Cout, device=dev), torch.zeros(tiles, Cout, device=dev)
+        dv = lambda t_: t_.to(dev) if t_ is not None else None
+        sd, hd, od, ohd = dv(scale), dv(shift), dv(osc), dv(osh)
+        check(lib().capnet_conv2d_fwd_wino(ptr(xd), H * W * Cin, W * Cin, Cin, ptr(wp), ptr(y), ptr(sd), ptr(hd),
+                                           int(pre), None if epi else ptr(psum), None if epi else ptr(psq),
+                                           B, H, W, Cin, Cout, ptr(od), ptr(ohd), int(epi), current_stream()))
+        e = rel_err(y, ref)
+        worst = max(worst, e)
+        assert e < 3e-6, (case, B, H, W, Cin, Cout, pre, epi, e)
+        if not epi:
+            assert rel_err(psum.sum(0), ref.sum(0)) < 1e-5, (case, B, H, W, Cin, Cout)
+            assert rel_err(psq.sum(0), (ref ** 2).sum(0)) < 1e-5, (case, B, H, W, Cin, Cout)
+    print("winograd sweep: worst relative error %.2e" % worst)
+
+
 def test_conv_winograd_strided_input_view(dev):
     """The ABI takes the input's batch / row / pixel strides: a channel slice of a wider NHWC tensor
     (pixel stride Cin + 16, first channel 16: 64-B offset) must give the same result as its dense copy."""
