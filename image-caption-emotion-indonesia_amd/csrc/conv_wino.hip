@@ -18,15 +18,18 @@
 //     (quad_perm): V[r][j] = R_r[j] + s_r * R_o(r)[j]. Row 3 comes out negated; the packed
 //     weights carry the same sign flip, so the products are unchanged. Patch offsets and masks
 //     are loop invariant: the k-loop's address arithmetic is one scalar add.
-//   * weights (B side): transformed once per weight version into [k-tile][n-tile][freq][64][8]
-//     blocks, streamed by LDS-DMA (32 KB contiguous per k-tile, no VGPRs).
+//   * weights (B side): transformed once per weight version into 32 KB blocks per (k-tile, 64
+//     channels), rows in MFMA lane order, streamed by LDS-DMA (no VGPRs).
 //   * MFMA: v_mfma_f32_16x16x4_f32; wave (mh, nw) owns 32 tiles x output channels 16nw..16nw+15
-//     for all 16 frequencies (128 accumulator registers; 2 waves per SIMD), so the output transform A^T M A runs
-//     in registers with no exchange, and the BatchNorm partial sums need two shuffles.
-//     Both LDS images are stored per frequency and 16-row block in MFMA lane order
+//     for all 16 frequencies (128 accumulator registers; 2 waves per SIMD), so the output
+//     transform A^T M A runs in registers with no exchange, and the BatchNorm partial sums need
+//     two shuffles. Both LDS images are stored per frequency and 16-row block in MFMA lane order
 //     ([k >> 1][row][k & 1]): lane (row i, kq) reads its two k with one ds_read_b64 and a wave
 //     reads 512 contiguous bytes (any k <-> (step, kq) bijection is a valid reduction order as
 //     long as A and B use the same one).
+//   * the k-loop is a software pipeline: one piece of side work (weight DMA of tile k+1, fold and
+//     transform of tile k+1, activation loads of tile k+2) between the MFMA groups of each
+//     frequency; see the comment at the loop.
 // Same contract as conv2d_fwd_v2: raw NHWC output + per-workgroup column sums / sums of squares
 // (train-mode BatchNorm), or the folded-BN (+ReLU) inference epilogue.
 #include <cstdlib>
