@@ -50,20 +50,29 @@ def parse():
                     help="trunk passes in flight ahead of the decoder")
     ap.add_argument("--no-lstm-roofline", action="store_true",
                     help="skip the LSTM-step microbenchmark (PMC passes profile the train step only)")
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=5)
     return ap.parse_args()
 
 
 def pmc_traffic(key="conv_bytes_per_launch"):
-    """HBM bytes per conv launch from the TCC counters (FETCH_SIZE x2 on gfx950 + WRITE_SIZE),
-    measured offline by tools/pmc_traffic.sh on this same command and committed under profiles/
-    (PMC passes cannot run inside the timed bench). None if the file is absent."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1_pmc_traffic.json")
-    try:
-        with open(path) as f:
-            return json.load(f)[key]
-    except Exception:
-        return None
+    """(bytes per launch, provenance) of HBM traffic from the TCC counters (FETCH_SIZE x2 on gfx950
+    + WRITE_SIZE). PMC passes cannot run inside the timed bench (one counter per pass, rocprofv3
+    attached): the value is measured OFFLINE by tools/pmc_traffic.sh on this same command and read
+    from the newest profiles/round*_pmc_traffic.json; (None, None) if there is none."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_pmc_traffic.json")))
+    for path in reversed(files):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+            if key in d:
+                return d[key], ("offline: %s (tools/pmc_traffic.sh -> tools/pmc_summarize.py; rocprofv3 "
+                                "--kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes of `%s`), "
+                                "not measured by this run" % (os.path.relpath(path, ROOT),
+                                                            d.get("command", "bench.py").split("-- ")[-1]))
+        except Exception:
+            continue
+    return None, None
 
 
 def log(msg):
@@ -87,9 +96,12 @@ def host_cores():
     return max(1, min(n, 16))
 
 
-def cpu_baseline(args, steps):
-    """The CPU oracle (oracle/: torch-CPU restatement of the reference step) timed on this
-    host's cores, same workload shape: batch 64, ResNet-152 + FactoredLSTM-512, V=8192."""
+def cpu_baseline(args, steps, warmup=2):
+    """The CPU oracle (oracle/: torch-CPU restatement of the reference step) timed on this host's
+    cores, same workload as the GPU line: batch 64, ResNet-152 train-mode trunk + head +
+    FactoredLSTM-512, V=8192, tf 0.8, dropout as on the GPU (a host-drawn mask). SURVEY 8(d) /
+    BASELINE.md 3 procedure: `warmup` untimed + `steps` (>= 5) timed steps, median; the trunk and
+    the trainable half (head + decoder forward, loss, backward, clamp, Adam) timed separately."""
     from capnet import synthetic
     from oracle import decoders_ref as D
     from oracle import step_ref as S
@@ -107,13 +119,21 @@ def cpu_baseline(args, steps):
     imgs, captions, lengths = synthetic.make_batch(B, V, seed=0)
     opt = S.AdamRef(lr=2e-4)
     random.seed(0)
-    times, losses = [], []
-    for it in range(steps + 1):
+    g = torch.Generator().manual_seed(0)
+    keep = 1.0 - args.dropout
+    t_all, t_trunk, losses = [], [], []
+    for it in range(warmup + steps):
         t0 = time.perf_counter()
         tf = [random.random() < 0.8 for _ in range(max(lengths))]
+        drop = None
+        if args.dropout > 0:      # nn.Dropout on the embedded captions (stylenet/model.py:166-167)
+            drop = (torch.rand(captions.shape + (300,), generator=g) < keep).float() / keep
         leaves = {k: v.detach().clone().requires_grad_(True) for k, v in p.items()}
-        feats = enc(imgs)
-        logits = D.factored_lstm_forward(leaves, captions, lengths, feats, tf, "factual")
+        with torch.no_grad():
+            pooled = enc.resnet(imgs).reshape(B, -1)          # frozen trunk (model.py:23-25)
+        t1 = time.perf_counter()
+        feats = enc.bn(enc.linear(pooled))
+        logits = D.factored_lstm_forward(leaves, captions, lengths, feats, tf, "factual", drop_mask=drop)
         loss = Fn.cross_entropy(logits, D.packed_targets(captions, lengths))
         enc.zero_grad()
         loss.backward()
@@ -123,22 +143,57 @@ def cpu_baseline(args, steps):
             opt.step(p, grads)
             hp = {("enc." + k): v for k, v in enc.named_parameters() if not k.startswith("resnet.")}
             hg = {k: v.grad for k, v in hp.items()}
-            S.clip_gradient_([g for g in hg.values() if g is not None], 0.5)
+            S.clip_gradient_([g_ for g_ in hg.values() if g_ is not None], 0.5)
             opt.step(hp, hg)
-        dt = time.perf_counter() - t0
-        log("cpu step %d: %.2f s, loss %.5f" % (it, dt, float(loss)))
-        if it > 0:
-            times.append(dt)
+        t2 = time.perf_counter()
+        log("cpu step %d: %.2f s (trunk %.2f s), loss %.5f" % (it, t2 - t0, t1 - t0, float(loss)))
+        if it >= warmup:
+            t_all.append(t2 - t0)
+            t_trunk.append(t1 - t0)
         losses.append(float(loss))
-    t = sorted(times)[len(times) // 2]
+    med = lambda v: sorted(v)[len(v) // 2]
+    t, tt = med(t_all), med(t_trunk)
     return {"value": round(B / t, 3), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": "%d full train steps at batch %d after 1 warm-up step (median %.2f s/step), "
-                      "oracle/ torch-CPU fp32, dropout 0" % (steps, B, t),
+            "sample": "%d full train steps at batch %d after %d warm-up steps (median %.2f s/step: trunk "
+                      "%.2f s + head/decoder/loss/backward/clamp/Adam %.2f s), oracle/ torch-CPU fp32, "
+                      "dropout %.2f" % (steps, B, warmup, t, tt, t - tt, args.dropout),
+            "trunk_s": round(tt, 3), "decoder_s": round(t - tt, 3), "step_s": round(t, 3),
             "loss_first": losses[0]}
+
+
+def self_launch(args):
+    """`python3 bench.py --gpus N` without a launcher: start N rank processes of this script (one
+    per GPU, env-style rendezvous on 127.0.0.1) BEFORE anything in this process touches the GPU,
+    relay rank 0's JSON line, fail if any rank fails. The parent never initialises HIP and never
+    exec-replaces itself."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(args.gpus),
+                    "LOCAL_WORLD_SIZE": str(args.gpus), "MASTER_ADDR": "127.0.0.1",
+                    "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+        env.setdefault("OMP_NUM_THREADS", "4")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    lines = [l for l in out.decode(errors="replace").splitlines() if l.startswith("{")]
+    if any(rcs) or not lines:
+        sys.stderr.write("[bench] rank exit codes %s, %d JSON line(s)\n" % (rcs, len(lines)))
+        raise SystemExit(next((rc for rc in rcs if rc), 1))
+    sys.stdout.write(lines[-1] + "\n")
+    sys.stdout.flush()
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args)
     # stdout carries exactly ONE line (the JSON): RCCL prints a version banner to fd 1 when the
     # process group comes up, so everything else this process (and its libraries) writes to stdout
     # goes to stderr, and the JSON line is written to the saved descriptor at the end.
@@ -149,9 +204,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d"
-                             % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no GPU visible); there is no CPU fallback")
     # CAPNET_REHEARSE_ONE_GPU=1: every rank on device 0 with the gloo backend -- a multi-rank
@@ -246,7 +299,10 @@ def main():
     runner = encoder._trunk()
     plan = runner._plan(B, 224, 224, dev)
     lib = capnet.lib()
-    if not args.no_conv_events:
+    # two hipEvents per conv launch: rank 0 only (the roofline is rank 0's; the other ranks share
+    # the host with it and need not pay for 6 200 event calls per 20 steps)
+    conv_events = not args.no_conv_events and rank == 0
+    if conv_events:
         runner.set_timing(plan, True)
     barrier()
     log("warm-up done, timing %d steps" % args.steps)
@@ -268,7 +324,7 @@ def main():
     ops.check_device_errors()
 
     roofline = None
-    if not args.no_conv_events:
+    if conv_events:
         ms, n, fl = C.c_double(), C.c_long(), C.c_double()
         capnet._lib.check(lib.capnet_trunk_collect_timing(plan["handle"], C.byref(ms), C.byref(n), C.byref(fl)))
         if n.value > 0:
@@ -284,7 +340,8 @@ def main():
                                "duration = time with at least one conv launch running (union of the "
                                "intervals: two trunk passes are in flight, their launches overlap)",
                         "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": pmc_traffic(),
+                        "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": pmc_traffic()[0],
+                        "traffic_source": pmc_traffic()[1],
                         "launches": n.value, "avg_launch_us": round(ms.value * 1e3 / n.value, 2),
                         "flops_per_launch": fl.value / n.value}
             # multiplies actually issued: the Winograd launches (weight image kind 2) do 16 per 2x2
@@ -370,7 +427,8 @@ def main():
         lstm = {"bound": "hbm", "kernel": "lstm_step_fused_kernel (b=64, H=512; 24 dependent steps replayed from a hipGraph)",
                 "achieved": round(step_bytes / us / 1e3, 1), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(step_bytes / us / 1e3 / 8000.0, 4),
-                "traffic": pmc_traffic("lstm_step_bytes_per_launch"),
+                "traffic": pmc_traffic("lstm_step_bytes_per_launch")[0],
+                "traffic_source": pmc_traffic("lstm_step_bytes_per_launch")[1],
                 "bytes_per_step": step_bytes, "us_per_step": round(us, 2)}
 
     # the two other rooflines SURVEY.md 8(d) names, timed with events on the launch stream:

@@ -19,8 +19,6 @@
 
 namespace capnet {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
 struct ConvArgs2 {
   const float* x;
   const float* wk;  // [Kw][Cout]
@@ -52,47 +50,6 @@ struct ConvArgs2 {
   unsigned ohw_mul, ohw_sh, ow_mul, ow_sh;
   unsigned tn_mul, tn_sh, cin_mul, cin_sh, kw_mul, kw_sh, split_mul, split_sh;  // tiles_n, Cin, KW, split
 };
-
-// mul = ceil(2^k / d), k = 24 + ceil(log2 d): exact quotient for every n < 2^24
-static void magic_div(unsigned d, unsigned* mul, unsigned* sh) {
-  unsigned l = 0;
-  while ((1u << l) < d) ++l;
-  const unsigned k = 24 + l;
-  const unsigned long long m = ((1ull << k) + d - 1) / d;
-  *mul = (unsigned)m;   // < 2^25
-  *sh = k;
-}
-__device__ __forceinline__ unsigned fast_div(unsigned n, unsigned mul, unsigned sh) {
-  return (unsigned)(((unsigned long long)n * mul) >> sh);
-}
-
-// LDS-DMA of 16 B per lane: LDS[m0_base + 16*lane] = *(sbase + voff). Inline asm on purpose:
-// with the builtin, hipcc cannot tell the DMA's LDS destination from the stage being read and
-// puts s_waitcnt vmcnt(0) in front of every ds_read of the k-loop (measured: the wait sat
-// right before the MFMAs). An asm DMA is invisible to its bookkeeping; it is ordered by hand:
-// it is issued BEFORE the tile's buffer loads, vmcnt retires in issue order, so once store()
-// has consumed those loads the DMA has landed, and the __syncthreads() that follows publishes
-// it to the other waves.
-__device__ __forceinline__ void glds16(const float* sbase, int voff_bytes, unsigned lds_byte_addr) {
-  unsigned keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\t"
-      "s_mov_b32 m0, %2\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %1, %3\n\t"
-      "s_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(voff_bytes), "s"(lds_byte_addr), "s"(sbase)
-      : "memory");
-}
-
-// 16-B global load, address = uniform 64-bit base (SGPR pair) + per-lane 32-bit byte offset.
-// Inline asm for the same reason as glds16: hipcc's own loads in this loop got 64-bit VALU
-// address arithmetic and an s_waitcnt vmcnt(0) that drained the LDS-DMA before they issued.
-// The result is NOT valid until wait_loads() (vmcnt is counted by hand).
-__device__ __forceinline__ void gload16(f32x4& dst, const float* sbase, unsigned voff_bytes) {
-  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff_bytes), "s"(sbase) : "memory");
-}
 
 // MODE (compile time, chosen by the launcher): bit 0 PRE = the previous BatchNorm (+ReLU) is
 // applied while the A tile is staged; bit 1 MASK = some staged element must be forced to 0

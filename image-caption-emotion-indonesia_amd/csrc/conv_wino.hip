@@ -40,7 +40,6 @@
 
 namespace capnet {
 
-typedef float w_f32x4 __attribute__((ext_vector_type(4)));
 typedef float w_f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int WBT = 64;              // output tiles (2x2 pixels each) per workgroup
@@ -73,35 +72,6 @@ struct WinoArgs {
   unsigned thw_mul, thw_sh, tw_mul, tw_sh, tn_mul, tn_sh;
 };
 
-static void w_magic_div(unsigned d, unsigned* mul, unsigned* sh) {
-  unsigned l = 0;
-  while ((1u << l) < d) ++l;
-  const unsigned k = 24 + l;
-  *mul = (unsigned)(((1ull << k) + d - 1) / d);
-  *sh = k;
-}
-__device__ __forceinline__ unsigned w_fast_div(unsigned n, unsigned mul, unsigned sh) {
-  return (unsigned)(((unsigned long long)n * mul) >> sh);
-}
-
-// see conv_f32_v2.hip: inline asm so that hipcc neither drains vmcnt in front of LDS reads nor
-// builds 64-bit VALU addresses; ordered by hand (vmcnt retires in issue order)
-__device__ __forceinline__ void w_glds16(const float* sbase, int voff_bytes, unsigned lds_byte_addr) {
-  unsigned keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\t"
-      "s_mov_b32 m0, %2\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %1, %3\n\t"
-      "s_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(voff_bytes), "s"(lds_byte_addr), "s"(sbase)
-      : "memory");
-}
-__device__ __forceinline__ void w_gload16(w_f32x4& dst, const float* sbase, unsigned voff_bytes) {
-  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff_bytes), "s"(sbase) : "memory");
-}
-
 // ABL: compile-time ablation mask for tools/conv_bench.py (CAPNET_WINO_ABLATE), 0 in the product:
 // 1 no ds_read + MFMA, 2 no transform / LDS store, 4 no weight DMA, 8 no activation loads,
 // 16 MFMAs without their LDS reads, 32 no barrier in the k-loop, 128 no wait for the weight DMA,
@@ -113,7 +83,7 @@ __global__ __launch_bounds__(W_THREADS) void conv_wino_kernel(WinoArgs g) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // consecutive ids share an A panel (same tm): keep them on one XCD's L2
   const int id = xcd_remap(blockIdx.x, gridDim.x);
-  const int tm = (int)w_fast_div((unsigned)id, g.tn_mul, g.tn_sh), tn = id - tm * g.tiles_n;
+  const int tm = (int)fast_div((unsigned)id, g.tn_mul, g.tn_sh), tn = id - tm * g.tiles_n;
   const int m0 = tm * WBT, n0 = tn * WBN;
   const int nk = g.C / WBK;
   const float inf = __builtin_inff();
@@ -127,9 +97,9 @@ __global__ __launch_bounds__(W_THREADS) void conv_wino_kernel(WinoArgs g) {
     const int t = m0 + tl;
     const bool valid = t < g.T;
     const int tc = valid ? t : g.T - 1;
-    const int b = (int)w_fast_div((unsigned)tc, g.thw_mul, g.thw_sh);
+    const int b = (int)fast_div((unsigned)tc, g.thw_mul, g.thw_sh);
     const int rem = tc - b * (g.TH * g.TW);
-    const int th = (int)w_fast_div((unsigned)rem, g.tw_mul, g.tw_sh);
+    const int th = (int)fast_div((unsigned)rem, g.tw_mul, g.tw_sh);
     const int tw = rem - th * g.TW;
     const int ih = 2 * th - 1 + r;
     const bool row_in = valid && (unsigned)ih < (unsigned)g.H;
@@ -167,21 +137,21 @@ __global__ __launch_bounds__(W_THREADS) void conv_wino_kernel(WinoArgs g) {
   // wave sat in the same VMEM / VALU / LDS-write phase (measured: 79 us of MFMA + LDS reads grew
   // to 104 us, and removing the *waits* changed nothing -- it is the issue phases themselves).
   constexpr int DPW = 32 / W_WAVES;  // weight DMA instructions (1 KB each) per wave and k-tile
-  w_f32x4 av[4], scv, shv;
+  f32x4 av[4], scv, shv;
   float d[4][4];  // [pixel s][channel] of the tile being transformed
   auto clampk = [&](int kt) { return kt < nk ? kt : nk - 1; };  // past the end: reload the last tile
   auto dma_b = [&](int stage, int kt, int j) {
     if (ABL & 4) return;
     const float* bs = wblk + (size_t)clampk(kt) * wstep + wave * (DPW * 256);
     const unsigned bdst = lds_b0 + (unsigned)(stage * W_B_ST + wave * (DPW * 256)) * 4u;
-    w_glds16(bs + j * 256, lane * 16, bdst + (unsigned)(j * 256) * 4u);
+    glds16(bs + j * 256, lane * 16, bdst + (unsigned)(j * 256) * 4u);
   };
   auto load_a = [&](int kt, int i) {   // piece i of 0..5
     if (ABL & 8) return;
     const int kc = clampk(kt) * WBK;
-    if (i < 4) w_gload16(av[i], g.x + kc, voff[i]);
-    else if (PRE && i == 4) w_gload16(scv, g.in_scale + kc, (unsigned)(16 * q));
-    else if (PRE && i == 5) w_gload16(shv, g.in_shift + kc, (unsigned)(16 * q));
+    if (i < 4) gload16(av[i], g.x + kc, voff[i]);
+    else if (PRE && i == 4) gload16(scv, g.in_scale + kc, (unsigned)(16 * q));
+    else if (PRE && i == 5) gload16(shv, g.in_shift + kc, (unsigned)(16 * q));
   };
   constexpr int NLA = PRE ? 6 : 4;     // VMEM loads of one tile's activations per thread
   // the activations of the next tile have landed once at most `keep` younger VMEM ops are in flight
@@ -206,7 +176,7 @@ __global__ __launch_bounds__(W_THREADS) void conv_wino_kernel(WinoArgs g) {
   auto transform = [&](int stage, int j) {   // frequency column j of this thread's patch row
     if (ABL & 2) return;
     float* dst = lds + 2 * W_B_ST + stage * W_A_ST + awr + j * W_FS_A;
-    w_f32x4 o;
+    f32x4 o;
 #pragma unroll
     for (int c = 0; c < 4; ++c)   // row transform B^T along the patch row
       o[c] = j == 0 ? d[0][c] - d[2][c]
@@ -229,11 +199,11 @@ __global__ __launch_bounds__(W_THREADS) void conv_wino_kernel(WinoArgs g) {
     *reinterpret_cast<w_f32x2*>(dst + 32) = w_f32x2{o[2], o[3]};
   };
 
-  w_f32x4 acc[16][2];
+  f32x4 acc[16][2];
 #pragma unroll
   for (int f = 0; f < 16; ++f)
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb) acc[f][mb] = w_f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int mb = 0; mb < 2; ++mb) acc[f][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // wave -> (tile half mh: tiles 32 mh .. 32 mh + 31, channel group nw: channels 16 nw .. + 15)
   const int li = lane & 15, kq = lane >> 4;
@@ -333,9 +303,9 @@ __global__ __launch_bounds__(W_THREADS) void conv_wino_kernel(WinoArgs g) {
         ta[1][j] = m1j - m2j - m3j;
       }
       if (t < g.T) {
-        const int b = (int)w_fast_div((unsigned)t, g.thw_mul, g.thw_sh);
+        const int b = (int)fast_div((unsigned)t, g.thw_mul, g.thw_sh);
         const int rem = t - b * (g.TH * g.TW);
-        const int th = (int)w_fast_div((unsigned)rem, g.tw_mul, g.tw_sh);
+        const int th = (int)fast_div((unsigned)rem, g.tw_mul, g.tw_sh);
         const int tw = rem - th * g.TW;
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
@@ -463,9 +433,9 @@ int conv2d_fwd_wino(const float* x, long sxb, long sxh, long sxw, const float* w
   g.tiles_m = cdiv(T, WBT);
   g.tiles_n = Cout / WBN;
   g.relu_in = relu_in; g.relu_out = relu_out;
-  w_magic_div((unsigned)(g.TH * g.TW), &g.thw_mul, &g.thw_sh);
-  w_magic_div((unsigned)g.TW, &g.tw_mul, &g.tw_sh);
-  w_magic_div((unsigned)g.tiles_n, &g.tn_mul, &g.tn_sh);
+  magic_div((unsigned)(g.TH * g.TW), &g.thw_mul, &g.thw_sh);
+  magic_div((unsigned)g.TW, &g.tw_mul, &g.tw_sh);
+  magic_div((unsigned)g.tiles_n, &g.tn_mul, &g.tn_sh);
   const long wgs = (long)g.tiles_m * g.tiles_n;
   CAPNET_REQUIRE(wgs < (1L << 24), "conv2d_fwd_wino: grid too large");
   const size_t lds_bytes = (size_t)W_LDS_FLOATS * sizeof(float);

@@ -48,6 +48,49 @@ class Adam:
                         p.grad.detach_()
                         p.grad.zero_()
 
+    def state_dict(self):
+        """torch.optim.Adam's layout: `state` {index: {step, exp_avg, exp_avg_sq}} and
+        `param_groups` with the parameters replaced by their indices in registration order, so the
+        reference's checkpoint/resume (stylenet/utils.py:76-90, train_multitask.py:168-177) works
+        with this class and the file loads under torch.load(weights_only=True)."""
+        index, groups = {}, []
+        for g in self.param_groups:
+            ids = []
+            for p in g["params"]:
+                index.setdefault(id(p), len(index))
+                ids.append(index[id(p)])
+            packed = {k: v for k, v in g.items() if k != "params"}
+            packed["betas"] = tuple(packed["betas"])
+            packed["params"] = ids
+            groups.append(packed)
+        state = {}
+        for p, st in self.state.items():
+            state[index[id(p)]] = {"step": torch.tensor(float(st["step"])),
+                                   "exp_avg": st["exp_avg"], "exp_avg_sq": st["exp_avg_sq"]}
+        return {"state": state, "param_groups": groups}
+
+    def load_state_dict(self, state_dict):
+        groups = state_dict["param_groups"]
+        if len(groups) != len(self.param_groups):
+            raise ValueError("loaded state dict has a different number of parameter groups")
+        by_index = {}
+        for g, saved in zip(self.param_groups, groups):
+            if len(saved["params"]) != len(g["params"]):
+                raise ValueError("loaded state dict contains a parameter group that doesn't match "
+                                 "the size of optimizer's group")
+            for k, v in saved.items():
+                if k != "params":
+                    g[k] = tuple(v) if k == "betas" else v
+            for i, p in zip(saved["params"], g["params"]):
+                by_index[i] = p
+        self.state = {}
+        for i, st in state_dict["state"].items():
+            p = by_index[int(i)]
+            self.state[p] = {
+                "step": int(float(st["step"])),
+                "exp_avg": st["exp_avg"].to(device=p.device, dtype=p.dtype).clone(),
+                "exp_avg_sq": st["exp_avg_sq"].to(device=p.device, dtype=p.dtype).clone()}
+
     def set_pending_clip(self, grad_clip):
         """Called by utils.clip_gradient: the clamp is applied inside the next step()'s kernel
         (and written back to .grad, so the visible effect equals clamp_ followed by step)."""

@@ -64,6 +64,11 @@ def train_step_att(encoder, decoder, optimizer, criterion, images, captions, len
     lengths = [l - 1 for l in lengths]
     targets = ops.packed_targets(captions[:, 1:].contiguous(), lengths)
     features = encoder(images)
+    # the attention encoder has no trainable head to hang pre_head_hook on: a data-parallel
+    # optimiser's overlapped update (capnet.parallel) must have landed before the decoder reads
+    # the parameters
+    if hasattr(optimizer, "wait_for_update"):
+        optimizer.wait_for_update()
     kw = {}
     if mode is not None:
         kw["mode"] = mode
@@ -175,9 +180,16 @@ class TrunkPipeline(object):
             kw["mode"] = mode
         if tf_mask is not None:
             kw["tf_mask"] = tf_mask
+        # `captions` was produced on the caller's stream (an H2D copy in the loops): order the side
+        # stream after it, and keep its memory from being handed out again while the side stream
+        # (up to `depth` steps behind the host) still reads it
+        self.side.wait_stream(torch.cuda.current_stream())
+        captions.record_stream(self.side)
         with torch.cuda.stream(self.side):
             self.side.wait_event(ready)
             if self.attention:
+                if hasattr(self.optimizer, "wait_for_update"):
+                    self.optimizer.wait_for_update()
                 lens = [l - 1 for l in lengths]
                 targets = ops.packed_targets(captions[:, 1:].contiguous(), lens)
                 outputs, alphas = dec(captions[:, :-1].contiguous(), lens, feats,
@@ -219,7 +231,8 @@ def _drain(pending, meter):
 
 
 def _pipelined_loop(pipe, loader, device, step_kwargs):
-    """Yields (i, loss, lengths): keeps `pipe.depth` batches prefetched ahead of the step."""
+    """Yields (i, loss, lengths): keeps `pipe.depth` batches prefetched ahead of the step.
+    step_kwargs: dict, or callable(step index) -> dict (e.g. an explicit tf_mask per step)."""
     it = iter(loader)
     meta = []
 
@@ -228,8 +241,9 @@ def _pipelined_loop(pipe, loader, device, step_kwargs):
             images, captions, lengths, _ = next(it)
         except StopIteration:
             return False
+        captions = captions.to(device, non_blocking=True)      # before prefetch's wait_stream
         pipe.prefetch(images.to(device, non_blocking=True))
-        meta.append((captions.to(device, non_blocking=True), lengths))
+        meta.append((captions, lengths))
         return True
 
     for _ in range(pipe.depth):
@@ -238,7 +252,7 @@ def _pipelined_loop(pipe, loader, device, step_kwargs):
     i = 0
     while meta:
         captions, lengths = meta.pop(0)
-        loss = pipe.step(captions, lengths, **step_kwargs)
+        loss = pipe.step(captions, lengths, **(step_kwargs(i) if callable(step_kwargs) else step_kwargs))
         feed()
         yield i, loss, lengths
         i += 1

@@ -30,7 +30,10 @@ def test_bench_prints_one_json_line():
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["unit"] == "images/sec" and d["scaling"] == "weak"
     assert d["value"] > 0 and math.isfinite(d["loss_last"]) and d["dtype"] == "f32"
     r = d["roofline"]
-    assert r["bound"] == "mfma" and 0 < r["frac"] < 1.5 and 0 < r["executed"]["frac"] < 1
+    # `frac` credits the Winograd launches with the direct sum's flops; `executed` is what the
+    # matrix pipe issued: neither may reach the peak
+    assert r["bound"] == "mfma" and 0 < r["executed"]["frac"] < r["frac"] < 1
+    assert r["traffic"] is None or "offline" in r["traffic_source"]
     assert d["roofline_lstm_step"]["bound"] == "hbm"
 
 
@@ -42,3 +45,21 @@ def test_two_rank_rehearsal_on_one_gpu():
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 128 and d["config"]["parallelism"] == "dp2"
     assert d["value"] > 0 and math.isfinite(d["loss_first"]) and math.isfinite(d["loss_last"])
     assert d["cpu_baseline"] is None
+
+
+def test_self_launched_two_rank_rehearsal():
+    """The driver's command shape without a launcher: `python3 bench.py --gpus 2` starts its own two
+    rank processes before touching the GPU and relays rank 0's line (rehearsed on device 0 / gloo)."""
+    d = _run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+              "--no-lstm-roofline"], {"CAPNET_REHEARSE_ONE_GPU": "1"})
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 128 and d["config"]["parallelism"] == "dp2"
+    assert d["value"] > 0 and math.isfinite(d["loss_last"]) and d["roofline"]["frac"] > 0
+
+
+def test_self_launch_propagates_a_rank_failure():
+    env = dict(os.environ)
+    env["CAPNET_REHEARSE_ONE_GPU"] = "1"
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--decoder", "factored", "--batch", "0"], cwd=ROOT, env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert p.returncode != 0 and not [l for l in p.stdout.splitlines() if l.startswith("{")]

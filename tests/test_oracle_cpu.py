@@ -214,3 +214,53 @@ def test_corpus_bleu_known_values():
     refs = [[1, 5, 6, 7, 1, 8, 9], [10, 6, 11, 5, 7, 1, 8]]
     hyp = [1, 1, 1, 1, 1, 1, 1]
     assert corpus_bleu([refs], [hyp], weights=(1.0,)) == pytest.approx(2 / 7)
+
+
+def test_corpus_bleu_matches_nltk_doctest_values():
+    """The worked example in the docstring of nltk.translate.bleu_score.corpus_bleu (nltk 3.4.1, the
+    version stylenet/requirements.txt pins; nltk itself is not installable here): two hypotheses,
+    three + one references. Published values: corpus 0.5920..., sentence scores 0.5045... and
+    0.7400... (their mean, 0.6223..., is the docstring's second number). This pins the restatement
+    to nltk's own output on a multi-reference corpus with clipping and closest-length selection."""
+    from capnet.metrics import corpus_bleu
+    words = {}
+
+    def ids(s):
+        return [words.setdefault(w, len(words)) for w in s.split()]
+    hyp1 = ids("It is a guide to action which ensures that the military always obeys the commands of the party")
+    ref1a = ids("It is a guide to action that ensures that the military will forever heed Party commands")
+    ref1b = ids("It is the guiding principle which guarantees the military forces always being under the "
+                "command of the Party")
+    ref1c = ids("It is the practical guide for the army always to heed the directions of the party")
+    hyp2 = ids("he read the book because he was interested in world history")
+    ref2a = ids("he was interested in world history because he read the book")
+    corpus = corpus_bleu([[ref1a, ref1b, ref1c], [ref2a]], [hyp1, hyp2])
+    s1 = corpus_bleu([[ref1a, ref1b, ref1c]], [hyp1])
+    s2 = corpus_bleu([[ref2a]], [hyp2])
+    assert abs(corpus - 0.5920) < 1e-4 and int(corpus * 1e4) == 5920
+    assert int(s1 * 1e4) == 5045 and int((s1 + s2) / 2 * 1e4) == 6223
+
+
+def test_corpus_bleu_hand_computed_corpus_cases():
+    """Counts pooled over the corpus BEFORE the ratio (micro-average), brevity penalty from the summed
+    closest reference lengths, zero higher-order matches."""
+    import math
+    from capnet.metrics import corpus_bleu
+    # two segments. A: hyp 1 2 3 4 5 (5 tok) vs refs [1 2 3 4 5 6] and [1 2 3 9]: closest length 6 (|6-5| = |4-5|
+    # -> the shorter one, 4, by nltk's (abs diff, length) tie-break). B: hyp 7 8 9 10 vs ref 7 8 9 11 12 13.
+    refs_a = [[1, 2, 3, 4, 5, 6], [1, 2, 3, 9]]
+    hyp_a = [1, 2, 3, 4, 5]
+    refs_b = [[7, 8, 9, 11, 12, 13]]
+    hyp_b = [7, 8, 9, 10]
+    # n-gram matches A: 5/5, 4/4, 3/3, 2/2 ; B: 3/4, 2/3, 1/2, 0/1
+    p = [(5 + 3) / 9, (4 + 2) / 7, (3 + 1) / 5, (2 + 0) / 3]
+    hyp_len, ref_len = 5 + 4, 4 + 6
+    bp = math.exp(1 - ref_len / hyp_len)
+    want = bp * math.exp(sum(0.25 * math.log(x) for x in p))
+    assert corpus_bleu([refs_a, refs_b], [hyp_a, hyp_b]) == pytest.approx(want, rel=1e-12)
+    # a corpus without any 4-gram match scores 0 (nltk: ~1e-77 through its float_info.min guard)
+    assert corpus_bleu([refs_b], [hyp_b]) == 0.0
+    # an empty hypothesis adds its reference length and, as in nltk's modified_precision
+    # (denominator max(1, count)), ONE to every n-gram denominator
+    want = math.exp(1 - (4 + 6) / 5) * (5 / 6 * 4 / 5 * 3 / 4 * 2 / 3) ** 0.25
+    assert corpus_bleu([refs_a, refs_b], [hyp_a, []]) == pytest.approx(want, rel=1e-12)

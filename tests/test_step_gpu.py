@@ -223,3 +223,223 @@ def test_training_loops_run_pipelined_and_sequential(dev, capsys):
     assert abs(fac_p - fac_s) / fac_s < 2e-3
     for a, b in zip(emo_p, emo_s):
         assert abs(a - b) / b < 2e-3
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE configs[3]: attention whole step (stylenet/train_multitask_att.py:398-417)
+# ---------------------------------------------------------------------------------------------
+def _att_modules(V, dev):
+    from capnet import model_att
+    enc = model_att.EncoderCNN(14)
+    est = synthetic.trunk_state(enc.state_dict(), seed=1234)
+    enc.load_state_dict(est)
+    dec = model_att.DecoderFactoredLSTMAtt(512, 300, 512, 512, V, 1, dropout=0.0)
+    p = synthetic.decoder_state(dec.state_dict(), seed=1234)
+    dec.load_state_dict(p)
+    return enc, est, dec, p
+
+
+def test_attention_train_steps_match_the_cpu_oracle(dev):
+    """configs[3] per GPU: 12 images, spatial ResNet-152 features [12, 14, 14, 2048], additive
+    attention decoder, V = 8192; inputs captions[:, :-1], targets captions[:, 1:], lengths - 1, loss
+    = NLL + ((1 - sum_t alpha)^2).mean() (train_multitask_att.py:402-411); two steps, so the second
+    loss checks backward + clamp + Adam of every attention / init / f_beta / factored parameter."""
+    from oracle.resnet152_ref import EncoderCNNAttRef
+    from capnet.train import train_step_att
+    V, B, steps, lr, clip = 8192, 12, 2, 2e-3, 0.5
+    torch.set_num_threads(16)
+    enc, est, dec, p = _att_modules(V, dev)
+    imgs, captions, lengths = synthetic.make_batch(B, V, seed=0)
+    random.seed(11)
+    tfs = [[random.random() < 0.8 for _ in range(max(lengths))] for _ in range(steps)]
+
+    ref_enc = EncoderCNNAttRef(14)
+    ref_enc.load_state_dict({k: v.clone() for k, v in est.items()})
+    ref_enc.train()
+    p_ref = {k: v.clone() for k, v in p.items()}
+    opt_ref = S.AdamRef(lr=lr)
+    lens1 = [l - 1 for l in lengths]
+    targets = D.packed_targets(captions[:, 1:], lens1)
+    ref_losses = []
+    for it in range(steps):
+        leaves = {k: v.detach().clone().requires_grad_(True) for k, v in p_ref.items()}
+        feats = ref_enc(imgs)
+        logits, alphas = D.factored_att_forward(leaves, captions[:, :-1], lens1, feats, tfs[it], "factual")
+        loss = D.att_loss(logits, alphas, targets, 1.0)
+        loss.backward()
+        grads = {k: v.grad for k, v in leaves.items()}
+        S.clip_gradient_(grads.values(), clip)
+        with torch.no_grad():
+            opt_ref.step(p_ref, grads)
+        ref_losses.append(float(loss.detach()))
+
+    enc.to(dev).train()
+    dec.to(dev).train()
+    opt = Adam(list(dec.parameters()), lr=lr)
+    imgs_d, caps_d = imgs.to(dev), captions.to(dev)
+    got = [float(train_step_att(enc, dec, opt, CrossEntropyLoss(), imgs_d, caps_d, lengths, clip,
+                                tf_mask=tfs[it]).item()) for it in range(steps)]
+    capnet.ops.check_device_errors()
+    print("att oracle", ref_losses, "gpu", got)
+    for a, b in zip(got, ref_losses):
+        assert abs(a - b) / abs(b) < 1e-4, (got, ref_losses)
+    assert ref_losses[-1] != ref_losses[0]
+    # one updated parameter of each family, after two steps
+    sd = dec.state_dict()
+    for k in ("attention.encoder_att.weight", "f_beta.weight", "init_h.weight", "V_i.weight", "C.bias"):
+        d = (sd[k].cpu() - p_ref[k]).abs().max().item()
+        assert d <= 0.05 * lr * steps + 1e-6 * p_ref[k].abs().max().item(), (k, d)
+
+
+def test_pipelined_attention_steps_equal_sequential_steps(dev):
+    """TrunkPipeline(attention=True) with the sequential schedule's kernels reproduces
+    train_step_att step by step (same losses, same running statistics of the trunk)."""
+    from capnet.train import TrunkPipeline, train_step_att
+    V, B, steps = 1000, 4, 5
+    batches = [synthetic.make_batch(B, V, seed=40 + s) for s in range(steps)]
+    random.seed(6)
+    tfs = [[random.random() < 0.8 for _ in range(24)] for _ in range(steps)]
+
+    def build():
+        enc, _, dec, _ = _att_modules(V, dev)
+        enc.to(dev).train()
+        dec.to(dev).train()
+        return enc, dec, Adam(list(dec.parameters()), lr=2e-3)
+
+    enc, dec, opt = build()
+    seq = [float(train_step_att(enc, dec, opt, CrossEntropyLoss(), i.to(dev), c.to(dev), l, 0.5,
+                                tf_mask=tf).item()) for (i, c, l), tf in zip(batches, tfs)]
+    ref_rm = enc.resnet[7][2].bn3.running_mean.clone()
+    ref_w = dec.attention.decoder_att.weight.detach().clone()
+
+    enc, dec, opt = build()
+    pipe = TrunkPipeline(enc, dec, opt, CrossEntropyLoss(), 0.5, attention=True, shared_chip_tuning=False)
+    dev_batches = [(i.to(dev), c.to(dev), l) for i, c, l in batches]
+    for k in range(pipe.depth):
+        pipe.prefetch(dev_batches[k][0])
+    got = []
+    for k, ((imgs, caps, lens), tf) in enumerate(zip(dev_batches, tfs)):
+        nxt = dev_batches[k + pipe.depth][0] if k + pipe.depth < steps else None
+        got.append(pipe.step(caps, lens, next_images=nxt, tf_mask=tf))
+    pipe.finish()
+    torch.cuda.synchronize()
+    got = [float(l.item()) for l in got]
+    print("att sequential", seq, "pipelined", got)
+    for a, b in zip(got, seq):
+        assert abs(a - b) / abs(b) < 2e-6
+    assert torch.equal(enc.resnet[7][2].bn3.running_mean, ref_rm)
+    assert (dec.attention.decoder_att.weight - ref_w).abs().max().item() <= 2e-3 * ref_w.abs().max().item()
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE configs[4] (1-layer cell, the only one with reference semantics): F = 1024, batch 96,
+# alternating factual / emotion steps (stylenet/train_multitask.py:163-167, 373-389, 527-537)
+# ---------------------------------------------------------------------------------------------
+def test_multitask_alternating_steps_match_the_cpu_oracle(dev):
+    """factual step: Adam(lr 2e-4) over decoder + encoder head, both modules zero_grad'ed;
+    emotion step: mode='happy', lang Adam(lr 5e-4) over the decoder only, encoder.zero_grad() NOT
+    called (train_multitask.py:534 is commented out) so the head's gradients pile up unused; then a
+    factual step again, which sees both updates, the two optimisers' separate moments, and S_happy
+    skipped for lack of a gradient. Losses of all three steps within 1e-4."""
+    V, B, F, clip = 8192, 96, 1024, 0.5
+    torch.set_num_threads(16)
+    enc = EncoderCNN(300)
+    est = _encoder_state(enc)
+    enc.load_state_dict(est)
+    dec = DecoderFactoredLSTM(300, 512, F, V, 1, dropout=0.0)
+    p = synthetic.decoder_state(dec.state_dict(), seed=1234)
+    dec.load_state_dict(p)
+    schedule = [(None, 0), ("happy", 1), (None, 2)]          # (mode, batch seed)
+    batches = [synthetic.make_batch(B, V, seed=s) for _, s in schedule]
+    random.seed(13)
+    tfs = [[random.random() < 0.8 for _ in range(max(b[2]))] for b in batches]
+
+    ref_enc = EncoderCNNRef(300)
+    ref_enc.load_state_dict({k: v.clone() for k, v in est.items()})
+    ref_enc.train()
+    p_ref = {k: v.clone() for k, v in p.items()}
+    opt_ref, lang_ref = S.AdamRef(lr=2e-4), S.AdamRef(lr=5e-4)
+    ref_losses = []
+    for (mode, _), (imgs, captions, lengths), tf in zip(schedule, batches, tfs):
+        leaves = {k: v.detach().clone().requires_grad_(True) for k, v in p_ref.items()}
+        feats = ref_enc(imgs)
+        logits = D.factored_lstm_forward(leaves, captions, lengths, feats, tf, mode or "factual")
+        loss = Fn.cross_entropy(logits, D.packed_targets(captions, lengths))
+        if mode is None:
+            ref_enc.zero_grad()
+        loss.backward()
+        grads = {k: v.grad for k, v in leaves.items()}
+        S.clip_gradient_(grads.values(), clip)
+        with torch.no_grad():
+            if mode is None:
+                hp = {("enc." + k): v for k, v in ref_enc.named_parameters() if not k.startswith("resnet.")}
+                hg = {k: v.grad for k, v in hp.items()}
+                S.clip_gradient_([g for g in hg.values() if g is not None], clip)
+                both, both_g = dict(p_ref), dict(grads)
+                both.update(hp)
+                both_g.update(hg)
+                opt_ref.step(both, both_g)
+            else:
+                lang_ref.step(p_ref, grads)
+        ref_losses.append(float(loss.detach()))
+
+    enc.to(dev).train()
+    dec.to(dev).train()
+    opt = Adam(list(dec.parameters()) + list(enc.linear.parameters()) + list(enc.bn.parameters()), lr=2e-4)
+    lang = Adam(list(dec.parameters()), lr=5e-4)
+    got = []
+    for (mode, _), (imgs, captions, lengths), tf in zip(schedule, batches, tfs):
+        l = train_step(enc, dec, opt if mode is None else lang, CrossEntropyLoss(), imgs.to(dev),
+                       captions.to(dev), lengths, clip, mode=mode, zero_encoder_grad=mode is None, tf_mask=tf)
+        got.append(float(l.item()))
+        if mode is not None:
+            assert enc.linear.weight.grad is not None      # left in place, as in the reference
+    capnet.ops.check_device_errors()
+    print("multitask oracle", ref_losses, "gpu", got)
+    for a, b in zip(got, ref_losses):
+        assert abs(a - b) / abs(b) < 1e-4, (got, ref_losses)
+    sd = dec.state_dict()
+    for k in ("S_happy_i.weight", "S_fi.weight", "W_c.weight", "C.weight"):
+        d = (sd[k].cpu() - p_ref[k]).abs().max().item()
+        assert d <= 1e-4, (k, d)
+    assert (sd["S_happy_i.weight"].cpu() - p["S_happy_i.weight"]).abs().max().item() > 1e-4   # it moved
+    assert torch.equal(sd["S_sad_i.weight"].cpu(), p["S_sad_i.weight"])                        # it did not
+
+
+def test_pipelined_loop_keeps_each_batch_with_its_captions(dev):
+    """in the loops the captions are copied to the device on the caller's stream
+    and freed on the host side while the pipeline's side stream is still `depth` steps behind. Ten
+    distinct batches through _pipelined_loop without an intermediate finish(): every step's loss
+    equals the sequential loop's (a step that read another batch's tokens would be off by ~1e-2)."""
+    from capnet.train import TrunkPipeline, _pipelined_loop
+    B, V, n = 2, 300, 10
+    loader = []
+    for s in range(n):
+        imgs, caps, lens = synthetic.make_batch(B, V, seed=100 + s, min_len=5, max_len=9)
+        loader.append((imgs, caps, lens, None))
+    random.seed(21)
+    tfs = [[random.random() < 0.8 for _ in range(9)] for _ in range(n)]
+
+    def build():
+        enc = EncoderCNN(300)
+        enc.load_state_dict(_encoder_state(enc))
+        dec = DecoderFactoredLSTM(300, 64, 64, V, 1, dropout=0.0)
+        dec.load_state_dict(synthetic.decoder_state(dec.state_dict(), seed=4))
+        enc.to(dev).train()
+        dec.to(dev).train()
+        return enc, dec, Adam(list(dec.parameters()) + list(enc.linear.parameters()) + list(enc.bn.parameters()), lr=1e-3)
+
+    enc, dec, opt = build()
+    seq = [float(train_step(enc, dec, opt, CrossEntropyLoss(), i.to(dev), c.to(dev), l, 0.5,
+                            tf_mask=tf[:max(l)]).item()) for (i, c, l, _), tf in zip(loader, tfs)]
+    enc, dec, opt = build()
+    pipe = TrunkPipeline(enc, dec, opt, CrossEntropyLoss(), 0.5, shared_chip_tuning=False)
+    losses = [loss for _, loss, _ in _pipelined_loop(
+        pipe, loader, dev, lambda i: {"tf_mask": tfs[i][:max(loader[i][2])]})]
+    pipe.finish()
+    torch.cuda.synchronize()
+    got = [float(l.item()) for l in losses]
+    print("loop sequential", seq, "pipelined", got)
+    assert len(set(round(x, 4) for x in seq)) == n        # the batches are distinguishable
+    for a, b in zip(got, seq):
+        assert abs(a - b) / abs(b) < 2e-6

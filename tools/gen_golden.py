@@ -529,8 +529,41 @@ def gen_sample_tiny():
     save("sample_tiny.npz", arrays)
 
 
+def gen_init():
+    """G5: what the reference's constructors draw. torch.manual_seed(s), construct each
+    reference decoder (its nn.Linear / nn.Embedding / nn.LSTMCell constructors consume the stream
+    first, then reset_parameters / init_weights, stylenet/model.py:99-113, nic/model.py:58-72,
+    stylenet/model_att.py:169-183), and store per parameter: shape, min, max, mean, std and the
+    first 8 values. Small dims keep the fixture small; the bounds depend on the shapes only."""
+    import json
+    out = {}
+    cases = [("stylenet.DecoderFactoredLSTM", "stylenet", "model", "DecoderFactoredLSTM", (30, 48, 40, 101, 1)),
+             ("stylenet.DecoderFactoredLSTMAtt", "stylenet", "model_att", "DecoderFactoredLSTMAtt",
+              (24, 30, 48, 40, 101, 1, 64)),
+             ("nic.DecoderRNN", "nic", "model", "DecoderRNN", (30, 48, 101, 1)),
+             ("nic.DecoderRNNAtt", "nic", "model_att", "DecoderRNNAtt", (24, 30, 48, 101, 1, 64))]
+    for name, pkg, mod, cls, args in cases:
+        ref = load_ref(pkg, mod)
+        for seed in (0, 1234):
+            torch.manual_seed(seed)
+            m = getattr(ref, cls)(*args)
+            rec = {}
+            for k, v in m.state_dict().items():
+                v = v.double()
+                rec[k] = {"shape": list(v.shape), "min": float(v.min()), "max": float(v.max()),
+                          "mean": float(v.mean()), "std": float(v.std()) if v.numel() > 1 else 0.0,
+                          "head": [float(x) for x in v.reshape(-1)[:8].float()]}
+            out["%s%s seed=%d" % (name, list(args), seed)] = rec
+    path = os.path.join(OUT, "init_stats.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=0)
+    print("wrote", path, {k: len(v) for k, v in out.items()})
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
+    if "init" in sys.argv[1:]:
+        gen_init()
     which = sys.argv[1:] or ["factored_tiny", "nic_tiny", "factored_full"]
     if "factored_tiny" in which:
         gen_factored_tiny()
