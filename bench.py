@@ -424,12 +424,71 @@ def main():
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / (n_rep * n_steps)
         step_bytes = 4 * Hh * Hh * 4 + bb * 4 * Hh * 4 + bb * Hh * 4 * 4 + bb * 4 * Hh * 4
+        per_launch = {"kernel": "lstm_step_fused_kernel, one launch per step replayed from a hipGraph",
+                      "us_per_step": round(us, 2), "achieved": round(step_bytes / us / 1e3, 1),
+                      "frac": round(step_bytes / us / 1e3 / 8000.0, 4)}
         lstm = {"bound": "hbm", "kernel": "lstm_step_fused_kernel (b=64, H=512; 24 dependent steps replayed from a hipGraph)",
                 "achieved": round(step_bytes / us / 1e3, 1), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(step_bytes / us / 1e3 / 8000.0, 4),
                 "traffic": pmc_traffic("lstm_step_bytes_per_launch")[0],
                 "traffic_source": pmc_traffic("lstm_step_bytes_per_launch")[1],
                 "bytes_per_step": step_bytes, "us_per_step": round(us, 2)}
+        if lib.capnet_lstm_persist_supported(bb, Hh):
+            # the product path for teacher-forced runs: ONE launch for the 24 dependent steps, weights
+            # register-resident (csrc/lstm_persist.hip); events on the launch stream around n_rep launches
+            img = torch.empty(lib.capnet_lstm_persist_w_floats(), device=dev)
+            capnet._lib.check(lib.capnet_lstm_persist_pack(wc.data_ptr(), img.data_ptr(), 0, capnet._lib.current_stream()))
+            bs24 = capnet._lib.int_array([bb] * n_steps)
+            G24 = torch.randn(n_steps * bb, 4 * Hh, device=dev)
+            G0 = G24.clone()
+            C24 = torch.empty(n_steps * bb, Hh, device=dev)
+            H24 = torch.empty(n_steps * bb, Hh, device=dev)
+            ctl = torch.zeros(lib.capnet_lstm_persist_ctl_ints(), dtype=torch.int32, device=dev)
+            errf = ops.err_flag(dev)
+
+            def persist_once():
+                ctl.zero_()
+                G24.copy_(G0)        # the launch overwrites its pre-activations with the gates
+                capnet._lib.check(lib.capnet_lstm_persist_run(
+                    img.data_ptr(), G24.data_ptr(), C24.data_ptr(), H24.data_ptr(), bs24, 0, n_steps, Hh, 0, 1,
+                    ctl.data_ptr(), errf.data_ptr(), None, capnet._lib.current_stream()))
+            for _ in range(3):
+                persist_once()
+            torch.cuda.synchronize()
+            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_rep)]
+            for e0, e1 in evs:
+                ctl.zero_()
+                G24.copy_(G0)
+                e0.record()
+                capnet._lib.check(lib.capnet_lstm_persist_run(
+                    img.data_ptr(), G24.data_ptr(), C24.data_ptr(), H24.data_ptr(), bs24, 0, n_steps, Hh, 0, 1,
+                    ctl.data_ptr(), errf.data_ptr(), None, capnet._lib.current_stream()))
+                e1.record()
+            torch.cuda.synchronize()
+            ops.check_device_errors()
+            t_launch = sorted(e0.elapsed_time(e1) * 1e3 for e0, e1 in evs)[n_rep // 2]     # us, median
+            us_p = t_launch / n_steps
+            w_bytes = 4 * Hh * Hh * 4
+            # step 0 has no recurrent product (h = 0): the 23 others are what the 5.77 MB describe;
+            # the whole launch (weight load, handshake, step 0) is charged to them
+            res_bytes = (step_bytes - w_bytes) * n_steps + w_bytes        # W read once per launch
+            lstm = {"bound": "hbm",
+                    "kernel": "lstm_persist_kernel<2> (b=64, H=512): %d dependent steps in ONE launch, weights "
+                              "register-resident, h handed between workgroups through L2" % n_steps,
+                    "how": "HIP events on the launch stream around each of %d launches, median; per step = launch "
+                           "time / %d (launch, weight load and step 0 included)" % (n_rep, n_steps),
+                    "accounting": "SURVEY 8(d): 5.77 MB per step (W 4.19 MB + pre-activations + h,c r/w + gate "
+                                  "save), i.e. as if W were re-read every step",
+                    "achieved": round(step_bytes / us_p / 1e3, 1), "peak": 8000.0, "unit": "GB/s",
+                    "frac": round(step_bytes / us_p / 1e3 / 8000.0, 4),
+                    "traffic": pmc_traffic("lstm_persist_bytes_per_step")[0],
+                    "traffic_source": pmc_traffic("lstm_persist_bytes_per_step")[1],
+                    "bytes_per_step": step_bytes, "us_per_step": round(us_p, 3), "us_per_launch": round(t_launch, 1),
+                    "weights_resident": {"accounting": "SURVEY 8(d) weights-resident variant: W counted once per launch",
+                                         "bytes_per_step": res_bytes // n_steps,
+                                         "achieved": round(res_bytes / t_launch / 1e3, 1),
+                                         "frac": round(res_bytes / t_launch / 1e3 / 8000.0, 4)},
+                    "launch_per_step": per_launch}
 
     # the two other rooflines SURVEY.md 8(d) names, timed with events on the launch stream:
     # the vocabulary projection (MFMA) and the attention step after the encoder_att hoist (HBM)

@@ -94,6 +94,11 @@ SIGNATURES = {
     "capnet_lstm_step_fused": (_i, [_vp, _vp, _vp, _l, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "capnet_lstm_step_fused_stamped": (_i, [_vp, _vp, _vp, _l, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "capnet_lstm_step_fused_supported": (_i, [_i, _i]),
+    "capnet_lstm_persist_supported": (_i, [_i, _i]),
+    "capnet_lstm_persist_w_floats": (_sz, []),
+    "capnet_lstm_persist_ctl_ints": (_sz, []),
+    "capnet_lstm_persist_pack": (_i, [_vp, _vp, _i, _vp]),
+    "capnet_lstm_persist_run": (_i, [_vp, _vp, _vp, _vp, _ip, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "capnet_xent_fwd": (_i, [_vp, _l, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "capnet_xent_bwd": (_i, [_vp, _l, _i, _i, _vp, _vp, _vp, _vp, _l, _vp]),
     "capnet_clamp_adam": (_i, [_i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp),

@@ -220,6 +220,28 @@ int capnet_lstm_step_fused_stamped(const float* h_prev, const float* w_frag, flo
 }
 int capnet_lstm_step_fused_supported(int b, int H) { return lstm_step_fused_supported(b, H) ? 1 : 0; }
 
+int capnet_lstm_persist_supported(int b, int H) { return lstm_persist_supported(b, H) ? 1 : 0; }
+size_t capnet_lstm_persist_w_floats(void) { return lstm_persist_w_floats(); }
+size_t capnet_lstm_persist_ctl_ints(void) { return lstm_persist_ctl_ints(); }
+int capnet_lstm_persist_pack(const float* w_cat, float* w_img, int cell, capnet_stream_t stream) {
+  CAPNET_REQUIRE(cell == kCellFactored || cell == kCellLSTM, "lstm_persist_pack: unknown cell %d", cell);
+  return cell == kCellFactored ? lstm_persist_pack(w_cat, w_img, 0, 1, 2, 3, S(stream))
+                               : lstm_persist_pack(w_cat, w_img, 0, 1, 3, 2, S(stream));
+}
+int capnet_lstm_persist_run(const float* w_img, float* gates, float* cell_states, float* hiddens,
+                            const int* batch_sizes, int t0, int t1, int H, int cell, int segment,
+                            int* ctl, int* err_flag, unsigned long long* stamps,
+                            capnet_stream_t stream) {
+  CAPNET_REQUIRE(cell == kCellFactored || cell == kCellLSTM, "lstm_persist_run: unknown cell %d", cell);
+  CAPNET_REQUIRE(batch_sizes && t1 > 0 && t1 <= kMaxSteps, "lstm_persist_run: bad steps");
+  int off[kMaxSteps + 1];
+  off[0] = 0;
+  for (int t = 0; t < t1; ++t) off[t + 1] = off[t] + batch_sizes[t];
+  const bool f = cell == kCellFactored;
+  return lstm_persist_run(w_img, gates, cell_states, hiddens, off, batch_sizes, t0, t1, H, 0, 1,
+                          f ? 2 : 3, f ? 3 : 2, f ? 0 : 1, segment, ctl, err_flag, S(stream), stamps);
+}
+
 size_t capnet_seq_saved_floats(const int* dims) { return seq_saved_floats(to_dims(dims)); }
 size_t capnet_seq_saved_ints(const int* dims) { return seq_saved_ints(to_dims(dims)); }
 size_t capnet_seq_fwd_scratch_floats(const int* dims) { return seq_fwd_scratch_floats(to_dims(dims)); }

@@ -23,9 +23,9 @@ namespace {
 
 struct Layout {
   // saved float buffer
-  size_t X, A1, A2, G, Cst, Vcat, Scat, Ucat, Wcat, Wfrag, bV, bS, bUW, total;
+  size_t X, A1, A2, G, Cst, Vcat, Scat, Ucat, Wcat, Wfrag, Wp, bV, bS, bUW, total;
   // int buffer
-  size_t row_sample, row_col, row_token, prev_row, itotal;
+  size_t row_sample, row_col, row_token, prev_row, ctl, itotal;
 };
 
 Layout make_layout(const SeqDims& d) {
@@ -38,6 +38,7 @@ Layout make_layout(const SeqDims& d) {
   L.Cst = take(N * H);
   L.Wcat = take(4 * H * H);
   L.Wfrag = take(H % 16 == 0 ? lstm_wfrag_floats((int)H) : 4);
+  L.Wp = take(H == 512 ? lstm_persist_w_floats() : 4);     // image of the persistent sequence kernel
   L.bUW = take(4 * H);
   if (d.cell == kCellFactored) {
     L.A1 = take(N * 4 * F);
@@ -58,6 +59,7 @@ Layout make_layout(const SeqDims& d) {
   L.row_col = itake(N);
   L.row_token = itake(N);
   L.prev_row = itake(N);
+  L.ctl = itake(lstm_persist_ctl_ints());
   L.itotal = io;
   return L;
 }
@@ -196,6 +198,13 @@ int seq_forward(const SeqDims& d, const int* batch_sizes, const unsigned char* t
 
   bool fused_step = H % 16 == 0 && lstm_step_fused_supported(batch_sizes[0], H);
   if (fused_step) RC(lstm_pack_wfrag(sv + L.Wcat, sv + L.Wfrag, H, go.gi, go.gf, go.go, go.gg, s));
+  // runs of teacher-forced steps go to ONE launch of the persistent kernel (csrc/lstm_persist.hip)
+  const bool persist = lstm_persist_supported(batch_sizes[0], H);
+  if (persist) {
+    RC(lstm_persist_pack(sv + L.Wcat, sv + L.Wp, go.gi, go.gf, go.go, go.gg, s));
+    CAPNET_HIP_CHECK(hipMemsetAsync(saved_i + L.ctl, 0, lstm_persist_ctl_ints() * sizeof(int), s));
+  }
+  int segment = 0;
 
   // ---- inputs + input chain for every row whose input is known up front
   CAPNET_HIP_CHECK(hipMemsetAsync(sv + L.X, 0, (size_t)N * E * sizeof(float), s));
@@ -220,6 +229,22 @@ int seq_forward(const SeqDims& d, const int* batch_sizes, const unsigned char* t
                          dropout_p, seed, 0, 1, err_flag, s));
         RC(input_chain(d, L, sv, r0, r0 + b, skws, kSplitKFloats, s));
       }
+    }
+    if (persist) {
+      // steps t .. t1-1: t's input is ready, the following ones are teacher forced
+      int t1 = t + 1;
+      while (t1 < d.steps && tf_mask[t1]) ++t1;
+      const bool single_fused = t1 == t + 1 && t > 0 && fused_step;   // one free-running step: no weights to keep
+      if (!single_fused) {
+        RC(lstm_persist_run(sv + L.Wp, sv + L.G, sv + L.Cst, hiddens, off.data(), batch_sizes, t, t1, H,
+                            go.gi, go.gf, go.go, go.gg, go.tanh_out, ++segment, saved_i + L.ctl,
+                            err_flag, s, nullptr));
+        t = t1 - 1;
+        continue;
+      }
+    }
+    if (t > 0) {
+      const float* h_prev = hiddens + (size_t)off[t - 1] * H;
       if (fused_step) {
         // gates += h_{t-1} . Wcat^T, activations and the c/h update in one launch
         RC(lstm_step_fused(h_prev, sv + L.Wfrag, sv + L.G + (size_t)r0 * 4 * H, 4 * H,

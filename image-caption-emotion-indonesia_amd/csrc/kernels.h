@@ -145,6 +145,16 @@ int lstm_step_fused(const float* hprev, const float* Wfrag, float* G, long ldg, 
                     float* c_out, float* h_out, int b, int H, int gi, int gf, int go, int gg,
                     int tanh_out, hipStream_t stream, unsigned long long* stamps = nullptr);
 
+// lstm_persist.hip: a run of teacher-forced steps [t0, t1) in one launch (H = 512, b <= 128)
+bool lstm_persist_supported(int b, int H);
+size_t lstm_persist_w_floats();
+size_t lstm_persist_ctl_ints();
+int lstm_persist_pack(const float* Wcat, float* Wp, int gi, int gf, int go, int gg, hipStream_t stream);
+int lstm_persist_run(const float* Wp, float* G, float* Cst, float* hiddens, const int* off,
+                     const int* batch_sizes, int t0, int t1, int H, int gi, int gf, int go, int gg,
+                     int tanh_out, int seg, int* ctl, int* err_flag, hipStream_t stream,
+                     unsigned long long* stamps);
+
 // att_kernels.hip
 int att_step_fwd(const float* att1, const float* feat, const float* att2, float* gate_io, long ldz,
                  const float* wf, const float* bf, int rows, int P, int A, int C,

@@ -1,0 +1,351 @@
+// Persistent LSTM sequence kernel: ONE launch runs a whole run of consecutive teacher-forced time
+// steps of the recurrence (stylenet/model.py:180-191 around forward_step :147-153; nn.LSTMCell of
+// nic/model.py:77), with the recurrent weights resident in registers for the launch.
+//
+//   per step t:  G_t += h_{t-1} . Wcat^T ;  i,f,o = sigmoid, g = tanh ;  c = f c + i g ;
+//                h = o c  (FactoredLSTM, model.py:153)  |  h = o tanh(c)  (LSTMCell)
+//
+// Decomposition (H = 512, b <= 128; 256 workgroups x 256 threads = one per CU):
+//   * workgroup id -> (shard = id % 8, slot = id / 8). A shard owns the batch rows g = 8 m + shard
+//     (m < 16) and ALL of Wcat; the dispatcher deals workgroups round-robin over the 8 XCDs, so a
+//     shard normally sits on ONE XCD and its 32 workgroups exchange h through that XCD's L2.
+//   * slot s owns hidden units 16 s .. 16 s + 15 = 64 gate columns, over the whole K = 512: 128 KB
+//     of fp32 weights = 128 VGPRs per lane, loaded once per launch. Wave w holds k in
+//     [128 w, 128 w + 128): split-K over the 4 waves, summed through LDS.
+//   * the product uses v_mfma_f32_4x4x1_16B_f32: 16 independent 4x4 outer products per instruction
+//     at the full f32 matrix rate (64 FLOP/clk/SIMD), so 8 rows per shard waste nothing (a 16x16x4
+//     tile would be half empty at b = 64). Block bl of an instruction = gate columns of unit bl of
+//     the slot; its A operand (4 rows x one k) comes from ONE VGPR that holds 16 different k (lane
+//     4 bl + i <-> row i, k0 + bl): the instruction's CBSZ = 4 / ABID = bl' broadcast selects which
+//     k. h_{t-1} therefore goes from global memory straight into MFMA operands: no LDS staging.
+//   * exchange of h between the steps: the rows of h_t are the rows of the `hiddens` output
+//     itself. A wave stores its part, waits for the stores (vmcnt), then stores tick t + 1 into its
+//     flag; a consuming wave polls the 32 flags of the 8 slots that produce its k range, then loads
+//     h with L1-bypassing (sc1) loads. Nothing is ever overwritten (every step has its own rows,
+//     flags only grow), so there is no write-after-read hazard and no reset.
+//   * c never leaves registers; pre-activations of step t are requested before the poll.
+//
+// Cross-workgroup visibility (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement &
+// inter-workgroup visibility"): correctness never assumes a placement. At start every workgroup
+// publishes its XCC id (HW_REG_XCC_ID) in a table, with a write-through store, and reads its
+// shard's 32 entries. If they are all equal the shard is in LOCAL mode: plain stores (they stay in
+// that XCD's L2, which all 32 workgroups share) + sc1 loads. Otherwise it is in SAFE mode: every
+// handed-off byte and flag is stored write-through (agent scope, sc1) and loaded with sc1 loads,
+// the form the guide measures as valid across XCDs. Both modes run the same code; only the cache
+// policy of the h / flag stores differs.
+// Every spin is bounded: a workgroup that waits too long (co-residency lost, a peer died) raises the
+// abort word, sets bit 2 of err_flag and every workgroup leaves; the host sees the flag at its next
+// check and the caller falls back to launch-per-step (CAPNET_NO_PERSISTENT_LSTM=1).
+#include <cstdlib>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace capnet {
+
+typedef float pf32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kPH = 512;            // hidden size
+constexpr int kPShards = 8;
+constexpr int kPSlots = 32;
+constexpr int kPUnits = 16;         // hidden units per slot
+constexpr int kPGrid = kPShards * kPSlots;
+constexpr int kPMaxRows = 16;       // rows per shard (b <= 128)
+// control block (ints): flags [shard][slot][wave] | xcc table [shard][slot] | abort
+constexpr int kCtlFlags = 0;
+constexpr int kCtlXcc = kPGrid * 4;
+constexpr int kCtlAbort = kCtlXcc + kPGrid;
+constexpr int kCtlInts = 2048;
+constexpr int kSpinBound = 1 << 21;
+
+struct PersistArgs {
+  const float* Wp;
+  float* G;
+  float* Cst;
+  float* hiddens;
+  int* ctl;
+  int* err_flag;
+  unsigned long long* stamps;   // diagnostics only (tools/step_phases.py), else nullptr
+  int t0, t1, cfg, seg;
+  int off[kMaxSteps + 1];
+  short b[kMaxSteps];
+};
+
+__device__ __forceinline__ float p_sigm(float x) { return 1.f / (1.f + expf(-x)); }
+
+__device__ __forceinline__ int ld_sc1_i32(const int* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_sc1_i32(int* p, int v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_sc1_f32(float* p, float v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// 16-B load that bypasses the vector L1 (served by L2 or beyond); not valid before wait_vm0()
+__device__ __forceinline__ void ld16_sc1(pf32x4& dst, const float* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(dst) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// RB: 4-row blocks per shard (rows per shard <= 4 RB)
+template <int RB>
+__global__ __launch_bounds__(256) void lstm_persist_kernel(const PersistArgs a) {
+  constexpr int H = kPH;
+  __shared__ __attribute__((aligned(16))) float red[2][4][4 * RB][64];
+  __shared__ int s_local, s_abort;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int shard = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int bl = lane >> 2, li = lane & 3;
+  int* ctl = a.ctl;
+  const int gi = a.cfg & 3, gf = (a.cfg >> 2) & 3, go = (a.cfg >> 4) & 3, gg = (a.cfg >> 6) & 3;
+  const int tanh_out = (a.cfg >> 8) & 1;
+  const int u0 = slot * kPUnits;
+
+  // ---- weights of this wave: 128 VGPRs, requested first so that the handshake hides behind them
+  pf32x4 wq[32];
+  {
+    const pf32x4* wp = reinterpret_cast<const pf32x4*>(a.Wp) + ((long)(slot * 4 + wave) * 32) * 64 + lane;
+#pragma unroll
+    for (int q = 0; q < 32; ++q) wq[q] = wp[(long)q * 64];
+  }
+  // ---- placement handshake: publish my XCC id, read the shard's 32 entries
+  if (tid == 0) {
+    s_abort = 0;
+    unsigned x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    st_sc1_i32(&ctl[kCtlXcc + shard * kPSlots + slot], (a.seg << 4) | (int)(x & 15));
+  }
+  if (wave == 0) {
+    int spins = 0, ok = 0, same = 0;
+    while (true) {
+      const int v = ld_sc1_i32(&ctl[kCtlXcc + shard * kPSlots + (lane & 31)]);
+      const int mine = __shfl(v, slot, 64);
+      ok = __all((v >> 4) == a.seg);
+      same = __all(v == mine);
+      if (ok) break;
+      if (++spins > kSpinBound || ((spins & 255) == 0 && ld_sc1_i32(&ctl[kCtlAbort]) != 0)) break;
+      __builtin_amdgcn_s_sleep(4);
+    }
+    if (lane == 0) {
+      s_local = ok && same;
+      if (!ok) {
+        s_abort = 1;
+        st_sc1_i32(&ctl[kCtlAbort], 1);
+        atomicOr(a.err_flag, 4);
+      }
+    }
+  }
+  __syncthreads();
+  if (s_abort) return;
+  const bool local = s_local != 0;
+
+  // ---- epilogue role: thread e -> (row m of the shard, unit u of the slot)
+  const int em = tid >> 4, eu = tid & 15;
+  const int grow = 8 * em + shard;          // global batch row
+  float c_reg = 0.f;
+  if (a.t0 > 0 && em < 4 * RB && grow < a.b[a.t0 - 1])
+    c_reg = a.Cst[(long)(a.off[a.t0 - 1] + grow) * H + u0 + eu];
+  // flags this wave polls: the 8 slots that produce k in [128 wave, 128 wave + 128), 4 waves each
+  const int* my_flags = ctl + kCtlFlags + (shard * kPSlots + 8 * wave) * 4 + (lane & 31);
+  int* out_flag = ctl + kCtlFlags + (shard * kPSlots + slot) * 4 + wave;
+
+  for (int t = a.t0; t < a.t1; ++t) {
+    const int bt = a.b[t];
+    const int rows_t = (bt - shard + 7) >> 3;        // rows of this shard still alive
+    const int ro = a.off[t];
+    const bool evalid = em < rows_t;                  // (rows_t <= 4 RB by construction)
+    const long erow = ro + (evalid ? grow : shard);
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0;
+    if (a.stamps) ts0 = __builtin_amdgcn_s_memtime();
+    // pre-activations of this step (written by the input-chain GEMMs before this launch)
+    float pre[4];
+    const int gsel[4] = {gi, gf, go, gg};
+#pragma unroll
+    for (int g = 0; g < 4; ++g) pre[g] = a.G[erow * (4 * H) + (long)gsel[g] * H + u0 + eu];
+    __builtin_amdgcn_sched_barrier(0);
+
+    if (t > 0) {
+      // ---- wait for h_{t-1}: produced inside this launch for t > t0, by earlier launches at t0
+      if (t > a.t0) {
+        int spins = 0;
+        while (true) {
+          const int v = ld_sc1_i32(my_flags);
+          if (__all(v - t >= 0)) break;
+          if (++spins > kSpinBound || ((spins & 255) == 0 && ld_sc1_i32(&ctl[kCtlAbort]) != 0)) {
+            if (lane == 0) {
+              st_sc1_i32(&ctl[kCtlAbort], 1);
+              atomicOr(a.err_flag, 4);
+            }
+            break;
+          }
+        }
+      }
+      if (a.stamps) ts1 = __builtin_amdgcn_s_memtime();
+      // ---- A operands: lane (bl, li) of row block r holds h[row 4 r + li][128 wave + 64 Q + 4 bl + e]
+      const int rp = a.off[t - 1];
+      pf32x4 av[RB][2];
+#pragma unroll
+      for (int r = 0; r < RB; ++r) {
+        const int m = 4 * r + li;
+        const int g = 8 * (m < rows_t ? m : 0) + shard;
+        const float* hp = a.hiddens + (long)(rp + g) * H + 128 * wave + 4 * bl;
+        ld16_sc1(av[r][0], hp);
+        ld16_sc1(av[r][1], hp + 64);
+      }
+      wait_vm0();
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- 128 k x RB row blocks: outer products, two accumulator sets per row block
+      pf32x4 acc[RB][2];
+#pragma unroll
+      for (int r = 0; r < RB; ++r) acc[r][0] = acc[r][1] = pf32x4{0.f, 0.f, 0.f, 0.f};
+      // (ABID must be an immediate: one macro instance per broadcast block)
+#define CAPNET_PBLK(B2)                                                                             \
+  _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                     \
+  _Pragma("unroll") for (int r = 0; r < RB; ++r)                                                    \
+    if (4 * r < rows_t)                                                                             \
+      acc[r][e & 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[r][Q][e], wq[16 * Q + B2][e],           \
+                                                         acc[r][e & 1], 4, B2, 0);
+#pragma unroll
+      for (int Q = 0; Q < 2; ++Q) {
+        CAPNET_PBLK(0) CAPNET_PBLK(1) CAPNET_PBLK(2) CAPNET_PBLK(3)
+        CAPNET_PBLK(4) CAPNET_PBLK(5) CAPNET_PBLK(6) CAPNET_PBLK(7)
+        CAPNET_PBLK(8) CAPNET_PBLK(9) CAPNET_PBLK(10) CAPNET_PBLK(11)
+        CAPNET_PBLK(12) CAPNET_PBLK(13) CAPNET_PBLK(14) CAPNET_PBLK(15)
+      }
+#undef CAPNET_PBLK
+      if (a.stamps) ts2 = __builtin_amdgcn_s_memtime();
+      // D: register i, lane 4 bl + j = out[row 4 r + i][unit bl, gate j]
+#pragma unroll
+      for (int r = 0; r < RB; ++r)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) red[t & 1][wave][4 * r + i][lane] = acc[r][0][i] + acc[r][1][i];
+      __syncthreads();
+      if (evalid) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          const pf32x4 p = *reinterpret_cast<const pf32x4*>(&red[t & 1][w][em][4 * eu]);
+          pre[0] += p[0]; pre[1] += p[1]; pre[2] += p[2]; pre[3] += p[3];
+        }
+      }
+    }
+    if (a.stamps) ts3 = __builtin_amdgcn_s_memtime();
+    if (evalid) {
+      const float i = p_sigm(pre[0]), f = p_sigm(pre[1]), og = p_sigm(pre[2]), gt = tanhf(pre[3]);
+      c_reg = f * c_reg + i * gt;
+      const float h = tanh_out ? og * tanhf(c_reg) : og * c_reg;
+      float* hp = a.hiddens + erow * H + u0 + eu;
+      if (local) *hp = h; else st_sc1_f32(hp, h);       // first: the flag waits for this one only
+      a.G[erow * (4 * H) + (long)gi * H + u0 + eu] = i;
+      a.G[erow * (4 * H) + (long)gf * H + u0 + eu] = f;
+      a.G[erow * (4 * H) + (long)go * H + u0 + eu] = og;
+      a.G[erow * (4 * H) + (long)gg * H + u0 + eu] = gt;
+      a.Cst[erow * H + u0 + eu] = c_reg;
+    }
+    if (t + 1 < a.t1) {
+      // every wave signals for its own stores: the h store is the oldest of (at most) six
+      if (evalid) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      if (__any(evalid) == 0) { /* no store of this wave to wait for */ }
+      else wait_vm0();   // lanes of a wave retire together: cover the partially valid wave too
+      if (lane == 0) {
+        if (local) *reinterpret_cast<volatile int*>(out_flag) = t + 1;
+        else st_sc1_i32(out_flag, t + 1);
+      }
+    }
+    if (a.stamps && tid == 0) {
+      unsigned long long* st = a.stamps + ((long)(t - a.t0) * kPGrid + blockIdx.x) * 5;
+      st[0] = ts0; st[1] = ts1; st[2] = ts2; st[3] = ts3; st[4] = __builtin_amdgcn_s_memtime();
+    }
+  }
+}
+
+// Wp[((slot*4 + w)*32 + q)*256 + lane*4 + e] = Wcat[grow[j]*H + 16 slot + bl][128 w + 4 q + e],
+// lane = 4 bl + j (bl: unit of the slot, j: gate role i,f,o,g)
+__global__ __launch_bounds__(256) void lstm_persist_pack_kernel(const float* __restrict__ Wcat,
+                                                                float* __restrict__ Wp, int g0,
+                                                                int g1, int g2, int g3) {
+  const int grow[4] = {g0, g1, g2, g3};
+  const long total = 4L * kPH * kPH;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int e = (int)(i & 3), lane = (int)((i >> 2) & 63);
+    long r = i >> 8;
+    const int q = (int)(r & 31); r >>= 5;
+    const int w = (int)(r & 3);
+    const int slot = (int)(r >> 2);
+    const int bl = lane >> 2, j = lane & 3;
+    Wp[i] = Wcat[((long)grow[j] * kPH + 16 * slot + bl) * kPH + 128 * w + 4 * q + e];
+  }
+}
+
+size_t lstm_persist_w_floats() { return 4ul * kPH * kPH; }
+size_t lstm_persist_ctl_ints() { return kCtlInts; }
+
+// One-time residency check: what a cooperative launch would verify (all 256 workgroups can be
+// resident at once on an idle device), without paying its per-launch cost.
+static int persist_device_ok() {
+  static int cached = -1;
+  if (cached >= 0) return cached;
+  int dev = 0, cus = 0, per_cu = 0;
+  if (hipGetDevice(&dev) != hipSuccess ||
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+    (void)hipGetLastError();
+    return cached = 0;
+  }
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)lstm_persist_kernel<4>, 256,
+                                                   0) != hipSuccess) {
+    (void)hipGetLastError();
+    return cached = 0;
+  }
+  const char* off = getenv("CAPNET_NO_PERSISTENT_LSTM");
+  cached = (cus >= kPGrid && per_cu >= 1 && !(off && off[0] == '1')) ? 1 : 0;
+  return cached;
+}
+
+bool lstm_persist_supported(int b, int H) {
+  return H == kPH && b >= 1 && b <= 8 * kPMaxRows && persist_device_ok();
+}
+
+int lstm_persist_pack(const float* Wcat, float* Wp, int gi, int gf, int go, int gg, hipStream_t stream) {
+  CAPNET_REQUIRE(Wcat && Wp && aligned16(Wp), "lstm_persist_pack: bad argument");
+  hipLaunchKernelGGL(lstm_persist_pack_kernel, dim3(1024), dim3(256), 0, stream, Wcat, Wp, gi, gf, go, gg);
+  CAPNET_LAUNCH_CHECK();
+  return kOk;
+}
+
+int lstm_persist_run(const float* Wp, float* G, float* Cst, float* hiddens, const int* off,
+                     const int* batch_sizes, int t0, int t1, int H, int gi, int gf, int go, int gg,
+                     int tanh_out, int seg, int* ctl, int* err_flag, hipStream_t stream,
+                     unsigned long long* stamps) {
+  CAPNET_REQUIRE(Wp && G && Cst && hiddens && off && batch_sizes && ctl && err_flag,
+                 "lstm_persist_run: null argument");
+  CAPNET_REQUIRE(0 <= t0 && t0 < t1 && t1 <= kMaxSteps, "lstm_persist_run: steps [%d, %d)", t0, t1);
+  CAPNET_REQUIRE(seg > 0 && seg < (1 << 26), "lstm_persist_run: segment tag %d", seg);
+  const int b0 = batch_sizes[t0 > 0 ? t0 - 1 : t0];
+  CAPNET_REQUIRE(lstm_persist_supported(b0, H), "lstm_persist_run: unsupported b=%d H=%d", b0, H);
+  CAPNET_REQUIRE(aligned16(Wp) && aligned16(hiddens), "lstm_persist_run: alignment");
+  PersistArgs a;
+  a.Wp = Wp; a.G = G; a.Cst = Cst; a.hiddens = hiddens; a.ctl = ctl; a.err_flag = err_flag;
+  a.stamps = stamps;
+  a.t0 = t0; a.t1 = t1; a.seg = seg;
+  a.cfg = gi | (gf << 2) | (go << 4) | (gg << 6) | ((tanh_out ? 1 : 0) << 8);
+  for (int t = 0; t <= t1; ++t) a.off[t] = off[t];
+  int prev = 1 << 30;
+  for (int t = (t0 > 0 ? t0 - 1 : 0); t < t1; ++t) {
+    CAPNET_REQUIRE(batch_sizes[t] >= 1 && batch_sizes[t] <= prev, "lstm_persist_run: batch sizes must not grow");
+    prev = batch_sizes[t];
+  }
+  for (int t = 0; t < t1; ++t) a.b[t] = (short)batch_sizes[t];
+  const int rows0 = (batch_sizes[t0] + 7) / 8;        // rows of shard 0 at the first step
+  const int rb = (rows0 + 3) / 4;
+  switch (rb) {
+    case 1: hipLaunchKernelGGL(lstm_persist_kernel<1>, dim3(kPGrid), dim3(256), 0, stream, a); break;
+    case 2: hipLaunchKernelGGL(lstm_persist_kernel<2>, dim3(kPGrid), dim3(256), 0, stream, a); break;
+    case 3: hipLaunchKernelGGL(lstm_persist_kernel<3>, dim3(kPGrid), dim3(256), 0, stream, a); break;
+    default: hipLaunchKernelGGL(lstm_persist_kernel<4>, dim3(kPGrid), dim3(256), 0, stream, a); break;
+  }
+  CAPNET_LAUNCH_CHECK();
+  return kOk;
+}
+
+}  // namespace capnet

@@ -313,6 +313,31 @@ int capnet_lstm_step_fused_stamped(const float* h_prev, const float* w_frag, flo
                                    unsigned long long* stamps, capnet_stream_t stream);
 int capnet_lstm_step_fused_supported(int b, int H);
 
+/* Persistent sequence kernel: steps [t0, t1) of the recurrence in ONE launch, the recurrent
+ * weights register-resident for the launch (north star: "the LSTM step as a persistent
+ * wavefront-resident kernel"; the loop it replaces: stylenet/model.py:180-191 for teacher-forced
+ * steps, cell :147-153 / nic/model.py:77). H = 512, b <= 128, a device with >= 256 CUs
+ * (capnet_lstm_persist_supported; CAPNET_NO_PERSISTENT_LSTM=1 disables it).
+ *   w_img        capnet_lstm_persist_pack image of w_cat [4H][H]     (capnet_lstm_persist_w_floats)
+ *   gates        [N][4H] packed time-major: in = pre-activations without the recurrent term,
+ *                out = activated gates (blocks in the cell's order)
+ *   cell_states  [N][H] out (row block of step t0-1 is read when t0 > 0)
+ *   hiddens      [N][H] out (row block of step t0-1 is read when t0 > 0); also the medium through
+ *                which the workgroups hand h_t to each other
+ *   batch_sizes  [t1] non-increasing rows per step (host array)
+ *   ctl          capnet_lstm_persist_ctl_ints() ints, zeroed once before the first segment of a
+ *                forward pass; segment = 1, 2, ... numbers the launches that share it
+ *   err_flag     bit 2 is set if a bounded wait expired (the results are then invalid)
+ *   stamps       NULL, or [t1-t0][256][5] uint64 s_memtime readings (diagnostics) */
+int capnet_lstm_persist_supported(int b, int H);
+size_t capnet_lstm_persist_w_floats(void);
+size_t capnet_lstm_persist_ctl_ints(void);
+int capnet_lstm_persist_pack(const float* w_cat, float* w_img, int cell, capnet_stream_t stream);
+int capnet_lstm_persist_run(const float* w_img, float* gates, float* cell_states, float* hiddens,
+                            const int* batch_sizes, int t0, int t1, int H, int cell, int segment,
+                            int* ctl, int* err_flag, unsigned long long* stamps,
+                            capnet_stream_t stream);
+
 /* ---- loss: nn.CrossEntropyLoss() (mean) -- stylenet/train_multitask.py:134,383 ---------- */
 int capnet_xent_fwd(const float* logits, long ld, int N, int V, const long long* targets,
                     float* lse, float* row_loss, float* loss, int* err_flag,

@@ -1,0 +1,161 @@
+"""The persistent LSTM sequence kernel (csrc/lstm_persist.hip) through the C ABI: one launch runs a
+whole run of recurrent steps -- stylenet/model.py:147-153 (h = o*c) and nn.LSTMCell of
+nic/model.py:77 (gate order i,f,g,o; h = o*tanh(c)) -- with shrinking batches, mid-sequence restarts
+(segments) and every batch size up to 128. Checked against a float64 loop of the same recurrence,
+and against the launch-per-step kernel it replaces."""
+import ctypes as C
+
+import pytest
+import torch
+
+import capnet
+from capnet import _lib
+from capnet._lib import check, current_stream, int_array
+
+pytestmark = pytest.mark.gpu
+H = 512
+
+
+def _reference(W, pre, bs, cell):
+    """float64: gates_t = pre_t + h_{t-1} W^T; returns (hiddens, cells, activated gates), packed."""
+    W = W.double()
+    off = [0]
+    for b in bs:
+        off.append(off[-1] + b)
+    hs, cs, gs = [], [], []
+    h = torch.zeros(bs[0], H, dtype=torch.float64)
+    c = torch.zeros(bs[0], H, dtype=torch.float64)
+    for t, b in enumerate(bs):
+        g = pre[off[t]:off[t + 1]].double() + (h[:b] @ W.t() if t > 0 else 0)
+        if cell == 0:
+            i, f, o, gg = [g[:, k * H:(k + 1) * H] for k in range(4)]
+        else:
+            i, f, gg, o = [g[:, k * H:(k + 1) * H] for k in range(4)]
+        i, f, o, gg = torch.sigmoid(i), torch.sigmoid(f), torch.sigmoid(o), torch.tanh(gg)
+        c = f * c[:b] + i * gg
+        h = o * c if cell == 0 else o * torch.tanh(c)
+        act = torch.cat([i, f, o, gg] if cell == 0 else [i, f, gg, o], 1)
+        hs.append(h)
+        cs.append(c)
+        gs.append(act)
+    return torch.cat(hs), torch.cat(cs), torch.cat(gs)
+
+
+def _run(dev, W, pre, bs, cell, segments):
+    L = capnet.lib()
+    N = sum(bs)
+    Wd = W.to(dev)
+    img = torch.empty(L.capnet_lstm_persist_w_floats(), device=dev)
+    check(L.capnet_lstm_persist_pack(Wd.data_ptr(), img.data_ptr(), cell, current_stream()))
+    G = pre.clone().to(dev)
+    Cst = torch.full((N, H), float("nan"), device=dev)
+    hid = torch.full((N, H), float("nan"), device=dev)
+    ctl = torch.zeros(L.capnet_lstm_persist_ctl_ints(), dtype=torch.int32, device=dev)
+    err = torch.zeros(1, dtype=torch.int32, device=dev)
+    for k, (t0, t1) in enumerate(segments):
+        check(L.capnet_lstm_persist_run(img.data_ptr(), G.data_ptr(), Cst.data_ptr(), hid.data_ptr(),
+                                        int_array(bs), t0, t1, H, cell, k + 1, ctl.data_ptr(), err.data_ptr(),
+                                        None, current_stream()), "capnet_lstm_persist_run")
+    torch.cuda.synchronize()
+    assert int(err.item()) == 0, "a bounded wait expired"
+    return hid.cpu(), Cst.cpu(), G.cpu()
+
+
+def _case(seed, bs):
+    g = torch.Generator().manual_seed(seed)
+    W = (torch.rand(4 * H, H, generator=g) * 2 - 1) * 0.06
+    pre = torch.randn(sum(bs), 4 * H, generator=g)
+    return W, pre
+
+
+def _close(a, b, tol):
+    assert torch.isfinite(a).all()
+    assert ((a.double() - b).abs().max() / b.abs().max()).item() < tol
+
+
+CASES = {
+    "b64_24": [64] * 8 + [60, 57, 50, 44, 41, 33, 32, 30, 25, 17, 16, 9, 8, 7, 2, 1],
+    "b96": [96, 96, 90, 75, 66, 65, 64, 40, 13],
+    "b128": [128, 128, 127, 100, 97],
+    "b8": [8, 8, 8, 5, 3, 1],
+    "b3": [3, 3, 2, 2, 1],
+    "b33": [33, 33, 32, 31, 17, 16, 15],
+}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+@pytest.mark.parametrize("cell", [0, 1])
+def test_persistent_sequence_matches_float64(dev, name, cell):
+    if not capnet.lib().capnet_lstm_persist_supported(64, H):
+        pytest.skip("persistent kernel not supported on this device")
+    bs = CASES[name]
+    W, pre = _case(len(bs) * 7 + cell, bs)
+    hid, cst, gates = _run(dev, W, pre, bs, cell, [(0, len(bs))])
+    rh, rc, rg = _reference(W, pre, bs, cell)
+    _close(hid, rh, 2e-6)
+    _close(cst, rc, 2e-6)
+    _close(gates, rg, 2e-6)
+
+
+def test_segments_restart_from_global_state(dev):
+    """A forward pass with free-running steps cuts the recurrence into several launches: each one
+    picks h and c of the previous step up from the output buffers (same control block, segment
+    tags 1, 2, ...), also from a step run by the launch-per-step kernel in between."""
+    L = capnet.lib()
+    if not L.capnet_lstm_persist_supported(64, H):
+        pytest.skip("persistent kernel not supported on this device")
+    bs = CASES["b64_24"]
+    W, pre = _case(5, bs)
+    rh, rc, rg = _reference(W, pre, bs, 0)
+    whole = _run(dev, W, pre, bs, 0, [(0, len(bs))])
+    parts = _run(dev, W, pre, bs, 0, [(0, 1), (1, 2), (2, 9), (9, 10), (10, 24)])
+    for a, b in zip(whole, parts):
+        assert torch.equal(a, b)          # same arithmetic whatever the cut
+    _close(parts[0], rh, 2e-6)
+
+
+def test_persistent_equals_launch_per_step_kernel(dev):
+    L = capnet.lib()
+    if not L.capnet_lstm_persist_supported(64, H):
+        pytest.skip("persistent kernel not supported on this device")
+    bs = [64] * 6
+    W, pre = _case(9, bs)
+    hid, cst, gates = _run(dev, W, pre, bs, 0, [(0, len(bs))])
+    # launch per step: capnet_lstm_pointwise_fwd for t = 0, capnet_lstm_step_fused afterwards
+    Wd = W.to(dev)
+    wf = torch.empty(L.capnet_lstm_wfrag_floats(H), device=dev)
+    check(L.capnet_lstm_pack_wfrag(Wd.data_ptr(), wf.data_ptr(), H, 0, current_stream()))
+    G = pre.clone().to(dev)
+    h = torch.zeros(sum(bs), H, device=dev)
+    c = torch.zeros(sum(bs), H, device=dev)
+    for t in range(len(bs)):
+        r0 = 64 * t
+        if t == 0:
+            check(L.capnet_lstm_pointwise_fwd(G[r0:].data_ptr(), None, c[r0:].data_ptr(), h[r0:].data_ptr(), 64, H, 0,
+                                              current_stream()))
+        else:
+            check(L.capnet_lstm_step_fused(h[r0 - 64:].data_ptr(), wf.data_ptr(), G[r0:].data_ptr(), 4 * H,
+                                           c[r0 - 64:].data_ptr(), c[r0:].data_ptr(), h[r0:].data_ptr(), 64, H, 0,
+                                           current_stream()))
+    torch.cuda.synchronize()
+    # different summation orders of the same fp32 products
+    assert (hid - h.cpu()).abs().max().item() < 2e-6
+    assert (cst - c.cpu()).abs().max().item() < 4e-6
+
+
+def test_persistent_rejects_bad_arguments(dev):
+    L = capnet.lib()
+    assert L.capnet_lstm_persist_supported(64, 256) == 0
+    assert L.capnet_lstm_persist_supported(129, H) == 0
+    if not L.capnet_lstm_persist_supported(64, H):
+        pytest.skip("persistent kernel not supported on this device")
+    img = torch.zeros(L.capnet_lstm_persist_w_floats(), device=dev)
+    buf = torch.zeros(64 * 4 * H, device=dev)
+    ctl = torch.zeros(L.capnet_lstm_persist_ctl_ints(), dtype=torch.int32, device=dev)
+    err = torch.zeros(1, dtype=torch.int32, device=dev)
+    args = lambda bs, t0, t1, seg: (img.data_ptr(), buf.data_ptr(), buf.data_ptr(), buf.data_ptr(), int_array(bs),
+                                    t0, t1, H, 0, seg, ctl.data_ptr(), err.data_ptr(), None, current_stream())
+    assert L.capnet_lstm_persist_run(*args([4, 8], 0, 2, 1)) != 0        # growing batch
+    assert L.capnet_lstm_persist_run(*args([4, 4], 1, 1, 1)) != 0        # empty range
+    assert L.capnet_lstm_persist_run(*args([4, 4], 0, 2, 0)) != 0        # segment tags start at 1
+    assert b"lstm_persist_run" in L.capnet_last_error()

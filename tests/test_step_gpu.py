@@ -239,19 +239,24 @@ def _att_modules(V, dev):
     return enc, est, dec, p
 
 
-def test_attention_train_steps_match_the_cpu_oracle(dev):
+@pytest.mark.parametrize("ratio", [1.0, 0.8])
+def test_attention_train_steps_match_the_cpu_oracle(dev, ratio):
     """configs[3] per GPU: 12 images, spatial ResNet-152 features [12, 14, 14, 2048], additive
     attention decoder, V = 8192; inputs captions[:, :-1], targets captions[:, 1:], lengths - 1, loss
     = NLL + ((1 - sum_t alpha)^2).mean() (train_multitask_att.py:402-411); two steps, so the second
     loss checks backward + clamp + Adam of every attention / init / f_beta / factored parameter."""
     from oracle.resnet152_ref import EncoderCNNAttRef
     from capnet.train import train_step_att
-    V, B, steps, lr, clip = 8192, 12, 2, 2e-3, 0.5
+    # lr = the reference's 2e-4 (train_multitask_att.py:655). Adam's first steps move EVERY element
+    # by ~lr whatever its gradient's size, so elements whose gradient is at rounding level take
+    # opposite signs on the two sides; at lr 2e-3 (26 M parameters, displacement norm 10) that
+    # second-order effect alone was 6e-4 of the second loss, at 2e-4 it is 100x smaller.
+    V, B, steps, lr, clip = 8192, 12, 3, 2e-4, 0.5
     torch.set_num_threads(16)
     enc, est, dec, p = _att_modules(V, dev)
     imgs, captions, lengths = synthetic.make_batch(B, V, seed=0)
     random.seed(11)
-    tfs = [[random.random() < 0.8 for _ in range(max(lengths))] for _ in range(steps)]
+    tfs = [[random.random() < ratio for _ in range(max(lengths))] for _ in range(steps)]
 
     ref_enc = EncoderCNNAttRef(14)
     ref_enc.load_state_dict({k: v.clone() for k, v in est.items()})
@@ -280,15 +285,21 @@ def test_attention_train_steps_match_the_cpu_oracle(dev):
     got = [float(train_step_att(enc, dec, opt, CrossEntropyLoss(), imgs_d, caps_d, lengths, clip,
                                 tf_mask=tfs[it]).item()) for it in range(steps)]
     capnet.ops.check_device_errors()
-    print("att oracle", ref_losses, "gpu", got)
+    print("att tf", ratio, "oracle", ref_losses, "gpu", got)
     for a, b in zip(got, ref_losses):
         assert abs(a - b) / abs(b) < 1e-4, (got, ref_losses)
     assert ref_losses[-1] != ref_losses[0]
-    # one updated parameter of each family, after two steps
+    # one updated parameter of each family after the three steps: it moved, and all but the
+    # rounding-level elements moved the same way (an element whose gradient sign is noise ends up
+    # to 2 * lr * steps away)
     sd = dec.state_dict()
-    for k in ("attention.encoder_att.weight", "f_beta.weight", "init_h.weight", "V_i.weight", "C.bias"):
-        d = (sd[k].cpu() - p_ref[k]).abs().max().item()
-        assert d <= 0.05 * lr * steps + 1e-6 * p_ref[k].abs().max().item(), (k, d)
+    for k in ("attention.encoder_att.weight", "attention.full_att.weight", "f_beta.weight", "init_h.weight",
+              "init_c.bias", "V_i.weight", "S_fo.weight", "U_c.weight", "W_f.weight", "C.weight"):
+        got_k = sd[k].cpu()
+        assert (got_k - p[k]).abs().max().item() > 0.5 * lr, k
+        off = ((got_k - p_ref[k]).abs() > 0.1 * lr).float().mean().item()
+        assert off < 2e-2, (k, off)
+        assert (got_k - p_ref[k]).abs().max().item() <= 2.01 * lr * steps, k
 
 
 def test_pipelined_attention_steps_equal_sequential_steps(dev):
@@ -304,7 +315,7 @@ def test_pipelined_attention_steps_equal_sequential_steps(dev):
         enc, _, dec, _ = _att_modules(V, dev)
         enc.to(dev).train()
         dec.to(dev).train()
-        return enc, dec, Adam(list(dec.parameters()), lr=2e-3)
+        return enc, dec, Adam(list(dec.parameters()), lr=2e-4)
 
     enc, dec, opt = build()
     seq = [float(train_step_att(enc, dec, opt, CrossEntropyLoss(), i.to(dev), c.to(dev), l, 0.5,
@@ -325,8 +336,13 @@ def test_pipelined_attention_steps_equal_sequential_steps(dev):
     torch.cuda.synchronize()
     got = [float(l.item()) for l in got]
     print("att sequential", seq, "pipelined", got)
-    for a, b in zip(got, seq):
+    # the embedding gradient is scattered with float atomics (order varies run to run) and Adam turns
+    # a rounding-level gradient into a +-lr update, so later steps agree closely, not bitwise; a step
+    # on the wrong features / tokens / parameters would be off by 1e-2
+    for a, b in zip(got[:2], seq[:2]):
         assert abs(a - b) / abs(b) < 2e-6
+    for a, b in zip(got, seq):
+        assert abs(a - b) / abs(b) < 2e-5
     assert torch.equal(enc.resnet[7][2].bn3.running_mean, ref_rm)
     assert (dec.attention.decoder_att.weight - ref_w).abs().max().item() <= 2e-3 * ref_w.abs().max().item()
 
@@ -400,8 +416,11 @@ def test_multitask_alternating_steps_match_the_cpu_oracle(dev):
         assert abs(a - b) / abs(b) < 1e-4, (got, ref_losses)
     sd = dec.state_dict()
     for k in ("S_happy_i.weight", "S_fi.weight", "W_c.weight", "C.weight"):
-        d = (sd[k].cpu() - p_ref[k]).abs().max().item()
-        assert d <= 1e-4, (k, d)
+        # all but the elements whose gradient is at rounding level moved as on the CPU (those end up
+        # to 2 * lr per step away: Adam's first steps are sign-like)
+        d = (sd[k].cpu() - p_ref[k]).abs()
+        assert (d > 2e-5).float().mean().item() < 2e-2, k
+        assert d.max().item() <= 2.01 * (2e-4 * 2 + 5e-4), (k, d.max().item())
     assert (sd["S_happy_i.weight"].cpu() - p["S_happy_i.weight"]).abs().max().item() > 1e-4   # it moved
     assert torch.equal(sd["S_sad_i.weight"].cpu(), p["S_sad_i.weight"])                        # it did not
 
@@ -416,6 +435,10 @@ def test_pipelined_loop_keeps_each_batch_with_its_captions(dev):
     loader = []
     for s in range(n):
         imgs, caps, lens = synthetic.make_batch(B, V, seed=100 + s, min_len=5, max_len=9)
+        # batch s draws its words from its own 25-id band; with the output bias ramp below its loss
+        # sits ~0.5 away from its neighbours' -- a step fed another batch's tokens cannot hide
+        band = (caps >= 4)
+        caps = torch.where(band, 4 + 25 * s + (caps - 4) % 25, caps)
         loader.append((imgs, caps, lens, None))
     random.seed(21)
     tfs = [[random.random() < 0.8 for _ in range(9)] for _ in range(n)]
@@ -424,10 +447,12 @@ def test_pipelined_loop_keeps_each_batch_with_its_captions(dev):
         enc = EncoderCNN(300)
         enc.load_state_dict(_encoder_state(enc))
         dec = DecoderFactoredLSTM(300, 64, 64, V, 1, dropout=0.0)
-        dec.load_state_dict(synthetic.decoder_state(dec.state_dict(), seed=4))
+        sd = synthetic.decoder_state(dec.state_dict(), seed=4)
+        sd["C.bias"] = -0.02 * torch.arange(V, dtype=torch.float32)
+        dec.load_state_dict(sd)
         enc.to(dev).train()
         dec.to(dev).train()
-        return enc, dec, Adam(list(dec.parameters()) + list(enc.linear.parameters()) + list(enc.bn.parameters()), lr=1e-3)
+        return enc, dec, Adam(list(dec.parameters()) + list(enc.linear.parameters()) + list(enc.bn.parameters()), lr=1e-4)
 
     enc, dec, opt = build()
     seq = [float(train_step(enc, dec, opt, CrossEntropyLoss(), i.to(dev), c.to(dev), l, 0.5,
@@ -440,6 +465,6 @@ def test_pipelined_loop_keeps_each_batch_with_its_captions(dev):
     torch.cuda.synchronize()
     got = [float(l.item()) for l in losses]
     print("loop sequential", seq, "pipelined", got)
-    assert len(set(round(x, 4) for x in seq)) == n        # the batches are distinguishable
+    assert min(abs(seq[i] - seq[j]) for i in range(n) for j in range(i)) > 0.1     # distinguishable
     for a, b in zip(got, seq):
-        assert abs(a - b) / abs(b) < 2e-6
+        assert abs(a - b) / abs(b) < 2e-5
