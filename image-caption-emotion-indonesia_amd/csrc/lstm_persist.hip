@@ -65,7 +65,7 @@ struct PersistArgs {
   float* hiddens;
   int* ctl;
   int* err_flag;
-  unsigned long long* stamps;   // diagnostics only (tools/step_phases.py), else nullptr
+  unsigned long long* stamps;   // diagnostics only (tools/persist_phases.py), else nullptr
   int t0, t1, cfg, seg;
   int off[kMaxSteps + 1];
   short b[kMaxSteps];
@@ -88,8 +88,92 @@ __device__ __forceinline__ void ld16_sc1(pf32x4& dst, const float* p) {
 }
 __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+// out[r] = rows 4r..4r+3 of h . W^T over this wave's 128 k, for r < NRB.
+// v_mfma_f32_4x4x1 needs ~50 cycles before its result can be accumulated into again
+// (tools/native/mfma4x4_rate.hip: 48 / 28 / 16 / 12 cycles per instruction with 1 / 2 / 4 / 8
+// independent accumulators), so every row block accumulates into NS independent chains that are
+// summed at the end: 8 chains for one live row block, 4 for two or three, 2 for four.
+// (ABID must be an immediate: one macro instance per broadcast block.)
+constexpr int persist_chains(int nrb) { return nrb == 1 ? 8 : nrb == 4 ? 2 : 4; }
+constexpr int persist_max_chains(int rb) { return rb == 1 ? 8 : rb == 2 ? 8 : 12; }
+
+template <int RB, int NRB, int Q>
+__device__ __forceinline__ void persist_mfma_half(const pf32x4 (&av)[RB][2], const pf32x4 (&wq)[32],
+                                                  pf32x4 (&acc)[persist_max_chains(RB)]) {
+  constexpr int NS = persist_chains(NRB);
+#define CAPNET_PBLK(B2)                                                                             \
+  _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                     \
+  _Pragma("unroll") for (int r = 0; r < NRB; ++r)                                                   \
+      acc[r * NS + ((e + 4 * (B2 & 1)) % NS)] = __builtin_amdgcn_mfma_f32_4x4x1f32(                 \
+          av[r][Q][e], wq[16 * Q + B2][e], acc[r * NS + ((e + 4 * (B2 & 1)) % NS)], 4, B2, 0);
+  CAPNET_PBLK(0) CAPNET_PBLK(1) CAPNET_PBLK(2) CAPNET_PBLK(3)
+  CAPNET_PBLK(4) CAPNET_PBLK(5) CAPNET_PBLK(6) CAPNET_PBLK(7)
+  CAPNET_PBLK(8) CAPNET_PBLK(9) CAPNET_PBLK(10) CAPNET_PBLK(11)
+  CAPNET_PBLK(12) CAPNET_PBLK(13) CAPNET_PBLK(14) CAPNET_PBLK(15)
+#undef CAPNET_PBLK
+}
+
+// the k half Q = 0 runs while the loads of half Q = 1 are still in flight (vmcnt retires in issue
+// order: all but the RB youngest loads done = half 0 has landed)
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+  static_assert(N >= 0 && N <= 13, "vmcnt immediate");
+  if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+  if (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  if (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  if (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  if (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  if (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  if (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+  if (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  if (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+  if (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  if (N == 11) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+  if (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  if (N == 13) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+}
+
+// The k half Q = 0 runs while the loads of half Q = 1 are still in flight. vmcnt retires in issue
+// order; YOUNG = operations this wave issued after the h loads (pre-activation loads, deferred stores).
+template <int RB, int NRB, int YOUNG>
+__device__ __forceinline__ void persist_mfma(const pf32x4 (&av)[RB][2], const pf32x4 (&wq)[32],
+                                             pf32x4 (&out)[RB]) {
+  constexpr int NS = persist_chains(NRB);
+  pf32x4 acc[persist_max_chains(RB)];
+#pragma unroll
+  for (int c = 0; c < NRB * NS; ++c) acc[c] = pf32x4{0.f, 0.f, 0.f, 0.f};
+  wait_vmcnt<RB + YOUNG>();
+  __builtin_amdgcn_sched_barrier(0);
+  persist_mfma_half<RB, NRB, 0>(av, wq, acc);
+  __builtin_amdgcn_sched_barrier(0);
+  wait_vmcnt<YOUNG>();
+  __builtin_amdgcn_sched_barrier(0);
+  persist_mfma_half<RB, NRB, 1>(av, wq, acc);
+#pragma unroll
+  for (int r = 0; r < RB; ++r) {
+    if (r < NRB) {
+      pf32x4 s = acc[r * NS];
+#pragma unroll
+      for (int c = 1; c < NS; ++c) s += acc[r * NS + c];
+      out[r] = s;
+    } else {
+      out[r] = pf32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+}
+
+// sigmoid / tanh on v_exp_f32 + v_rcp_f32 (about 1 ulp each): the pointwise part sits on the
+// step's critical path between the last MFMA and the store of h
+__device__ __forceinline__ float fast_sigm(float x) {
+  return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float fast_tanh(float x) {
+  return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
+}
+
 // RB: 4-row blocks per shard (rows per shard <= 4 RB)
-template <int RB>
+// DIAG: s_memtime stamps (tools/persist_phases.py); the product instantiation has none
+template <int RB, bool DIAG>
 __global__ __launch_bounds__(256) void lstm_persist_kernel(const PersistArgs a) {
   constexpr int H = kPH;
   __shared__ __attribute__((aligned(16))) float red[2][4][4 * RB][64];
@@ -139,6 +223,7 @@ __global__ __launch_bounds__(256) void lstm_persist_kernel(const PersistArgs a) 
   __syncthreads();
   if (s_abort) return;
   const bool local = s_local != 0;
+  if (tid == 0 && slot == 0) ctl[kCtlAbort + 1 + shard] = local ? 1 : 2;   // diagnostics: mode taken
 
   // ---- epilogue role: thread e -> (row m of the shard, unit u of the slot)
   const int em = tid >> 4, eu = tid & 15;
@@ -150,22 +235,50 @@ __global__ __launch_bounds__(256) void lstm_persist_kernel(const PersistArgs a) 
   const int* my_flags = ctl + kCtlFlags + (shard * kPSlots + 8 * wave) * 4 + (lane & 31);
   int* out_flag = ctl + kCtlFlags + (shard * kPSlots + slot) * 4 + wave;
 
-  for (int t = a.t0; t < a.t1; ++t) {
-    const int bt = a.b[t];
-    const int rows_t = (bt - shard + 7) >> 3;        // rows of this shard still alive
-    const int ro = a.off[t];
-    const bool evalid = em < rows_t;                  // (rows_t <= 4 RB by construction)
-    const long erow = ro + (evalid ? grow : shard);
-    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0;
-    if (a.stamps) ts0 = __builtin_amdgcn_s_memtime();
-    // pre-activations of this step (written by the input-chain GEMMs before this launch)
-    float pre[4];
-    const int gsel[4] = {gi, gf, go, gg};
-#pragma unroll
-    for (int g = 0; g < 4; ++g) pre[g] = a.G[erow * (4 * H) + (long)gsel[g] * H + u0 + eu];
-    __builtin_amdgcn_sched_barrier(0);
+  // step metadata in two VGPRs (lane l: steps l and l + 64), read per step with v_readlane: a
+  // scalar load from the argument segment per step would be a dependent fetch on the critical path
+  unsigned long long rt0 = 0, mt0 = 0;
+  if (DIAG) { rt0 = __builtin_amdgcn_s_memrealtime(); mt0 = __builtin_amdgcn_s_memtime(); }
+  int v_off0 = a.off[lane], v_off1 = a.off[64 + lane < kMaxSteps ? 64 + lane : kMaxSteps];
+  int v_b0 = a.b[lane], v_b1 = a.b[64 + lane < kMaxSteps ? 64 + lane : kMaxSteps - 1];
+  // complete the four loads HERE and hide their origin: otherwise hipcc's waitcnt pass treats them
+  // as possibly pending around the loop's back edge and drains vmcnt(0) in front of every readlane
+  wait_vm0();
+  asm volatile("" : "+v"(v_off0), "+v"(v_off1), "+v"(v_b0), "+v"(v_b1));
+  auto off_of = [&](int t) { return t < 64 ? __builtin_amdgcn_readlane(v_off0, t) : __builtin_amdgcn_readlane(v_off1, t - 64); };
+  auto b_of = [&](int t) { return t < 64 ? __builtin_amdgcn_readlane(v_b0, t) : __builtin_amdgcn_readlane(v_b1, t - 64); };
+  // Every vector-memory instruction of the loop is inline asm with hand-counted vmcnt (in issue
+  // order per step: [5 deferred stores of the previous step] 2 RB h loads, 4 pre-activation loads,
+  // the h store). hipcc's own loads in a loop make its waitcnt pass drain vmcnt(0) at points it
+  // cannot see our in-flight operations from; only the poll is a compiler-visible (atomic) load,
+  // and at that point nothing but the previous flag store is in flight.
+  pf32x4 dgate = {0.f, 0.f, 0.f, 0.f};    // activated gates + c of the previous step, stored one
+  float dcell = 0.f;                       // step late, behind the next step's h loads
+  long drow = -1;
 
-    if (t > 0) {
+  auto st32 = [](float* p, float v) { asm volatile("global_store_dword %0, %1, off" :: "v"(p), "v"(v) : "memory"); };
+  auto flush_deferred = [&]() {
+    if (drow >= 0) {
+      float* gp = a.G + drow * (4 * H) + u0 + eu;
+      st32(gp + (long)gi * H, dgate[0]);
+      st32(gp + (long)gf * H, dgate[1]);
+      st32(gp + (long)go * H, dgate[2]);
+      st32(gp + (long)gg * H, dgate[3]);
+      st32(a.Cst + drow * H + u0 + eu, dcell);
+    }
+  };
+
+  for (int t = a.t0; t < a.t1; ++t) {
+    unsigned long long ts[6] = {0, 0, 0, 0, 0, 0};
+    if (DIAG) ts[0] = __builtin_amdgcn_s_memtime();
+    const int bt = b_of(t);
+    const int rows_t = (bt - shard + 7) >> 3;        // rows of this shard still alive
+    const int ro = off_of(t);
+    const bool evalid = em < rows_t;                  // (rows_t <= 4 RB by construction)
+    const long erow = ro + (evalid ? grow : 0);       // row `ro` always exists (b_t >= 1)
+    const bool product = t > 0;
+    pf32x4 av[RB][2];
+    if (product) {
       // ---- wait for h_{t-1}: produced inside this launch for t > t0, by earlier launches at t0
       if (t > a.t0) {
         int spins = 0;
@@ -181,81 +294,108 @@ __global__ __launch_bounds__(256) void lstm_persist_kernel(const PersistArgs a) 
           }
         }
       }
-      if (a.stamps) ts1 = __builtin_amdgcn_s_memtime();
+      if (DIAG) ts[1] = __builtin_amdgcn_s_memtime();
       // ---- A operands: lane (bl, li) of row block r holds h[row 4 r + li][128 wave + 64 Q + 4 bl + e]
-      const int rp = a.off[t - 1];
-      pf32x4 av[RB][2];
+      const int rp = off_of(t - 1);
+      const float* hrow[RB];
 #pragma unroll
       for (int r = 0; r < RB; ++r) {
         const int m = 4 * r + li;
-        const int g = 8 * (m < rows_t ? m : 0) + shard;
-        const float* hp = a.hiddens + (long)(rp + g) * H + 128 * wave + 4 * bl;
-        ld16_sc1(av[r][0], hp);
-        ld16_sc1(av[r][1], hp + 64);
+        const int g = m < rows_t ? 8 * m + shard : 0;   // clamped rows only feed ignored outputs
+        hrow[r] = a.hiddens + (long)(rp + g) * H + 128 * wave + 4 * bl;
       }
-      wait_vm0();
-      __builtin_amdgcn_sched_barrier(0);
-      // ---- 128 k x RB row blocks: outer products, two accumulator sets per row block
-      pf32x4 acc[RB][2];
 #pragma unroll
-      for (int r = 0; r < RB; ++r) acc[r][0] = acc[r][1] = pf32x4{0.f, 0.f, 0.f, 0.f};
-      // (ABID must be an immediate: one macro instance per broadcast block)
-#define CAPNET_PBLK(B2)                                                                             \
-  _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                     \
-  _Pragma("unroll") for (int r = 0; r < RB; ++r)                                                    \
-    if (4 * r < rows_t)                                                                             \
-      acc[r][e & 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[r][Q][e], wq[16 * Q + B2][e],           \
-                                                         acc[r][e & 1], 4, B2, 0);
+      for (int r = 0; r < RB; ++r) ld16_sc1(av[r][0], hrow[r]);
 #pragma unroll
-      for (int Q = 0; Q < 2; ++Q) {
-        CAPNET_PBLK(0) CAPNET_PBLK(1) CAPNET_PBLK(2) CAPNET_PBLK(3)
-        CAPNET_PBLK(4) CAPNET_PBLK(5) CAPNET_PBLK(6) CAPNET_PBLK(7)
-        CAPNET_PBLK(8) CAPNET_PBLK(9) CAPNET_PBLK(10) CAPNET_PBLK(11)
-        CAPNET_PBLK(12) CAPNET_PBLK(13) CAPNET_PBLK(14) CAPNET_PBLK(15)
+      for (int r = 0; r < RB; ++r) ld16_sc1(av[r][1], hrow[r] + 64);
+    }
+    // ---- pre-activations of this step (written by the input-chain GEMMs before this launch):
+    // behind the h loads, they have the whole product to arrive
+    pf32x4 pre;
+    {
+      const float* gp = a.G + erow * (4 * H) + u0 + eu;
+      asm volatile("global_load_dword %0, %1, off" : "=v"(pre[0]) : "v"(gp + (long)gi * H) : "memory");
+      asm volatile("global_load_dword %0, %1, off" : "=v"(pre[1]) : "v"(gp + (long)gf * H) : "memory");
+      asm volatile("global_load_dword %0, %1, off" : "=v"(pre[2]) : "v"(gp + (long)go * H) : "memory");
+      asm volatile("global_load_dword %0, %1, off" : "=v"(pre[3]) : "v"(gp + (long)gg * H) : "memory");
+    }
+    // ---- gates / cell state of the previous step: off the critical path, behind this step's loads
+    const bool had_deferred = drow >= 0;
+    flush_deferred();
+    drow = -1;
+    __builtin_amdgcn_sched_barrier(0);
+
+    if (product) {
+      // Younger than the first k half of the h loads: RB loads, 4 loads and, if this wave executed
+      // them, the 5 deferred stores (the wave executes them iff one of its lanes had a live row; if
+      // the count assumed here were too low the wait would only be longer, never shorter).
+      pf32x4 sum[RB];
+      const int nrb = (rows_t + 3) >> 2;
+      const bool stores_in_flight = __any(had_deferred);
+      if (stores_in_flight) {
+        if (RB >= 4 && nrb >= 4) persist_mfma<RB, (RB >= 4 ? 4 : RB), 9>(av, wq, sum);
+        else if (RB >= 3 && nrb == 3) persist_mfma<RB, (RB >= 3 ? 3 : RB), 9>(av, wq, sum);
+        else if (RB >= 2 && nrb == 2) persist_mfma<RB, (RB >= 2 ? 2 : RB), 9>(av, wq, sum);
+        else persist_mfma<RB, 1, 9>(av, wq, sum);
+      } else {
+        if (RB >= 4 && nrb >= 4) persist_mfma<RB, (RB >= 4 ? 4 : RB), 4>(av, wq, sum);
+        else if (RB >= 3 && nrb == 3) persist_mfma<RB, (RB >= 3 ? 3 : RB), 4>(av, wq, sum);
+        else if (RB >= 2 && nrb == 2) persist_mfma<RB, (RB >= 2 ? 2 : RB), 4>(av, wq, sum);
+        else persist_mfma<RB, 1, 4>(av, wq, sum);
       }
-#undef CAPNET_PBLK
-      if (a.stamps) ts2 = __builtin_amdgcn_s_memtime();
+      if (DIAG) ts[2] = __builtin_amdgcn_s_memtime();
       // D: register i, lane 4 bl + j = out[row 4 r + i][unit bl, gate j]
 #pragma unroll
       for (int r = 0; r < RB; ++r)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) red[t & 1][wave][4 * r + i][lane] = acc[r][0][i] + acc[r][1][i];
+        for (int i = 0; i < 4; ++i) red[t & 1][wave][4 * r + i][lane] = sum[r][i];
+    }
+    wait_vm0();     // pre-activations (and the deferred stores, long gone)
+    __builtin_amdgcn_sched_barrier(0);
+    if (product) {
       __syncthreads();
       if (evalid) {
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-          const pf32x4 p = *reinterpret_cast<const pf32x4*>(&red[t & 1][w][em][4 * eu]);
-          pre[0] += p[0]; pre[1] += p[1]; pre[2] += p[2]; pre[3] += p[3];
-        }
+        for (int w = 0; w < 4; ++w) pre += *reinterpret_cast<const pf32x4*>(&red[t & 1][w][em][4 * eu]);
       }
     }
-    if (a.stamps) ts3 = __builtin_amdgcn_s_memtime();
+    if (DIAG) ts[3] = __builtin_amdgcn_s_memtime();
     if (evalid) {
-      const float i = p_sigm(pre[0]), f = p_sigm(pre[1]), og = p_sigm(pre[2]), gt = tanhf(pre[3]);
+      const float i = fast_sigm(pre[0]), f = fast_sigm(pre[1]), og = fast_sigm(pre[2]), gt = fast_tanh(pre[3]);
       c_reg = f * c_reg + i * gt;
-      const float h = tanh_out ? og * tanhf(c_reg) : og * c_reg;
+      const float h = tanh_out ? og * fast_tanh(c_reg) : og * c_reg;
       float* hp = a.hiddens + erow * H + u0 + eu;
-      if (local) *hp = h; else st_sc1_f32(hp, h);       // first: the flag waits for this one only
-      a.G[erow * (4 * H) + (long)gi * H + u0 + eu] = i;
-      a.G[erow * (4 * H) + (long)gf * H + u0 + eu] = f;
-      a.G[erow * (4 * H) + (long)go * H + u0 + eu] = og;
-      a.G[erow * (4 * H) + (long)gg * H + u0 + eu] = gt;
-      a.Cst[erow * H + u0 + eu] = c_reg;
+      if (local) st32(hp, h);
+      else asm volatile("global_store_dword %0, %1, off sc1" :: "v"(hp), "v"(h) : "memory");
+      dgate = pf32x4{i, f, og, gt};
+      dcell = c_reg;
+      drow = erow;
     }
     if (t + 1 < a.t1) {
-      // every wave signals for its own stores: the h store is the oldest of (at most) six
-      if (evalid) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-      if (__any(evalid) == 0) { /* no store of this wave to wait for */ }
-      else wait_vm0();   // lanes of a wave retire together: cover the partially valid wave too
+      // every wave signals for its own stores: the h store is the only operation in flight
+      wait_vm0();
+      if (DIAG) ts[4] = __builtin_amdgcn_s_memtime();
       if (lane == 0) {
-        if (local) *reinterpret_cast<volatile int*>(out_flag) = t + 1;
-        else st_sc1_i32(out_flag, t + 1);
+        // (a C++ volatile store becomes flat_store sc0 sc1 + vmcnt(0): write-through and a drain)
+        if (local) asm volatile("global_store_dword %0, %1, off" :: "v"(out_flag), "v"(t + 1) : "memory");
+        else asm volatile("global_store_dword %0, %1, off sc1" :: "v"(out_flag), "v"(t + 1) : "memory");
       }
     }
-    if (a.stamps && tid == 0) {
-      unsigned long long* st = a.stamps + ((long)(t - a.t0) * kPGrid + blockIdx.x) * 5;
-      st[0] = ts0; st[1] = ts1; st[2] = ts2; st[3] = ts3; st[4] = __builtin_amdgcn_s_memtime();
+    if (DIAG) {
+      ts[5] = __builtin_amdgcn_s_memtime();
+      if (tid == 0) {
+        unsigned long long* st = a.stamps + ((long)(t - a.t0) * kPGrid + blockIdx.x) * 8;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) st[k] = ts[k];
+      }
+      wait_vm0();
     }
+  }
+  flush_deferred();
+  if (DIAG && tid == 0) {     // shader clock over the launch: d(s_memtime) / d(s_memrealtime) x 100 MHz
+    unsigned long long* st = a.stamps + (long)(a.t1 - a.t0) * kPGrid * 8 + blockIdx.x * 2;
+    st[0] = __builtin_amdgcn_s_memtime() - mt0;
+    st[1] = __builtin_amdgcn_s_memrealtime() - rt0;
   }
 }
 
@@ -292,7 +432,7 @@ static int persist_device_ok() {
     (void)hipGetLastError();
     return cached = 0;
   }
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)lstm_persist_kernel<4>, 256,
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)lstm_persist_kernel<4, false>, 256,
                                                    0) != hipSuccess) {
     (void)hipGetLastError();
     return cached = 0;
@@ -338,12 +478,18 @@ int lstm_persist_run(const float* Wp, float* G, float* Cst, float* hiddens, cons
   for (int t = 0; t < t1; ++t) a.b[t] = (short)batch_sizes[t];
   const int rows0 = (batch_sizes[t0] + 7) / 8;        // rows of shard 0 at the first step
   const int rb = (rows0 + 3) / 4;
+#define CAPNET_PLAUNCH(RBV)                                                                          \
+  do {                                                                                              \
+    if (stamps) hipLaunchKernelGGL((lstm_persist_kernel<RBV, true>), dim3(kPGrid), dim3(256), 0, stream, a); \
+    else hipLaunchKernelGGL((lstm_persist_kernel<RBV, false>), dim3(kPGrid), dim3(256), 0, stream, a);       \
+  } while (0)
   switch (rb) {
-    case 1: hipLaunchKernelGGL(lstm_persist_kernel<1>, dim3(kPGrid), dim3(256), 0, stream, a); break;
-    case 2: hipLaunchKernelGGL(lstm_persist_kernel<2>, dim3(kPGrid), dim3(256), 0, stream, a); break;
-    case 3: hipLaunchKernelGGL(lstm_persist_kernel<3>, dim3(kPGrid), dim3(256), 0, stream, a); break;
-    default: hipLaunchKernelGGL(lstm_persist_kernel<4>, dim3(kPGrid), dim3(256), 0, stream, a); break;
+    case 1: CAPNET_PLAUNCH(1); break;
+    case 2: CAPNET_PLAUNCH(2); break;
+    case 3: CAPNET_PLAUNCH(3); break;
+    default: CAPNET_PLAUNCH(4); break;
   }
+#undef CAPNET_PLAUNCH
   CAPNET_LAUNCH_CHECK();
   return kOk;
 }

@@ -328,7 +328,7 @@ int capnet_lstm_step_fused_supported(int b, int H);
  *   ctl          capnet_lstm_persist_ctl_ints() ints, zeroed once before the first segment of a
  *                forward pass; segment = 1, 2, ... numbers the launches that share it
  *   err_flag     bit 2 is set if a bounded wait expired (the results are then invalid)
- *   stamps       NULL, or [t1-t0][256][5] uint64 s_memtime readings (diagnostics) */
+ *   stamps       NULL, or ([t1-t0][256][8] + [256][2]) uint64 s_memtime readings (diagnostic instantiation) */
 int capnet_lstm_persist_supported(int b, int H);
 size_t capnet_lstm_persist_w_floats(void);
 size_t capnet_lstm_persist_ctl_ints(void);

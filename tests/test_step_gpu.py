@@ -239,28 +239,39 @@ def _att_modules(V, dev):
     return enc, est, dec, p
 
 
-@pytest.mark.parametrize("ratio", [1.0, 0.8])
-def test_attention_train_steps_match_the_cpu_oracle(dev, ratio):
+@pytest.mark.parametrize("trunk,steps,tol", [("oracle", 2, 1e-4), ("shared", 4, 2e-5)])
+def test_attention_train_steps_match_the_cpu_oracle(dev, trunk, steps, tol):
     """configs[3] per GPU: 12 images, spatial ResNet-152 features [12, 14, 14, 2048], additive
     attention decoder, V = 8192; inputs captions[:, :-1], targets captions[:, 1:], lengths - 1, loss
-    = NLL + ((1 - sum_t alpha)^2).mean() (train_multitask_att.py:402-411); two steps, so the second
-    loss checks backward + clamp + Adam of every attention / init / f_beta / factored parameter."""
+    = NLL + ((1 - sum_t alpha)^2).mean() (train_multitask_att.py:402-411), Adam lr 2e-4 (:655).
+    trunk="oracle": the CPU side runs its own ResNet-152 (EncoderCNNAttRef): the whole step, two
+        losses within 1e-4 (the second one checks backward + clamp + Adam of every attention / init /
+        f_beta / factored parameter). Not more steps: at 12 images the train-mode BatchNorm chain
+        leaves the two fp32 trunks ~1e-4 apart, and the loss, blind to the features at step 0
+        (6e-6), follows them more closely with every update (2e-5 at step 1, 2e-4 at step 2; the
+        decoder itself is exact: tools/att_grad_check.py, same features -> loss 1e-8, grads 2e-6).
+    trunk="shared": the CPU decoder is fed the GPU trunk's features, which isolates
+        train_step_att + decoder + optimiser over four steps, held to 2e-5."""
     from oracle.resnet152_ref import EncoderCNNAttRef
     from capnet.train import train_step_att
-    # lr = the reference's 2e-4 (train_multitask_att.py:655). Adam's first steps move EVERY element
-    # by ~lr whatever its gradient's size, so elements whose gradient is at rounding level take
-    # opposite signs on the two sides; at lr 2e-3 (26 M parameters, displacement norm 10) that
-    # second-order effect alone was 6e-4 of the second loss, at 2e-4 it is 100x smaller.
-    V, B, steps, lr, clip = 8192, 12, 3, 2e-4, 0.5
+    V, B, lr, clip = 8192, 12, 2e-4, 0.5
     torch.set_num_threads(16)
     enc, est, dec, p = _att_modules(V, dev)
     imgs, captions, lengths = synthetic.make_batch(B, V, seed=0)
     random.seed(11)
-    tfs = [[random.random() < ratio for _ in range(max(lengths))] for _ in range(steps)]
+    tfs = [[random.random() < 0.8 for _ in range(max(lengths))] for _ in range(steps)]
+    enc.to(dev).train()
+    dec.to(dev).train()
+    imgs_d, caps_d = imgs.to(dev), captions.to(dev)
 
-    ref_enc = EncoderCNNAttRef(14)
-    ref_enc.load_state_dict({k: v.clone() for k, v in est.items()})
-    ref_enc.train()
+    if trunk == "oracle":
+        ref_enc = EncoderCNNAttRef(14)
+        ref_enc.load_state_dict({k: v.clone() for k, v in est.items()})
+        ref_enc.train()
+        feats_of = lambda: ref_enc(imgs)
+    else:
+        shared = enc(imgs_d).cpu()       # train-mode batch statistics: the same features at every step
+        feats_of = lambda: shared
     p_ref = {k: v.clone() for k, v in p.items()}
     opt_ref = S.AdamRef(lr=lr)
     lens1 = [l - 1 for l in lengths]
@@ -268,8 +279,7 @@ def test_attention_train_steps_match_the_cpu_oracle(dev, ratio):
     ref_losses = []
     for it in range(steps):
         leaves = {k: v.detach().clone().requires_grad_(True) for k, v in p_ref.items()}
-        feats = ref_enc(imgs)
-        logits, alphas = D.factored_att_forward(leaves, captions[:, :-1], lens1, feats, tfs[it], "factual")
+        logits, alphas = D.factored_att_forward(leaves, captions[:, :-1], lens1, feats_of(), tfs[it], "factual")
         loss = D.att_loss(logits, alphas, targets, 1.0)
         loss.backward()
         grads = {k: v.grad for k, v in leaves.items()}
@@ -278,20 +288,16 @@ def test_attention_train_steps_match_the_cpu_oracle(dev, ratio):
             opt_ref.step(p_ref, grads)
         ref_losses.append(float(loss.detach()))
 
-    enc.to(dev).train()
-    dec.to(dev).train()
     opt = Adam(list(dec.parameters()), lr=lr)
-    imgs_d, caps_d = imgs.to(dev), captions.to(dev)
     got = [float(train_step_att(enc, dec, opt, CrossEntropyLoss(), imgs_d, caps_d, lengths, clip,
                                 tf_mask=tfs[it]).item()) for it in range(steps)]
     capnet.ops.check_device_errors()
-    print("att tf", ratio, "oracle", ref_losses, "gpu", got)
+    print("att", trunk, "oracle", ref_losses, "gpu", got)
     for a, b in zip(got, ref_losses):
-        assert abs(a - b) / abs(b) < 1e-4, (got, ref_losses)
-    assert ref_losses[-1] != ref_losses[0]
-    # one updated parameter of each family after the three steps: it moved, and all but the
-    # rounding-level elements moved the same way (an element whose gradient sign is noise ends up
-    # to 2 * lr * steps away)
+        assert abs(a - b) / abs(b) < tol, (got, ref_losses)
+    assert ref_losses[-1] < ref_losses[0] - 0.5
+    # one updated parameter of each family: it moved, and all but the rounding-level elements moved
+    # the same way (an element whose gradient sign is noise ends up to 2 * lr * steps away)
     sd = dec.state_dict()
     for k in ("attention.encoder_att.weight", "attention.full_att.weight", "f_beta.weight", "init_h.weight",
               "init_c.bias", "V_i.weight", "S_fo.weight", "U_c.weight", "W_f.weight", "C.weight"):
