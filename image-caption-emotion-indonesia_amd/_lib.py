@@ -57,6 +57,11 @@ SIGNATURES = {
     "capnet_conv_wino_tiles_m": (_i, [_i, _i, _i]),
     "capnet_conv2d_fwd_wino": (_i, [_vp, _l, _l, _l, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i,
                                     _vp, _vp, _i, _vp]),
+    "capnet_sgemm_nt_dma_eligible": (_i, [_i, _i, _i, _vp, _l, _vp, _l, _vp, _l]),
+    "capnet_sgemm_nt_dma": (_i, [_i, _i, _i, _vp, _l, _vp, _vp, _vp, _vp]),
+    "capnet_conv1x1_tiles_m": (_i, [_l]),
+    "capnet_conv1x1_fwd_dma": (_i, [_vp, _l, _l, _l, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp,
+                                    _vp, _i, _vp]),
     "capnet_conv_kmajor_slab_floats": (_sz, [_i, _i, _i, _i]),
     "capnet_conv_kmajor_plan": (None, [_i, _i, _i, _i, _ip]),
     "capnet_conv_kmajor_tiles_m": (_i, [_i, _i, _i, _i]),

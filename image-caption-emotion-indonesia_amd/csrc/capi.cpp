@@ -28,6 +28,24 @@ int capnet_sgemm(int transA, int transB, int M, int N, int K, const float* A, lo
                strideA, strideB, strideC, strideBias, force_tile, S(stream));
 }
 
+int capnet_sgemm_nt_dma_eligible(int M, int N, int K, const float* A, long lda, const float* B,
+                                 long ldb, const float* C, long ldc) {
+  return sgemm_nt_dma_eligible(M, N, K, A, lda, B, ldb, C, ldc) ? 1 : 0;
+}
+int capnet_sgemm_nt_dma(int M, int N, int K, const float* A, long lda, const float* B, float* C,
+                        const float* bias, capnet_stream_t stream) {
+  CAPNET_REQUIRE(A && B && C, "sgemm_nt_dma: null operand");
+  return sgemm_nt_dma(M, N, K, A, lda, B, C, bias, S(stream));
+}
+int capnet_conv1x1_tiles_m(long M) { return conv1x1_tiles_m(M); }
+int capnet_conv1x1_fwd_dma(const float* x, long sxb, long sxh, long sxw, const float* w_oi, float* y,
+                           float* part_sum, float* part_sq, int B, int H, int W, int Cin, int Cout,
+                           int stride, const float* out_scale, const float* out_shift, const float* res,
+                           int relu_out, capnet_stream_t stream) {
+  return conv1x1_fwd_dma(x, sxb, sxh, sxw, w_oi, y, part_sum, part_sq, B, H, W, Cin, Cout, stride,
+                         S(stream), out_scale, out_shift, res, relu_out);
+}
+
 int capnet_sgemm_splitk(int transA, int transB, int M, int N, int K, const float* A, long lda,
                         const float* B, long ldb, float* C, long ldc, const float* bias,
                         int accumulate, float* workspace, size_t workspace_floats,

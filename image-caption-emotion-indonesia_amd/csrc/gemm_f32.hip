@@ -138,6 +138,11 @@ int sgemm(bool ta, bool tb, int M, int N, int K, const float* A, long lda, const
                  "sgemm: leading dimension too small (lda=%ld ldb=%ld ldc=%ld M=%d N=%d K=%d)",
                  lda, ldb, ldc, M, N, K);
   CAPNET_REQUIRE(batch <= 65535, "sgemm: batch too large");
+  // y = x . W^T + b with dense K-contiguous operands and enough rows for 128-row tiles: the LDS-DMA
+  // core (gemm_dma.hip) -- the vocabulary projection, encoder_att over all pixels, ...
+  if (!ta && tb && batch == 1 && !accumulate && force_tile == 0 && M > 64 &&
+      (long)cdiv(M, 128) * (N / 64) >= 64 && sgemm_nt_dma_eligible(M, N, K, A, lda, B, ldb, C, ldc))
+    return sgemm_nt_dma(M, N, K, A, lda, B, C, bias, stream);
   GemmArgs g;
   g.A = A; g.B = B; g.C = C; g.bias = bias;
   g.M = M; g.N = N; g.K = K;

@@ -50,6 +50,19 @@ int conv2d_fwd_wino(const float* x, long sxb, long sxh, long sxw, const float* w
                     const float* out_scale = nullptr, const float* out_shift = nullptr,
                     int relu_out = 0);
 
+// gemm_dma.hip: C = A . B^T with both operands K-contiguous, LDS-DMA staging (1x1 convs, vocabulary projection)
+bool sgemm_nt_dma_eligible(int M, int N, int K, const float* A, long lda, const float* B, long ldb,
+                           const float* C, long ldc);
+int sgemm_nt_dma(int M, int N, int K, const float* A, long lda, const float* B, float* C,
+                 const float* bias, hipStream_t stream);
+bool conv1x1_dma_eligible(const float* x, long sxb, long sxh, long sxw, long sxc, int Bn, int H, int W,
+                          int Cin, int Cout, int stride);
+int conv1x1_tiles_m(long M);
+int conv1x1_fwd_dma(const float* x, long sxb, long sxh, long sxw, const float* w_oi, float* y,
+                    float* part_sum, float* part_sq, int Bn, int H, int W, int Cin, int Cout, int stride,
+                    hipStream_t stream, const float* out_scale = nullptr, const float* out_shift = nullptr,
+                    const float* res = nullptr, int relu_out = 0);
+
 // bn_pool.hip
 int bn_finalize(const float* part_sum, const float* part_sq, int tiles, int C, long count,
                 const float* gamma, const float* beta, float* running_mean, float* running_var,

@@ -29,6 +29,7 @@ struct TrunkConv {
   int Kw;      // packed K extent (rows of the K-major image / row stride of the row-major one)
   bool kmajor; // weights packed [Kw][Cout] for conv_f32_v2 (else [Cout][Kw] for conv_f32)
   bool wino;   // 3x3 / stride 1 on an even map: Winograd F(2x2,3x3) (conv_wino.hip), its own weight image
+  bool dma1x1; // 1x1 on an activated input (conv1, downsample): LDS-DMA NT core (gemm_dma.hip), weights as [Cout][Cin]
 };
 
 struct Trunk {
@@ -62,7 +63,10 @@ int trunk_create(int B, int H, int W, Trunk** out) {
   // CAPNET_NO_WINOGRAD=1: every 3x3 through the direct implicit-GEMM kernel (A/B runs, diagnostics)
   const char* now = getenv("CAPNET_NO_WINOGRAD");
   const bool use_wino = !(now && now[0] == '1');
-  auto add = [&](int cin, int cout, int k, int stride, int pad, int h, int w) {
+  // CAPNET_NO_DMA1X1=1: conv1 / downsample through the K-major kernel as well (A/B runs)
+  const char* nod = getenv("CAPNET_NO_DMA1X1");
+  const bool use_dma = !(nod && nod[0] == '1');
+  auto add = [&](int cin, int cout, int k, int stride, int pad, int h, int w, bool activated_input = false) {
     TrunkConv c;
     c.Cin = cin; c.Cout = cout; c.k = k; c.stride = stride; c.pad = pad; c.H = h; c.W = w;
     c.OH = (h + 2 * pad - k) / stride + 1;
@@ -70,6 +74,7 @@ int trunk_create(int B, int H, int W, Trunk** out) {
     c.Kw = round_up(k * k * cin, 16);
     c.kmajor = (cin % 16 == 0) && (cout % 64 == 0);
     c.wino = use_wino && c.kmajor && conv_wino_shape_ok(h, w, cin, cout, k, k, stride, pad);
+    c.dma1x1 = use_dma && activated_input && k == 1 && pad == 0 && cin % 16 == 0 && cout % 64 == 0;
     t->convs.push_back(c);
     return c;
   };
@@ -83,14 +88,14 @@ int trunk_create(int B, int H, int W, Trunk** out) {
     for (int b = 0; b < blocks[L]; ++b) {
       const int stride = (b == 0 && L > 0) ? 2 : 1;
       const int p = planes[L];
-      TrunkConv c1 = add(inplanes, p, 1, 1, 0, h, w);
+      TrunkConv c1 = add(inplanes, p, 1, 1, 0, h, w, true);
       TrunkConv c2 = add(p, p, 3, stride, 1, h, w);
       TrunkConv c3 = add(p, p * 4, 1, 1, 0, c2.OH, c2.OW);
       max_y1 = std::max(max_y1, (size_t)c1.OH * c1.OW * c1.Cout);
       max_y2 = std::max(max_y2, (size_t)c2.OH * c2.OW * c2.Cout);
       max_y3 = std::max(max_y3, (size_t)c3.OH * c3.OW * c3.Cout);
       if (b == 0) {
-        TrunkConv d = add(inplanes, p * 4, 1, stride, 0, h, w);
+        TrunkConv d = add(inplanes, p * 4, 1, stride, 0, h, w, true);
         max_d = std::max(max_d, (size_t)d.OH * d.OW * d.Cout);
       }
       h = c2.OH; w = c2.OW;
@@ -116,6 +121,7 @@ int trunk_create(int B, int H, int W, Trunk** out) {
     const int tile = c.kmajor ? conv_v2_auto_tile((int)M, c.Cout, c.Kw) : conv_auto_tile((int)M, c.Cout);
     max_part = std::max(max_part, (size_t)conv_tiles_m((int)M, tile) * c.Cout);
     if (c.wino) max_part = std::max(max_part, (size_t)conv_wino_tiles_m(B, c.H, c.W) * c.Cout);
+    if (c.dma1x1) max_part = std::max(max_part, (size_t)conv1x1_tiles_m(M) * c.Cout);
   }
   t->off_part = take(2 * max_part);
   size_t max_slab = 0;
@@ -196,7 +202,7 @@ int trunk_conv_shape(const Trunk* t, int i, int* cout, int* cin, int* k, int* st
 
 int trunk_conv_kmajor(const Trunk* t, int i) {
   if (i < 0 || i >= (int)t->convs.size()) return 0;
-  return t->convs[i].wino ? 2 : (t->convs[i].kmajor ? 1 : 0);
+  return t->convs[i].dma1x1 ? 3 : t->convs[i].wino ? 2 : (t->convs[i].kmajor ? 1 : 0);
 }
 
 double trunk_conv_flops(const Trunk* t, int i) {
@@ -242,7 +248,7 @@ int conv_bn(const Ctx& c, int i, const float* x, long sxb, long sxh, long sxw, l
   int tile = d.kmajor ? conv_v2_auto_tile((int)M, d.Cout, d.Kw) : conv_auto_tile((int)M, d.Cout);
   if (d.kmajor && !c.t->tail_balance && M >= 5000) tile = 12864;
   // rows of the statistics partials this conv writes
-  const int prows = d.wino ? conv_wino_tiles_m(c.t->B, d.H, d.W) : conv_tiles_m((int)M, tile);
+  const int prows = d.dma1x1 ? conv1x1_tiles_m(M) : d.wino ? conv_wino_tiles_m(c.t->B, d.H, d.W) : conv_tiles_m((int)M, tile);
   float* psum = c.ws + c.t->off_part;
   float* psq = psum + (size_t)prows * d.Cout;
   hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -252,7 +258,12 @@ int conv_bn(const Ctx& c, int i, const float* x, long sxb, long sxh, long sxw, l
     CAPNET_HIP_CHECK(hipEventRecord(e0, c.s));
   }
   int rc;
-  if (d.wino) {
+  if (d.dma1x1) {
+    CAPNET_REQUIRE(!in_scale && conv1x1_dma_eligible(x, sxb, sxh, sxw, sxc, c.t->B, d.H, d.W, d.Cin, d.Cout, d.stride),
+                   "trunk: conv %d planned for the LDS-DMA 1x1 kernel but its operands are not eligible", i);
+    rc = conv1x1_fwd_dma(x, sxb, sxh, sxw, c.w[i], y, c.train ? psum : nullptr, c.train ? psq : nullptr, c.t->B,
+                         d.H, d.W, d.Cin, d.Cout, d.stride, c.s);
+  } else if (d.wino) {
     CAPNET_REQUIRE(sxc == 1, "trunk: conv %d planned for the Winograd kernel needs channel-contiguous input", i);
     rc = conv2d_fwd_wino(x, sxb, sxh, sxw, c.w[i], y, in_scale, in_shift, relu_in, c.train ? psum : nullptr,
                          c.train ? psq : nullptr, c.t->B, d.H, d.W, d.Cin, d.Cout, c.s);
@@ -290,7 +301,7 @@ int conv_folded(const Ctx& c, int i, const float* x, const float* res, int relu,
   const TrunkConv& d = c.t->convs[i];
   const long M = (long)c.t->B * d.OH * d.OW;
   const long sw = d.Cin, sh = (long)d.W * d.Cin, sb = (long)d.H * d.W * d.Cin;
-  CAPNET_REQUIRE(d.kmajor && conv_v2_eligible(x, sb, sh, sw, 1, c.t->B, d.Cin, d.Cout, nullptr, nullptr),
+  CAPNET_REQUIRE(d.dma1x1 || (d.kmajor && conv_v2_eligible(x, sb, sh, sw, 1, c.t->B, d.Cin, d.Cout, nullptr, nullptr)),
                  "trunk: conv %d is not eligible for the folded-BN kernel", i);
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (c.t->timing) {
@@ -299,7 +310,10 @@ int conv_folded(const Ctx& c, int i, const float* x, const float* res, int relu,
     CAPNET_HIP_CHECK(hipEventRecord(e0, c.s));
   }
   int rc;
-  if (d.wino) {
+  if (d.dma1x1) {
+    rc = conv1x1_fwd_dma(x, sb, sh, sw, c.w[i], y, nullptr, nullptr, c.t->B, d.H, d.W, d.Cin, d.Cout, d.stride,
+                         c.s, c.scale(i), c.shift(i), res, relu);
+  } else if (d.wino) {
     CAPNET_REQUIRE(res == nullptr, "trunk: conv %d (Winograd) has no residual input", i);
     rc = conv2d_fwd_wino(x, sb, sh, sw, c.w[i], y, nullptr, nullptr, 0, nullptr, nullptr, c.t->B, d.H, d.W,
                          d.Cin, d.Cout, c.s, c.scale(i), c.shift(i), relu);

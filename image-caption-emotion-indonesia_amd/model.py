@@ -178,8 +178,11 @@ class _TrunkRunner:
                 if tuple(c.weight.shape) != (cout, cin, k, k) or c.stride != stride:
                     raise CapnetError("conv %d: module shape %s does not match the plan" %
                                       (i, tuple(c.weight.shape)))
-                kind = L.capnet_trunk_conv_kmajor(plan["handle"], i)   # 0 rows, 1 K-major, 2 Winograd
-                if kind == 2:
+                # 0 rows, 1 K-major, 2 Winograd, 3 as stored: a 1x1 OIHW weight IS [Cout][Cin]
+                kind = L.capnet_trunk_conv_kmajor(plan["handle"], i)
+                if kind == 3:
+                    packed.append(c.weight.detach().reshape(cout, cin).contiguous())
+                elif kind == 2:
                     packed.append(ops.pack_conv_weight_wino(c.weight.detach()))
                 else:
                     packed.append(ops.pack_conv_weight(c.weight.detach(), kw, kmajor=kind == 1))

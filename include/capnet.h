@@ -140,6 +140,24 @@ int capnet_conv2d_fwd(const float* x, long sxb, long sxh, long sxw, long sxc,
                       const float* in_shift, int relu_in, float* part_sum, float* part_sq, int B,
                       int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
                       int tile, capnet_stream_t stream);
+/* C[M][N] = A[M][K] . B[N][K]^T + bias[N] with both operands staged by LDS-DMA (csrc/gemm_dma.hip):
+ * the vocabulary projection logits = hiddens . C^T + b (stylenet/model.py:193-194) and every
+ * nn.Linear forward whose shape is eligible (N % 64 == 0, K % 32 == 0, B and C dense, 16-B aligned). */
+int capnet_sgemm_nt_dma_eligible(int M, int N, int K, const float* A, long lda, const float* B,
+                                 long ldb, const float* C, long ldc);
+int capnet_sgemm_nt_dma(int M, int N, int K, const float* A, long lda, const float* B, float* C,
+                        const float* bias, capnet_stream_t stream);
+/* 1x1 convolution (any stride) on an NHWC input, weights in their OIHW = [Cout][Cin] layout, same
+ * kernel: the conv1 / conv3 / downsample convolutions of the bottlenecks (torchvision resnet152 via
+ * stylenet/model.py:15-18,24). Cin % 32 == 0, Cout % 64 == 0. Either raw output +
+ * capnet_conv1x1_tiles_m(M) rows of part_sum / part_sq (train-mode BatchNorm statistics of each
+ * 128-row tile), or, with out_scale / out_shift, y = act(conv * out_scale[n] + out_shift[n] + res). */
+int capnet_conv1x1_tiles_m(long M);
+int capnet_conv1x1_fwd_dma(const float* x, long sxb, long sxh, long sxw, const float* w_oi, float* y,
+                           float* part_sum, float* part_sq, int B, int H, int W, int Cin, int Cout,
+                           int stride, const float* out_scale, const float* out_shift, const float* res,
+                           int relu_out, capnet_stream_t stream);
+
 /* the low-VALU kernel used for every trunk convolution with Cin % 16 == 0 and Cout % 64 == 0:
  * NHWC channel-contiguous input, K-major weights, k_rows == KH*KW*Cin */
 int capnet_conv2d_fwd_kmajor(const float* x, long sxb, long sxh, long sxw, const float* w_kmajor,

@@ -467,3 +467,81 @@ def test_sgemm_splitk_matches_fp64(dev, M, N, K, tb):
                                     ptr(bd), 1, None, 0, current_stream()))
     # (one fp32 accumulator over all of K: looser than the chunked sum above)
     assert (Cd2.cpu().double() - ref).abs().max().item() / ref.abs().max().item() < 6e-6
+
+
+# ---- LDS-DMA NT GEMM / 1x1 convolution core (csrc/gemm_dma.hip) --------------------------------
+@pytest.mark.parametrize("M,N,K,bias", [(999, 8192, 512, True),     # the vocabulary projection of configs[1]
+                                        (128, 128, 32, False),       # one tile, one k-tile
+                                        (130, 64, 64, True),         # ragged second M tile, 128x64 tiles
+                                        (257, 192, 96, False),       # 64-wide N tiles, odd k-tile count
+                                        (64, 256, 2048, True), (1, 64, 32, True)])
+def test_sgemm_nt_dma_matches_fp64(dev, M, N, K, bias):
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g)
+    Bw = torch.randn(N, K, generator=g) * 0.1
+    b = torch.randn(N, generator=g) if bias else None
+    ref = A.double() @ Bw.double().t() + (b.double() if bias else 0)
+    Ad, Bd = A.to(dev), Bw.to(dev)
+    bd = b.to(dev) if bias else None
+    out = torch.full((M, N), float("nan"), device=dev)
+    assert lib().capnet_sgemm_nt_dma_eligible(M, N, K, ptr(Ad), K, ptr(Bd), K, ptr(out), N) == 1
+    check(lib().capnet_sgemm_nt_dma(M, N, K, ptr(Ad), K, ptr(Bd), ptr(out), ptr(bd), current_stream()))
+    assert rel_err(out, ref) < 3e-6
+    # capnet_sgemm (ops.linear) takes this path by itself once there are enough 128-row tiles
+    out2 = ops.linear(Ad, Bd, bd)
+    if M > 64 and ((M + 127) // 128) * (N // 64) >= 64:
+        assert torch.equal(out2, out)
+    else:
+        assert rel_err(out2, ref) < 3e-6
+
+
+def test_sgemm_nt_dma_rejects_ineligible(dev):
+    A, Bw, out = torch.zeros(8, 40, device=dev), torch.zeros(70, 40, device=dev), torch.zeros(8, 70, device=dev)
+    assert lib().capnet_sgemm_nt_dma_eligible(8, 70, 40, ptr(A), 40, ptr(Bw), 40, ptr(out), 70) == 0
+    assert lib().capnet_sgemm_nt_dma(8, 70, 40, ptr(A), 40, ptr(Bw), ptr(out), None, current_stream()) != 0
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,stride,epi", [
+    (2, 8, 8, 128, 256, 1, 0),        # M = 128: one row of tiles
+    (3, 7, 7, 128, 128, 1, 0),        # ragged last M tile (147 rows): statistics ignore the padding rows
+    (2, 8, 8, 64, 64, 2, 0),          # stride 2 (downsample branch), 128x64 tiles
+    (5, 14, 14, 256, 64, 1, 0),
+    (4, 14, 14, 1024, 256, 1, 0),     # stage-3 conv1 shape at batch 4
+    (3, 6, 10, 96, 192, 2, 0),        # non-square map, odd k-tile count
+    (2, 7, 7, 64, 128, 1, 1),         # folded BatchNorm + residual + ReLU epilogue (inference trunk)
+    (2, 8, 8, 32, 64, 2, 2),          # folded epilogue without residual / ReLU
+])
+def test_conv1x1_dma_path(dev, B, H, W, Cin, Cout, stride, epi):
+    g = torch.Generator().manual_seed(B + H + Cin + Cout + stride)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) * 0.1
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), stride=stride)
+    OH, OW = ref.shape[2], ref.shape[3]
+    M = B * OH * OW
+    ref = ref.permute(0, 2, 3, 1).reshape(M, Cout)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    wd = w.reshape(Cout, Cin).contiguous().to(dev)
+    y = torch.full((M, Cout), float("nan"), device=dev)
+    tiles = lib().capnet_conv1x1_tiles_m(M)
+    assert tiles == (M + 127) // 128
+    if epi == 0:
+        psum = torch.full((tiles, Cout), float("nan"), device=dev)
+        psq = torch.full((tiles, Cout), float("nan"), device=dev)
+        check(lib().capnet_conv1x1_fwd_dma(ptr(xd), H * W * Cin, W * Cin, Cin, ptr(wd), ptr(y), ptr(psum), ptr(psq),
+                                           B, H, W, Cin, Cout, stride, None, None, None, 0, current_stream()))
+        assert rel_err(y, ref) < 3e-6
+        assert rel_err(psum.sum(0), ref.sum(0)) < 1e-5
+        assert rel_err(psq.sum(0), (ref ** 2).sum(0)) < 1e-5
+        return
+    sc = (torch.rand(Cout, generator=g) + 0.5)
+    sh = torch.randn(Cout, generator=g)
+    res = torch.randn(M, Cout, generator=g) if epi == 1 else None
+    want = ref * sc.double() + sh.double()
+    if res is not None:
+        want = torch.relu(want + res.double())
+    rd = res.to(dev) if res is not None else None
+    scd, shd = sc.to(dev), sh.to(dev)
+    check(lib().capnet_conv1x1_fwd_dma(ptr(xd), H * W * Cin, W * Cin, Cin, ptr(wd), ptr(y), None, None, B, H, W,
+                                       Cin, Cout, stride, ptr(scd), ptr(shd), ptr(rd),
+                                       1 if epi == 1 else 0, current_stream()))
+    assert rel_err(y, want) < 3e-6
