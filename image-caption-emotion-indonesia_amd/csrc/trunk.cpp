@@ -63,9 +63,11 @@ int trunk_create(int B, int H, int W, Trunk** out) {
   // CAPNET_NO_WINOGRAD=1: every 3x3 through the direct implicit-GEMM kernel (A/B runs, diagnostics)
   const char* now = getenv("CAPNET_NO_WINOGRAD");
   const bool use_wino = !(now && now[0] == '1');
-  // CAPNET_NO_DMA1X1=1: conv1 / downsample through the K-major kernel as well (A/B runs)
-  const char* nod = getenv("CAPNET_NO_DMA1X1");
-  const bool use_dma = !(nod && nod[0] == '1');
+  // CAPNET_DMA1X1=1: conv1 / downsample through the LDS-DMA NT core (gemm_dma.hip) instead of the
+  // K-major kernel. Off by default: measured in the pipelined step on one MI355X it is slower
+  // (4876 vs 5177 images/s) although it has no VALU in its k-loop -- see DESIGN 4e.
+  const char* dma = getenv("CAPNET_DMA1X1");
+  const bool use_dma = dma && dma[0] == '1';
   auto add = [&](int cin, int cout, int k, int stride, int pad, int h, int w, bool activated_input = false) {
     TrunkConv c;
     c.Cin = cin; c.Cout = cout; c.k = k; c.stride = stride; c.pad = pad; c.H = h; c.W = w;

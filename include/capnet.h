@@ -122,7 +122,9 @@ int capnet_trunk_collect_timing(capnet_trunk_t* t, double* conv_ms, long* conv_l
 /* Weight image convolution i expects: 0 = rows [Cout][row_stride] (capnet_pack_conv_weight),
  * 1 = K-major [row_stride][Cout] (capnet_pack_conv_weight_kmajor; streamed to LDS by LDS-DMA),
  * 2 = Winograd F(2x2,3x3) (capnet_pack_conv_weight_wino: the 3x3 / stride-1 convolutions on even
- * maps, unless the trunk was created with CAPNET_NO_WINOGRAD=1 in the environment). */
+ * maps, unless the trunk was created with CAPNET_NO_WINOGRAD=1 in the environment),
+ * 3 = the 1x1 weight as stored, [Cout][Cin] (capnet_conv1x1_fwd_dma; only when the trunk was
+ * created with CAPNET_DMA1X1=1: an experiment, slower than image 1 in the pipelined step). */
 int capnet_trunk_conv_kmajor(const capnet_trunk_t* t, int i);
 int capnet_pack_conv_weight_kmajor(const float* w_oihw, float* out, int Cout, int Cin, int KH,
                                    int KW, int k_rows, capnet_stream_t stream);
