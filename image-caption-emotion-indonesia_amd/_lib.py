@@ -106,6 +106,8 @@ SIGNATURES = {
     "capnet_lstm_persist_run": (_i, [_vp, _vp, _vp, _vp, _ip, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "capnet_xent_fwd": (_i, [_vp, _l, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "capnet_xent_bwd": (_i, [_vp, _l, _i, _i, _vp, _vp, _vp, _vp, _l, _vp]),
+    "capnet_att_loss_fwd": (_i, [_vp, _vp, _i, _i, _i, C.c_float, _vp, _vp, _vp]),
+    "capnet_att_loss_bwd": (_i, [_vp, _vp, _i, _i, _i, C.c_float, _vp, _vp]),
     "capnet_clamp_adam": (_i, [_i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp),
                                C.POINTER(_vp), C.POINTER(_l), _ip, C.c_float, C.c_float,
                                C.c_float, C.c_float, C.c_float, _i, _vp]),

@@ -402,6 +402,14 @@ int capnet_xent_bwd(const float* logits, long ld, int N, int V, const long long*
                     capnet_stream_t stream) {
   return xent_bwd(logits, ld, N, V, targets, lse, grad_out, dlogits, ldd, S(stream));
 }
+int capnet_att_loss_fwd(const float* nll, const float* alphas, int B, int steps, int P, float alpha_c,
+                        float* colsum, float* out, capnet_stream_t stream) {
+  return att_loss_fwd(nll, alphas, B, steps, P, alpha_c, colsum, out, S(stream));
+}
+int capnet_att_loss_bwd(const float* gout, const float* colsum, int B, int steps, int P, float alpha_c,
+                        float* dalphas, capnet_stream_t stream) {
+  return att_loss_bwd(gout, colsum, B, steps, P, alpha_c, dalphas, S(stream));
+}
 
 int capnet_clamp_adam(int n, float* const* params, float* const* grads, float* const* exp_avg,
                       float* const* exp_avg_sq, const long* numel, const int* step, float lr,

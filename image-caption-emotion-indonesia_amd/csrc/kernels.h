@@ -197,6 +197,10 @@ int topk_correct(const float* logits, long ld, int N, int V, const long long* ta
                  int* count, int* err_flag, hipStream_t stream);
 int xent_bwd(const float* logits, long ld, int N, int V, const long long* targets,
              const float* lse, const float* gout, float* dlogits, long ldd, hipStream_t stream);
+int att_loss_fwd(const float* nll, const float* alphas, int B, int steps, int P, float alpha_c,
+                 float* colsum, float* out, hipStream_t stream);
+int att_loss_bwd(const float* gout, const float* colsum, int B, int steps, int P, float alpha_c,
+                 float* dalphas, hipStream_t stream);
 int clamp_adam(int n_tensors, float* const* params, float* const* grads, float* const* exp_avg,
                float* const* exp_avg_sq, const long* numel, const int* step, float lr, float b1,
                float b2, float eps, float clip, int write_grad, hipStream_t stream);

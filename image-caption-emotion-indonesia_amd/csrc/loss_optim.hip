@@ -396,4 +396,67 @@ int bn1d_bwd(const float* dy, const float* x, int B, int C, const float* gamma,
   return kOk;
 }
 
+// ---- attention loss: nll + alpha_c * ((1 - sum_t alphas[b][t][p])^2).mean() -------------------------
+// (stylenet/train_multitask_att.py:409-411). One workgroup: B*P sums over the steps (fixed order),
+// a block reduction, the scalar total. `colsum` [B*P] keeps sum_t alpha for the backward kernel.
+__global__ __launch_bounds__(256) void att_loss_fwd_kernel(const float* __restrict__ nll,
+                                                           const float* __restrict__ alphas, int B,
+                                                           int steps, int P, float alpha_c,
+                                                           float* __restrict__ colsum,
+                                                           float* __restrict__ out) {
+  __shared__ float red[256];
+  const int n = B * P;
+  float part = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int b = i / P, p = i - b * P;
+    const float* a = alphas + (long)b * steps * P + p;
+    float s = 0.f;
+    for (int t = 0; t < steps; ++t) s += a[(long)t * P];
+    colsum[i] = s;
+    const float d = 1.f - s;
+    part = fmaf(d, d, part);
+  }
+  red[threadIdx.x] = part;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = nll[0] + alpha_c * (red[0] / (float)n);
+}
+
+// dalphas[b][t][p] = gout * alpha_c * 2 (sum_t alpha - 1) / (B P), the same for every step t
+__global__ __launch_bounds__(256) void att_loss_bwd_kernel(const float* __restrict__ gout,
+                                                           const float* __restrict__ colsum, int B,
+                                                           int steps, int P, float alpha_c,
+                                                           float* __restrict__ dalphas) {
+  const long total = (long)B * steps * P;
+  const float k = gout[0] * alpha_c * 2.f / (float)(B * P);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int p = (int)(i % P);
+    const int b = (int)(i / ((long)steps * P));
+    dalphas[i] = k * (colsum[b * P + p] - 1.f);
+  }
+}
+
+int att_loss_fwd(const float* nll, const float* alphas, int B, int steps, int P, float alpha_c,
+                 float* colsum, float* out, hipStream_t stream) {
+  CAPNET_REQUIRE(nll && alphas && colsum && out && B > 0 && steps > 0 && P > 0, "att_loss_fwd: bad argument");
+  hipLaunchKernelGGL(att_loss_fwd_kernel, dim3(1), dim3(256), 0, stream, nll, alphas, B, steps, P, alpha_c,
+                     colsum, out);
+  CAPNET_LAUNCH_CHECK();
+  return kOk;
+}
+
+int att_loss_bwd(const float* gout, const float* colsum, int B, int steps, int P, float alpha_c,
+                 float* dalphas, hipStream_t stream) {
+  CAPNET_REQUIRE(gout && colsum && dalphas && B > 0 && steps > 0 && P > 0, "att_loss_bwd: bad argument");
+  const long total = (long)B * steps * P;
+  hipLaunchKernelGGL(att_loss_bwd_kernel, dim3(cdiv(total, 256) > 1024 ? 1024 : cdiv(total, 256)), dim3(256), 0,
+                     stream, gout, colsum, B, steps, P, alpha_c, dalphas);
+  CAPNET_LAUNCH_CHECK();
+  return kOk;
+}
+
 }  // namespace capnet

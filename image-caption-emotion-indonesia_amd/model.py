@@ -459,7 +459,17 @@ class DecoderFactoredLSTM(nn.Module):
         S = self._S(mode)
         U = [getattr(self, "U_" + g) for g in "ifoc"]
         W = [getattr(self, "W_" + g) for g in "ifoc"]
-        pre = torch.cat([U[k](S[k](V[k](embedded))) + W[k](h_t) for k in range(4)], 1)
+        # gate pre-activations [b, 4H]: U_g(S_g(V_g(x))) lands in its column block, W_g(h) is
+        # accumulated onto it (no torch.cat / add kernels on the decode path)
+        H = self.hidden_size
+        with torch.no_grad():
+            pre = torch.empty((embedded.shape[0], 4 * H), dtype=torch.float32, device=embedded.device)
+            h_c = h_t.contiguous()
+            for k in range(4):
+                a2 = S[k](V[k](embedded))
+                blk = pre[:, k * H:(k + 1) * H]
+                ops.sgemm(a2, U[k].weight, transB=True, bias=U[k].bias, out=blk)
+                ops.sgemm(h_c, W[k].weight, transB=True, bias=W[k].bias, out=blk, accumulate=True)
         h_t, c_t = ops.lstm_pointwise(pre, c_t, ops.CELL_FACTORED)
         return h_t, (h_t, c_t)
 

@@ -71,10 +71,11 @@ def sgemm(A, B, transA=False, transB=False, bias=None, out=None, accumulate=Fals
         if accumulate:
             raise CapnetError("sgemm: accumulate needs an output tensor")
         out = torch.empty((M, N), dtype=torch.float32, device=A.device)
-    if not out.is_contiguous() or tuple(out.shape) != (M, N):
+    # `out` may be a column block of a wider row-major matrix (unit column stride)
+    if out.dim() != 2 or tuple(out.shape) != (M, N) or out.stride(1) != 1 or out.stride(0) < N:
         raise CapnetError("sgemm: bad output tensor")
     check(_lib.lib().capnet_sgemm(int(transA), int(transB), M, N, K, ptr(A), A.shape[1], ptr(B),
-                                  B.shape[1], ptr(out), N, ptr(bias), int(accumulate), 1, 0, 0, 0,
+                                  B.shape[1], ptr(out), out.stride(0), ptr(bias), int(accumulate), 1, 0, 0, 0,
                                   0, force_tile, current_stream()), "capnet_sgemm")
     return out
 
@@ -340,6 +341,38 @@ class CrossEntropyFn(torch.autograd.Function):
 
 def cross_entropy(logits, targets):
     return CrossEntropyFn.apply(logits, targets)
+
+
+class AttentionLossFn(torch.autograd.Function):
+    """nll + alpha_c * ((1 - alphas.sum(dim=1)) ** 2).mean()  (train_multitask_att.py:409-411)."""
+
+    @staticmethod
+    def forward(ctx, nll, alphas, alpha_c):
+        _need_cuda(nll, alphas)
+        alphas = _c(alphas)
+        B, steps, P = alphas.shape
+        colsum = torch.empty(B * P, dtype=torch.float32, device=alphas.device)
+        out = torch.empty((), dtype=torch.float32, device=alphas.device)
+        check(_lib.lib().capnet_att_loss_fwd(ptr(_c(nll.reshape(1))), ptr(alphas), B, steps, P, float(alpha_c),
+                                             ptr(colsum), ptr(out), current_stream()), "capnet_att_loss_fwd")
+        ctx.dims, ctx.alpha_c = (B, steps, P), float(alpha_c)
+        ctx.save_for_backward(colsum)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        (colsum,) = ctx.saved_tensors
+        B, steps, P = ctx.dims
+        gout = _c(gout.to(torch.float32)).reshape(1)
+        dalphas = torch.empty((B, steps, P), dtype=torch.float32, device=colsum.device)
+        check(_lib.lib().capnet_att_loss_bwd(ptr(gout), ptr(colsum), B, steps, P, ctx.alpha_c, ptr(dalphas),
+                                             current_stream()), "capnet_att_loss_bwd")
+        return gout.reshape(()), dalphas, None
+
+
+def attention_loss(nll, alphas, alpha_c=1.0):
+    return AttentionLossFn.apply(nll, alphas, alpha_c)
 
 
 # ---------------------------------------------------------------------------------------

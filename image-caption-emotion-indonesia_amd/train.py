@@ -20,6 +20,25 @@ from .metrics import corpus_bleu
 from .utils import AverageMeter, accuracy, clip_gradient
 
 
+_scale_cache = {}
+
+
+def _backward(loss, loss_scale):
+    """loss.backward(), or d(loss_scale * loss): the weight goes in as the incoming gradient of the
+    loss kernels' backward instead of a torch multiply on the scalar."""
+    if loss_scale is None:
+        loss.backward()
+        return
+    key = (loss.device, float(loss_scale))
+    g = _scale_cache.get(key)
+    if g is None:
+        if len(_scale_cache) > 64:
+            _scale_cache.clear()
+        g = torch.full((), float(loss_scale), dtype=torch.float32, device=loss.device)
+        _scale_cache[key] = g
+    loss.backward(g)
+
+
 class CrossEntropyLoss(nn.Module):
     """nn.CrossEntropyLoss() (mean reduction) on the fused HIP softmax+NLL kernels."""
 
@@ -49,7 +68,7 @@ def train_step(encoder, decoder, optimizer, criterion, images, captions, lengths
     decoder.zero_grad()
     if zero_encoder_grad:
         encoder.zero_grad()
-    (loss if loss_scale is None else loss * loss_scale).backward()
+    _backward(loss, loss_scale)
     clip_gradient(optimizer, grad_clip)
     optimizer.step()
     return loss.detach()
@@ -77,11 +96,11 @@ def train_step_att(encoder, decoder, optimizer, criterion, images, captions, len
     outputs, alphas = decoder(captions[:, :-1].contiguous(), lengths, features,
                               teacher_forcing_ratio=teacher_forcing_ratio, **kw)
     loss = criterion(outputs, targets)
-    loss = loss + alpha_c * ((1. - alphas.sum(dim=1)) ** 2).mean()
+    loss = ops.attention_loss(loss, alphas, alpha_c)
     decoder.zero_grad()
     if zero_encoder_grad:
         encoder.zero_grad()
-    (loss if loss_scale is None else loss * loss_scale).backward()
+    _backward(loss, loss_scale)
     clip_gradient(optimizer, grad_clip)
     optimizer.step()
     return loss.detach()
@@ -195,7 +214,7 @@ class TrunkPipeline(object):
                 outputs, alphas = dec(captions[:, :-1].contiguous(), lens, feats,
                                       teacher_forcing_ratio=teacher_forcing_ratio, **kw)
                 loss = self.criterion(outputs, targets)
-                loss = loss + self.alpha_c * ((1.0 - alphas.sum(dim=1)) ** 2).mean()
+                loss = ops.attention_loss(loss, alphas, self.alpha_c)
             else:
                 targets = ops.packed_targets(captions, lengths)
                 if enc.pre_head_hook is not None:
@@ -207,7 +226,7 @@ class TrunkPipeline(object):
             dec.zero_grad()
             if zero_encoder_grad:
                 enc.zero_grad()
-            (loss if loss_scale is None else loss * loss_scale).backward()
+            _backward(loss, loss_scale)
             clip_gradient(self.optimizer, self.grad_clip)
             self.optimizer.step()
             loss = loss.detach()

@@ -365,6 +365,14 @@ int capnet_xent_fwd(const float* logits, long ld, int N, int V, const long long*
 int capnet_xent_bwd(const float* logits, long ld, int N, int V, const long long* targets,
                     const float* lse, const float* grad_out, float* dlogits, long ldd,
                     capnet_stream_t stream);
+/* Loss of the attention loops (stylenet/train_multitask_att.py:409-411):
+ *   out = nll + alpha_c * ((1 - sum_t alphas[b][t][p])^2).mean()     alphas [B][steps][P]
+ * colsum [B*P] receives sum_t alphas for the backward call, which writes
+ *   dalphas[b][t][p] = gout * alpha_c * 2 (colsum[b][p] - 1) / (B P). */
+int capnet_att_loss_fwd(const float* nll, const float* alphas, int B, int steps, int P, float alpha_c,
+                        float* colsum, float* out, capnet_stream_t stream);
+int capnet_att_loss_bwd(const float* gout, const float* colsum, int B, int steps, int P, float alpha_c,
+                        float* dalphas, capnet_stream_t stream);
 
 /* ---- input pipeline (stylenet/train_multitask.py:62-69: Resize((336,336)) -> RandomCrop(224) ->
  * RandomHorizontalFlip -> ToTensor -> Normalize) on uint8 HWC device images ----------------------

@@ -545,3 +545,24 @@ def test_conv1x1_dma_path(dev, B, H, W, Cin, Cout, stride, epi):
                                        Cin, Cout, stride, ptr(scd), ptr(shd), ptr(rd),
                                        1 if epi == 1 else 0, current_stream()))
     assert rel_err(y, want) < 3e-6
+
+
+def test_attention_loss_matches_torch(dev):
+    """ops.attention_loss = nll + alpha_c * ((1 - alphas.sum(dim=1)) ** 2).mean()
+    (stylenet/train_multitask_att.py:409-411), value and both gradients."""
+    g = torch.Generator().manual_seed(3)
+    B, steps, P = 5, 7, 196
+    alphas = torch.rand(B, steps, P, generator=g) * 0.3
+    alphas[3:, 5:] = 0.0                       # rows of finished sequences stay zero and still count
+    nll = torch.tensor(3.25)
+    a_ref = alphas.double().requires_grad_(True)
+    n_ref = nll.double().requires_grad_(True)
+    want = n_ref + 0.7 * ((1.0 - a_ref.sum(dim=1)) ** 2).mean()
+    (want * 1.5).backward()
+    a_d = alphas.to(dev).requires_grad_(True)
+    n_d = nll.to(dev).requires_grad_(True)
+    got = ops.attention_loss(n_d, a_d, 0.7)
+    got.backward(torch.tensor(1.5, device=dev))
+    assert abs(got.item() - want.item()) < 1e-6 * abs(want.item())
+    assert rel_err(a_d.grad, a_ref.grad) < 1e-6
+    assert abs(n_d.grad.item() - 1.5) < 1e-7
