@@ -49,6 +49,7 @@ SIGNATURES = {
     "capnet_conv2d_fwd": (_i, [_vp, _l, _l, _l, _l, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _i,
                                _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "capnet_trunk_conv_kmajor": (_i, [_vp, _i]),
+    "capnet_trunk_conv_x6_bn": (_i, [_vp, _i]),
     "capnet_pack_conv_weight_kmajor": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "capnet_conv2d_fwd_kmajor": (_i, [_vp, _l, _l, _l, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _i,
                                       _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
@@ -62,6 +63,11 @@ SIGNATURES = {
     "capnet_conv1x1_tiles_m": (_i, [_l]),
     "capnet_conv1x1_fwd_dma": (_i, [_vp, _l, _l, _l, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp,
                                     _vp, _i, _vp]),
+    "capnet_conv1x1_bf16x6_weight_words": (_sz, [_i, _i]),
+    "capnet_conv1x1_bf16x6_bn": (_i, [_l, _i]),
+    "capnet_conv1x1_bf16x6_pack": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "capnet_conv1x1_fwd_bf16x6": (_i, [_vp, _l, _l, _l, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i,
+                                       _i, _vp, _vp, _vp, _i, _vp]),
     "capnet_conv_kmajor_slab_floats": (_sz, [_i, _i, _i, _i]),
     "capnet_conv_kmajor_plan": (None, [_i, _i, _i, _i, _ip]),
     "capnet_conv_kmajor_tiles_m": (_i, [_i, _i, _i, _i]),

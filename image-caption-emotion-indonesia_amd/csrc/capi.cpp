@@ -46,6 +46,21 @@ int capnet_conv1x1_fwd_dma(const float* x, long sxb, long sxh, long sxw, const f
                          S(stream), out_scale, out_shift, res, relu_out);
 }
 
+size_t capnet_conv1x1_bf16x6_weight_words(int Cin, int Cout) { return conv1x1_bf16x6_weight_words(Cin, Cout); }
+int capnet_conv1x1_bf16x6_bn(long M, int Cout) { return conv1x1_bf16x6_bn(M, Cout); }
+int capnet_conv1x1_bf16x6_pack(const float* w_oi, unsigned* image, int Cout, int Cin, int bn,
+                               capnet_stream_t stream) {
+  return conv1x1_bf16x6_pack(w_oi, image, Cout, Cin, bn, S(stream));
+}
+int capnet_conv1x1_fwd_bf16x6(const float* x, long sxb, long sxh, long sxw, const unsigned* image, int bn,
+                              float* y, const float* in_scale, const float* in_shift, int relu_in,
+                              float* part_sum, float* part_sq, int B, int H, int W, int Cin, int Cout,
+                              int stride, const float* out_scale, const float* out_shift,
+                              const float* res, int relu_out, capnet_stream_t stream) {
+  return conv1x1_fwd_bf16x6(x, sxb, sxh, sxw, image, bn, y, in_scale, in_shift, relu_in, part_sum, part_sq, B,
+                            H, W, Cin, Cout, stride, S(stream), out_scale, out_shift, res, relu_out);
+}
+
 int capnet_sgemm_splitk(int transA, int transB, int M, int N, int K, const float* A, long lda,
                         const float* B, long ldb, float* C, long ldc, const float* bias,
                         int accumulate, float* workspace, size_t workspace_floats,
@@ -112,6 +127,7 @@ double capnet_trunk_conv_flops(const capnet_trunk_t* t, int i) {
 int capnet_trunk_conv_kmajor(const capnet_trunk_t* t, int i) {
   return trunk_conv_kmajor(reinterpret_cast<const Trunk*>(t), i);
 }
+int capnet_trunk_conv_x6_bn(const capnet_trunk_t* t, int i) { return trunk_conv_x6_bn(reinterpret_cast<const Trunk*>(t), i); }
 int capnet_pack_conv_weight_kmajor(const float* w_oihw, float* out, int Cout, int Cin, int KH,
                                    int KW, int k_rows, capnet_stream_t stream) {
   return pack_conv_weight_kmajor(w_oihw, out, Cout, Cin, KH, KW, k_rows, S(stream));

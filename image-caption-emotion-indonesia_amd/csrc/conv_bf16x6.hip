@@ -1,0 +1,385 @@
+// 1x1 convolution with fp32-grade results on the bf16 matrix cores: every fp32 operand is split
+// into three bf16 pieces x = h + m + l (h = bf16(x), m = bf16(x - h), l = bf16(x - h - m): 24
+// mantissa bits in all) and the product is formed from the six partial products that matter,
+//     x y  =  h h' + (h m' + m h') + (m m' + h l' + l h')   [ + terms below 2^-24 |x y| ],
+// each an exact bf16 x bf16 product accumulated in fp32 by v_mfma_f32_32x32x16_bf16. Six bf16 MFMAs
+// per K = 16 cost 6 x 32 cycles where eight K = 2 f32 MFMAs cost 512: 2.67x the f32 matrix rate, and
+// the bf16 MFMA does not share its pipe with the VALU (the f32 one does).
+// Accuracy (tests/test_kernels_gpu.py, tools/split_error.py): rms error against fp64 5e-8 .. 1e-7 on
+// the trunk's shapes -- not above the f32 MFMA kernels' (1e-7 .. 2e-7): the results are fp32 results.
+//
+// Replaces the K-major f32 kernel on the 1x1 convolutions of the ResNet-152 bottlenecks in train mode
+// (torchvision Bottleneck conv1 / conv3 / downsample, call sites stylenet/model.py:15-18,24): raw
+// output + per-tile column sums / sums of squares for the BatchNorm that follows; PRE applies the
+// previous BatchNorm + ReLU while the A tile is staged, exactly as conv_f32_v2.hip does.
+//
+// Layout (tile 128 x BN, BN = 64 / 128; 256 threads = 2 x 2 waves of 64 x BN/2; k-tile = 16):
+//   * B (weights): split and laid out ONCE per weight version as the exact LDS image of every
+//     (n-tile, k-tile): [plane h,m,l][16-row group][row][2 cells], a cell = 8 consecutive k of one
+//     output channel as bf16 (16 B): 1-KB contiguous pieces per wave-instruction, global -> registers
+//     -> LDS (see the note on LDS-DMA below).
+//   * A (activations): thread (row = tid >> 1, cell = tid & 1) loads 8 consecutive fp32 of its pixel
+//     (two 16-B loads off one scalar base), folds the BatchNorm, splits them (11 VALU per pair:
+//     3 v_cvt_pk_bf16_f32, 4 bit extractions, 4 exact subtractions) and writes one 16-B cell per
+//     plane. Cell position inside a row is XOR-ed with bit 3 of the row, so that the fragment reads
+//     (ds_read_b128, 16 lanes per LDS pass, row stride 32 B) touch 16 distinct bank slots.
+//   * fragments: lane (row = lane & 31, half = lane >> 5) needs k = 8 half .. 8 half + 7 of its row
+//     = ONE cell per plane: 12 ds_read_b128 feed the 24 MFMAs of a wave's k-tile.
+//   * 24 KB of LDS per stage, two stages: three workgroups per CU.
+//
+// Why the weights do not use LDS-DMA here. The first version streamed the B image with
+// global_load_lds_dwordx4 (two or three per wave and k-tile). Its own results were right, but workgroups
+// of OTHER kernels sharing its CUs computed wrong values now and then: att_scores_fwd_kernel (no LDS of
+// its own; a wave reduction through __shfl_xor) returned one wrong score in ~25 % of its launches
+// beside it (tools/victim2.py), which showed up as TrunkPipeline(attention=True) steps that were no longer
+// reproducible. No out-of-bounds access (guard bands, tools/x6_guard.py), no LDS or register damage
+// in a canary kernel (tools/native/canary_probe.hip), wait states around the M0 writes changed nothing,
+// and neither the K-major conv kernel nor gemm_dma.hip (both LDS-DMA users) trigger it. With the
+// weights going through registers the interference is gone (0 / 100) at the same speed (-4 % in
+// isolation). tests/test_step_gpu.py keeps a decoder-beside-trunk reproducibility check for this.
+#include <cstdlib>
+
+#include "common.h"
+#include "mfma_core.h"
+#include "kernels.h"
+
+namespace capnet {
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int XBM = 128, XBK = 16;
+constexpr int kPlaneA = XBM * 2 * 16;            // bytes of one plane of the A image (128 rows x 2 cells)
+
+struct XArgs {
+  const float* x;
+  const unsigned* wimg;      // packed weight image
+  float* y;
+  const float* in_scale;
+  const float* in_shift;
+  float* part_sum;
+  float* part_sq;
+  // inference epilogue (out_scale != null): y = act(acc * out_scale[n] + out_shift[n] + res)
+  const float* out_scale;
+  const float* out_shift;
+  const float* res;
+  int relu_out;
+  int M, Cin, Cout, relu_in;
+  int abl;   // diagnostics (CAPNET_X6_ABLATE): 1 no DMA, 2 no A cell writes, 4 no statistics, 8 no output stores
+  int tiles_m, tiles_n;
+  unsigned tn_mul, tn_sh;
+  int OW, OHW, stride, sxb, sxh, sxw;
+  unsigned ohw_mul, ohw_sh, ow_mul, ow_sh;
+};
+
+__device__ __forceinline__ unsigned x_row_offset(const XArgs& g, int m) {
+  const int b = (int)fast_div((unsigned)m, g.ohw_mul, g.ohw_sh);
+  const int rem = m - b * g.OHW;
+  const int oh = (int)fast_div((unsigned)rem, g.ow_mul, g.ow_sh);
+  const int ow = rem - oh * g.OW;
+  return (unsigned)(b * g.sxb + oh * g.stride * g.sxh + ow * g.stride * g.sxw);
+}
+
+// byte offset of cell (row, c) inside one plane
+__host__ __device__ inline unsigned x_cell(int row, int c) {
+  const int rg = row >> 4, r = row & 15;
+  return (unsigned)(((rg * 16 + r) * 2 + (c ^ ((r >> 3) & 1))) * 16);
+}
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+  unsigned p;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(p) : "v"(a), "v"(b));
+  return p;
+}
+
+// (x0, x1) -> packed bf16 pairs of the three pieces; the subtractions are exact in fp32
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+  h = cvt_pk_bf16(x0, x1);
+  const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
+  m = cvt_pk_bf16(r0, r1);
+  const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
+  l = cvt_pk_bf16(s0, s1);
+}
+
+template <int BN, bool PRE>
+__global__ __launch_bounds__(256, 3) void conv1x1_bf16x6_kernel(const XArgs g) {
+  constexpr int NT = BN / 64;
+  constexpr int kPlaneB = BN * 2 * 16;
+  constexpr int kImgA = 3 * kPlaneA, kImgB = 3 * kPlaneB;
+  constexpr int kStage = kImgA + kImgB;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kStage];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+  const int id = xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n);
+  const int tm = (int)fast_div((unsigned)id, g.tn_mul, g.tn_sh), tn = id - tm * g.tiles_n;
+  const int m0 = tm * XBM, n0 = tn * BN;
+  const int nk = g.Cin / XBK;
+
+  // ---- A staging: thread (row, cell)
+  const int arow = tid >> 1, ac = tid & 1;
+  const int am = m0 + arow;
+  const bool a_ok = am < g.M;
+  const unsigned avoff = (x_row_offset(g, a_ok ? am : g.M - 1) + 8u * ac) * 4u;
+  const unsigned awr = x_cell(arow, ac);
+  const float lo = g.relu_in ? 0.f : -__builtin_inff();
+  // ---- B: the image of (tn, kt) is kImgB contiguous bytes = the LDS image; thread t moves the
+  // 16-B cells t, t + 256, ... through registers (NOT by LDS-DMA: see the note at the end of the header)
+  const float* sA = g.x;
+  const float* sS = g.in_scale;
+  const float* sT = g.in_shift;
+
+  f32x4 a0, a1, sc0, sc1, sh0, sh1;
+  constexpr int NBR = (kImgB / 16 + 255) / 256;     // 16-B cells of the B image per thread
+  f32x4 bq[NBR];
+  const float* sBr = reinterpret_cast<const float*>(g.wimg) + ((long)tn * nk) * (kImgB / 4);
+  auto issue = [&](int stage) {
+#pragma unroll
+    for (int q = 0; q < NBR; ++q) {
+      const int cell = tid + 256 * q;
+      gload16(bq[q], sBr, (unsigned)((cell < kImgB / 16 ? cell : 0) * 16));
+    }
+    sBr += kImgB / 4;
+    gload16(a0, sA, avoff);
+    gload16(a1, sA + 4, avoff);
+    if (PRE) {
+      gload16(sc0, sS, (unsigned)(32 * ac));
+      gload16(sc1, sS + 4, (unsigned)(32 * ac));
+      gload16(sh0, sT, (unsigned)(32 * ac));
+      gload16(sh1, sT + 4, (unsigned)(32 * ac));
+      sS += XBK;
+      sT += XBK;
+    }
+    sA += XBK;
+  };
+  auto store = [&](int stage) {
+    // every load and DMA of this tile has landed after this wait (vmcnt retires in order); the "+v"
+    // operands make the loaded registers defined HERE for the compiler
+    if (PRE)
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(sc0), "+v"(sc1), "+v"(sh0), "+v"(sh1)::"memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(a0), "+v"(a1)::"memory");
+#pragma unroll
+    for (int q = 0; q < NBR; ++q) {
+      asm volatile("" : "+v"(bq[q]));       // (loaded by asm: defined for the compiler from here on)
+      const int cell = tid + 256 * q;
+      if (cell < kImgB / 16) *reinterpret_cast<f32x4*>(lds + stage * kStage + kImgA + cell * 16) = bq[q];
+    }
+    float x[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+    if (PRE) {
+      const float s[8] = {sc0[0], sc0[1], sc0[2], sc0[3], sc1[0], sc1[1], sc1[2], sc1[3]};
+      const float t[8] = {sh0[0], sh0[1], sh0[2], sh0[3], sh1[0], sh1[1], sh1[2], sh1[3]};
+#pragma unroll
+      for (int i = 0; i < 8; ++i) x[i] = fmaxf(fmaf(x[i], s[i], t[i]), lo);
+    }
+    if (!a_ok) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) x[i] = 0.f;      // rows past M: zero products, zero statistics
+    }
+    u32x4 ph, pm, pl;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      unsigned h, m, l;
+      split_pair(x[2 * i], x[2 * i + 1], h, m, l);
+      ph[i] = h; pm[i] = m; pl[i] = l;
+    }
+    unsigned char* d = lds + stage * kStage + awr;
+    *reinterpret_cast<u32x4*>(d) = ph;
+    *reinterpret_cast<u32x4*>(d + kPlaneA) = pm;
+    *reinterpret_cast<u32x4*>(d + 2 * kPlaneA) = pl;
+  };
+
+  f32x16 acc[2][NT];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+  // fragment addresses: cell `lh` of row (wave's 64 rows + li); + 32 rows = 2 row groups = 1024 B
+  const unsigned char* a_rd = lds + x_cell(wm * 64 + li, lh);
+  const unsigned char* b_rd = lds + kImgA + x_cell(wn * (BN / 2) + li, lh);
+  auto compute = [&](int stage) {
+    bf16x8 af[2][3], bf[NT][3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+        af[mt][p] = *reinterpret_cast<const bf16x8*>(a_rd + stage * kStage + p * kPlaneA + mt * 1024);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        bf[nt][p] = *reinterpret_cast<const bf16x8*>(b_rd + stage * kStage + p * kPlaneB + nt * 1024);
+    }
+    // small terms first: (l h', h l', m m'), (m h', h m'), h h'
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
+    constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+    for (int term = 0; term < 6; ++term)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt][PA[term]], bf[nt][PB[term]], acc[mt][nt], 0, 0, 0);
+  };
+
+  issue(0);
+  store(0);
+  __syncthreads();
+  int kt = 0;
+  for (; kt + 2 <= nk; kt += 2) {
+    issue(1);
+    compute(0);
+    store(1);
+    __syncthreads();
+    const bool more = kt + 2 < nk;
+    if (more) issue(0);
+    compute(1);
+    if (more) store(0);
+    __syncthreads();
+  }
+  if (kt < nk) compute(0);
+
+  // ---- epilogue: raw output (D layout: column = lane & 31, rows (r & 3) + 8 (r >> 2) + 4 lh)
+  const bool ragged = m0 + XBM > g.M;
+  const unsigned rstep = (unsigned)g.Cout * 4u;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int n = n0 + wn * (BN / 2) + nt * 32 + li;
+    const float osc = g.out_scale ? g.out_scale[n] : 1.f, osh = g.out_scale ? g.out_shift[n] : 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      int row = m0 + wm * 64 + mt * 32 + 4 * lh;
+      unsigned off = ((unsigned)row * (unsigned)g.Cout + (unsigned)n) * 4u;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (!ragged || row < g.M) {
+          float v = acc[mt][nt][r];
+          if (g.out_scale) {
+            v = fmaf(v, osc, osh);
+            if (g.res) v += *reinterpret_cast<const float*>(reinterpret_cast<const char*>(g.res) + off);
+            if (g.relu_out) v = fmaxf(v, 0.f);
+          }
+          asm volatile("global_store_dword %0, %1, %2" ::"v"(off), "v"(v), "s"(g.y) : "memory");
+        }
+        if ((r & 3) == 3) { row += 5; off += 5u * rstep; } else { row += 1; off += rstep; }
+      }
+    }
+  }
+  if (g.part_sum) {
+    using T = TileCfg<XBM, BN, 16>;
+    __syncthreads();
+    block_col_stats<T>(acc, reinterpret_cast<float*>(lds), g.part_sum + (long)tm * g.Cout,
+                       g.part_sq + (long)tm * g.Cout, n0, g.Cout);
+  }
+}
+
+// One thread per (tn, kt, plane, row, pos): 8 consecutive k of output channel n -> one 16-B cell.
+template <int BN>
+__global__ __launch_bounds__(256) void conv1x1_bf16x6_pack_kernel(const float* __restrict__ w, unsigned* __restrict__ img,
+                                                                  int Cout, int Cin) {
+  const int nk = Cin / XBK, tiles_n = Cout / BN;
+  const long cells = (long)tiles_n * nk * 3 * BN * 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < cells; i += (long)gridDim.x * blockDim.x) {
+    long r = i;
+    const int pos = (int)(r & 1); r >>= 1;
+    const int row = (int)(r % BN); r /= BN;
+    const int plane = (int)(r % 3); r /= 3;
+    const int kt = (int)(r % nk);
+    const int tn = (int)(r / nk);
+    const int c = pos ^ (((row & 15) >> 3) & 1);
+    const float* src = w + (long)(tn * BN + row) * Cin + kt * XBK + 8 * c;
+    unsigned out[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float x0 = src[2 * q], x1 = src[2 * q + 1];
+      // same split as the device staging code, written with plain conversions
+      auto bf = [](float v) { return __uint_as_float(((__float_as_uint(v) + 0x7fffu + ((__float_as_uint(v) >> 16) & 1u)) & 0xffff0000u)); };
+      const float h0 = bf(x0), h1 = bf(x1);
+      const float m0 = bf(x0 - h0), m1 = bf(x1 - h1);
+      const float l0 = bf(x0 - h0 - m0), l1 = bf(x1 - h1 - m1);
+      const float p0 = plane == 0 ? h0 : plane == 1 ? m0 : l0;
+      const float p1 = plane == 0 ? h1 : plane == 1 ? m1 : l1;
+      out[q] = (__float_as_uint(p0) >> 16) | (__float_as_uint(p1) & 0xffff0000u);
+    }
+    // cell index inside the image of (tn, kt): [plane][row][pos]
+    unsigned* dst = img + (((long)(tn * nk + kt) * 3 + plane) * BN * 2 + (long)row * 2 + pos) * 4;
+    dst[0] = out[0]; dst[1] = out[1]; dst[2] = out[2]; dst[3] = out[3];
+  }
+}
+
+int x_pick_bn(int M, int Cout) {
+  const char* f = getenv("CAPNET_X6_BN");
+  if (f && f[0] == '1' && Cout % 128 == 0) return 128;
+  if (f && f[0] == '6') return 64;
+  (void)M;
+  return 64;
+}
+
+}  // namespace
+
+bool conv1x1_bf16x6_eligible(const float* x, long sxb, long sxh, long sxw, long sxc, int Bn, int H, int W,
+                             int Cin, int Cout, int stride, const float* in_scale, const float* in_shift) {
+  const long OH = (H - 1) / stride + 1, OW = (W - 1) / stride + 1;
+  return sxc == 1 && Cin % XBK == 0 && Cout % 64 == 0 && aligned16(x) && sxb % 4 == 0 && sxh % 4 == 0 &&
+         sxw % 4 == 0 && (long)Bn * sxb * 4 < (1l << 32) && (long)Bn * OH * OW < (1l << 24) &&
+         (long)Bn * OH * OW * Cout * 4 < (1l << 32) &&
+         (!in_scale || (aligned16(in_scale) && aligned16(in_shift)));
+}
+
+int conv1x1_bf16x6_tiles_m(long M) { return cdiv(M, XBM); }
+int conv1x1_bf16x6_bn(long M, int Cout) { return x_pick_bn((int)M, Cout); }
+size_t conv1x1_bf16x6_weight_words(int Cin, int Cout) { return (size_t)Cout * Cin * 3 / 2; }
+
+// w [Cout][Cin] fp32 -> the split bf16 image for tile width bn
+int conv1x1_bf16x6_pack(const float* w, unsigned* img, int Cout, int Cin, int bn, hipStream_t stream) {
+  CAPNET_REQUIRE(w && img && Cin % XBK == 0 && (bn == 64 || bn == 128) && Cout % bn == 0 && aligned16(img),
+                 "conv1x1_bf16x6_pack: bad argument (Cin=%d Cout=%d bn=%d)", Cin, Cout, bn);
+  const long cells = (long)Cout * Cin * 3 / 8;
+  const int grid = (int)(cdiv(cells, 256) > 4096 ? 4096 : cdiv(cells, 256));
+  if (bn == 128) hipLaunchKernelGGL(conv1x1_bf16x6_pack_kernel<128>, dim3(grid), dim3(256), 0, stream, w, img, Cout, Cin);
+  else hipLaunchKernelGGL(conv1x1_bf16x6_pack_kernel<64>, dim3(grid), dim3(256), 0, stream, w, img, Cout, Cin);
+  CAPNET_LAUNCH_CHECK();
+  return kOk;
+}
+
+int conv1x1_fwd_bf16x6(const float* x, long sxb, long sxh, long sxw, const unsigned* wimg, int bn, float* y,
+                       const float* in_scale, const float* in_shift, int relu_in, float* part_sum,
+                       float* part_sq, int Bn, int H, int W, int Cin, int Cout, int stride,
+                       hipStream_t stream, const float* out_scale, const float* out_shift, const float* res,
+                       int relu_out) {
+  CAPNET_REQUIRE(x && wimg && y && stride >= 1, "conv1x1_fwd_bf16x6: bad argument");
+  CAPNET_REQUIRE(conv1x1_bf16x6_eligible(x, sxb, sxh, sxw, 1, Bn, H, W, Cin, Cout, stride, in_scale, in_shift) &&
+                     aligned16(wimg) && (bn == 64 || bn == 128) && Cout % bn == 0,
+                 "conv1x1_fwd_bf16x6: operands not eligible");
+  CAPNET_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv1x1_fwd_bf16x6: scale/shift pair");
+  CAPNET_REQUIRE((part_sum == nullptr) == (part_sq == nullptr), "conv1x1_fwd_bf16x6: stats pair");
+  XArgs a{};
+  const int OH = (H - 1) / stride + 1, OW = (W - 1) / stride + 1;
+  a.x = x; a.wimg = wimg; a.y = y; a.in_scale = in_scale; a.in_shift = in_shift;
+  a.part_sum = part_sum; a.part_sq = part_sq;
+  a.out_scale = out_scale; a.out_shift = out_shift; a.res = res; a.relu_out = relu_out;
+  CAPNET_REQUIRE(!out_scale || (out_shift && !part_sum), "conv1x1_fwd_bf16x6: folded epilogue takes no statistics");
+  { const char* e = getenv("CAPNET_X6_ABLATE"); a.abl = e ? atoi(e) : 0; }
+  a.M = Bn * OH * OW; a.Cin = Cin; a.Cout = Cout; a.relu_in = relu_in;
+  a.tiles_m = cdiv(a.M, XBM); a.tiles_n = Cout / bn;
+  magic_div((unsigned)a.tiles_n, &a.tn_mul, &a.tn_sh);
+  a.OW = OW; a.OHW = OH * OW; a.stride = stride;
+  a.sxb = (int)sxb; a.sxh = (int)sxh; a.sxw = (int)sxw;
+  magic_div((unsigned)(OH * OW), &a.ohw_mul, &a.ohw_sh);
+  magic_div((unsigned)OW, &a.ow_mul, &a.ow_sh);
+  const dim3 grid(a.tiles_m * a.tiles_n), block(256);
+  if (bn == 128) {
+    if (in_scale) hipLaunchKernelGGL((conv1x1_bf16x6_kernel<128, true>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((conv1x1_bf16x6_kernel<128, false>), grid, block, 0, stream, a);
+  } else {
+    if (in_scale) hipLaunchKernelGGL((conv1x1_bf16x6_kernel<64, true>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((conv1x1_bf16x6_kernel<64, false>), grid, block, 0, stream, a);
+  }
+  CAPNET_LAUNCH_CHECK();
+  return kOk;
+}
+
+}  // namespace capnet

@@ -63,6 +63,19 @@ int conv1x1_fwd_dma(const float* x, long sxb, long sxh, long sxw, const float* w
                     hipStream_t stream, const float* out_scale = nullptr, const float* out_shift = nullptr,
                     const float* res = nullptr, int relu_out = 0);
 
+// conv_bf16x6.hip: 1x1 convolution as six bf16 MFMA products of 3-way split fp32 operands (fp32-grade results)
+bool conv1x1_bf16x6_eligible(const float* x, long sxb, long sxh, long sxw, long sxc, int Bn, int H, int W,
+                             int Cin, int Cout, int stride, const float* in_scale, const float* in_shift);
+int conv1x1_bf16x6_tiles_m(long M);
+int conv1x1_bf16x6_bn(long M, int Cout);
+size_t conv1x1_bf16x6_weight_words(int Cin, int Cout);
+int conv1x1_bf16x6_pack(const float* w, unsigned* img, int Cout, int Cin, int bn, hipStream_t stream);
+int conv1x1_fwd_bf16x6(const float* x, long sxb, long sxh, long sxw, const unsigned* wimg, int bn, float* y,
+                       const float* in_scale, const float* in_shift, int relu_in, float* part_sum,
+                       float* part_sq, int Bn, int H, int W, int Cin, int Cout, int stride,
+                       hipStream_t stream, const float* out_scale = nullptr, const float* out_shift = nullptr,
+                       const float* res = nullptr, int relu_out = 0);
+
 // bn_pool.hip
 int bn_finalize(const float* part_sum, const float* part_sq, int tiles, int C, long count,
                 const float* gamma, const float* beta, float* running_mean, float* running_var,
@@ -97,6 +110,7 @@ int trunk_num_convs(const Trunk* t);
 int trunk_final_side(const Trunk* t);
 int trunk_conv_shape(const Trunk* t, int i, int* cout, int* cin, int* k, int* stride, int* kw);
 int trunk_conv_kmajor(const Trunk* t, int i);
+int trunk_conv_x6_bn(const Trunk* t, int i);
 double trunk_flops(const Trunk* t);
 double trunk_conv_flops(const Trunk* t, int i);
 int trunk_set_timing(Trunk* t, int enable);

@@ -30,6 +30,8 @@ struct TrunkConv {
   bool kmajor; // weights packed [Kw][Cout] for conv_f32_v2 (else [Cout][Kw] for conv_f32)
   bool wino;   // 3x3 / stride 1 on an even map: Winograd F(2x2,3x3) (conv_wino.hip), its own weight image
   bool dma1x1; // 1x1 on an activated input (conv1, downsample): LDS-DMA NT core (gemm_dma.hip), weights as [Cout][Cin]
+  bool x6;     // 1x1: six bf16 MFMA products of 3-way split fp32 operands (conv_bf16x6.hip), its own weight image
+  int x6_bn;   // tile width that image was laid out for
 };
 
 struct Trunk {
@@ -68,6 +70,10 @@ int trunk_create(int B, int H, int W, Trunk** out) {
   // (4876 vs 5177 images/s) although it has no VALU in its k-loop -- see DESIGN 4e.
   const char* dma = getenv("CAPNET_DMA1X1");
   const bool use_dma = dma && dma[0] == '1';
+  // 1x1 convolutions on the bf16 matrix cores with split operands (fp32-grade results);
+  // CAPNET_NO_X6=1 keeps them on the f32-MFMA K-major kernel (A/B runs)
+  const char* nox = getenv("CAPNET_NO_X6");
+  const bool use_x6 = !(nox && nox[0] == '1');
   auto add = [&](int cin, int cout, int k, int stride, int pad, int h, int w, bool activated_input = false) {
     TrunkConv c;
     c.Cin = cin; c.Cout = cout; c.k = k; c.stride = stride; c.pad = pad; c.H = h; c.W = w;
@@ -77,6 +83,8 @@ int trunk_create(int B, int H, int W, Trunk** out) {
     c.kmajor = (cin % 16 == 0) && (cout % 64 == 0);
     c.wino = use_wino && c.kmajor && conv_wino_shape_ok(h, w, cin, cout, k, k, stride, pad);
     c.dma1x1 = use_dma && activated_input && k == 1 && pad == 0 && cin % 16 == 0 && cout % 64 == 0;
+    c.x6 = use_x6 && !c.dma1x1 && k == 1 && pad == 0 && cin % 16 == 0 && cout % 64 == 0;
+    c.x6_bn = c.x6 ? conv1x1_bf16x6_bn((long)B * c.OH * c.OW, cout) : 0;
     t->convs.push_back(c);
     return c;
   };
@@ -123,7 +131,7 @@ int trunk_create(int B, int H, int W, Trunk** out) {
     const int tile = c.kmajor ? conv_v2_auto_tile((int)M, c.Cout, c.Kw) : conv_auto_tile((int)M, c.Cout);
     max_part = std::max(max_part, (size_t)conv_tiles_m((int)M, tile) * c.Cout);
     if (c.wino) max_part = std::max(max_part, (size_t)conv_wino_tiles_m(B, c.H, c.W) * c.Cout);
-    if (c.dma1x1) max_part = std::max(max_part, (size_t)conv1x1_tiles_m(M) * c.Cout);
+    if (c.dma1x1 || c.x6) max_part = std::max(max_part, (size_t)conv1x1_tiles_m(M) * c.Cout);
   }
   t->off_part = take(2 * max_part);
   size_t max_slab = 0;
@@ -204,7 +212,12 @@ int trunk_conv_shape(const Trunk* t, int i, int* cout, int* cin, int* k, int* st
 
 int trunk_conv_kmajor(const Trunk* t, int i) {
   if (i < 0 || i >= (int)t->convs.size()) return 0;
-  return t->convs[i].dma1x1 ? 3 : t->convs[i].wino ? 2 : (t->convs[i].kmajor ? 1 : 0);
+  return t->convs[i].x6 ? 4 : t->convs[i].dma1x1 ? 3 : t->convs[i].wino ? 2 : (t->convs[i].kmajor ? 1 : 0);
+}
+
+int trunk_conv_x6_bn(const Trunk* t, int i) {
+  if (i < 0 || i >= (int)t->convs.size()) return 0;
+  return t->convs[i].x6_bn;
 }
 
 double trunk_conv_flops(const Trunk* t, int i) {
@@ -250,7 +263,7 @@ int conv_bn(const Ctx& c, int i, const float* x, long sxb, long sxh, long sxw, l
   int tile = d.kmajor ? conv_v2_auto_tile((int)M, d.Cout, d.Kw) : conv_auto_tile((int)M, d.Cout);
   if (d.kmajor && !c.t->tail_balance && M >= 5000) tile = 12864;
   // rows of the statistics partials this conv writes
-  const int prows = d.dma1x1 ? conv1x1_tiles_m(M) : d.wino ? conv_wino_tiles_m(c.t->B, d.H, d.W) : conv_tiles_m((int)M, tile);
+  const int prows = (d.dma1x1 || d.x6) ? conv1x1_tiles_m(M) : d.wino ? conv_wino_tiles_m(c.t->B, d.H, d.W) : conv_tiles_m((int)M, tile);
   float* psum = c.ws + c.t->off_part;
   float* psq = psum + (size_t)prows * d.Cout;
   hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -260,7 +273,13 @@ int conv_bn(const Ctx& c, int i, const float* x, long sxb, long sxh, long sxw, l
     CAPNET_HIP_CHECK(hipEventRecord(e0, c.s));
   }
   int rc;
-  if (d.dma1x1) {
+  if (d.x6) {
+    CAPNET_REQUIRE(conv1x1_bf16x6_eligible(x, sxb, sxh, sxw, sxc, c.t->B, d.H, d.W, d.Cin, d.Cout, d.stride, in_scale, in_shift),
+                   "trunk: conv %d planned for the split-bf16 kernel but its operands are not eligible", i);
+    rc = conv1x1_fwd_bf16x6(x, sxb, sxh, sxw, reinterpret_cast<const unsigned*>(c.w[i]), d.x6_bn, y, in_scale,
+                            in_shift, relu_in, c.train ? psum : nullptr, c.train ? psq : nullptr, c.t->B, d.H,
+                            d.W, d.Cin, d.Cout, d.stride, c.s);
+  } else if (d.dma1x1) {
     CAPNET_REQUIRE(!in_scale && conv1x1_dma_eligible(x, sxb, sxh, sxw, sxc, c.t->B, d.H, d.W, d.Cin, d.Cout, d.stride),
                    "trunk: conv %d planned for the LDS-DMA 1x1 kernel but its operands are not eligible", i);
     rc = conv1x1_fwd_dma(x, sxb, sxh, sxw, c.w[i], y, c.train ? psum : nullptr, c.train ? psq : nullptr, c.t->B,
@@ -303,7 +322,7 @@ int conv_folded(const Ctx& c, int i, const float* x, const float* res, int relu,
   const TrunkConv& d = c.t->convs[i];
   const long M = (long)c.t->B * d.OH * d.OW;
   const long sw = d.Cin, sh = (long)d.W * d.Cin, sb = (long)d.H * d.W * d.Cin;
-  CAPNET_REQUIRE(d.dma1x1 || (d.kmajor && conv_v2_eligible(x, sb, sh, sw, 1, c.t->B, d.Cin, d.Cout, nullptr, nullptr)),
+  CAPNET_REQUIRE(d.x6 || d.dma1x1 || (d.kmajor && conv_v2_eligible(x, sb, sh, sw, 1, c.t->B, d.Cin, d.Cout, nullptr, nullptr)),
                  "trunk: conv %d is not eligible for the folded-BN kernel", i);
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (c.t->timing) {
@@ -312,7 +331,11 @@ int conv_folded(const Ctx& c, int i, const float* x, const float* res, int relu,
     CAPNET_HIP_CHECK(hipEventRecord(e0, c.s));
   }
   int rc;
-  if (d.dma1x1) {
+  if (d.x6) {
+    rc = conv1x1_fwd_bf16x6(x, sb, sh, sw, reinterpret_cast<const unsigned*>(c.w[i]), d.x6_bn, y, nullptr, nullptr,
+                            0, nullptr, nullptr, c.t->B, d.H, d.W, d.Cin, d.Cout, d.stride, c.s, c.scale(i),
+                            c.shift(i), res, relu);
+  } else if (d.dma1x1) {
     rc = conv1x1_fwd_dma(x, sb, sh, sw, c.w[i], y, nullptr, nullptr, c.t->B, d.H, d.W, d.Cin, d.Cout, d.stride,
                          c.s, c.scale(i), c.shift(i), res, relu);
   } else if (d.wino) {

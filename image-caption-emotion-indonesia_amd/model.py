@@ -180,13 +180,25 @@ class _TrunkRunner:
                                       (i, tuple(c.weight.shape)))
                 # 0 rows, 1 K-major, 2 Winograd, 3 as stored: a 1x1 OIHW weight IS [Cout][Cin]
                 kind = L.capnet_trunk_conv_kmajor(plan["handle"], i)
-                if kind == 3:
+                if kind == 4:
+                    packed.append(ops.pack_conv_weight_bf16x6(c.weight.detach(), L.capnet_trunk_conv_x6_bn(plan["handle"], i)))
+                elif kind == 3:
                     packed.append(c.weight.detach().reshape(cout, cin).contiguous())
                 elif kind == 2:
                     packed.append(ops.pack_conv_weight_wino(c.weight.detach()))
                 else:
                     packed.append(ops.pack_conv_weight(c.weight.detach(), kw, kmajor=kind == 1))
             self.packed, self.packed_key = packed, key
+            # the images were written on THIS stream; passes on other streams (TrunkPipeline runs
+            # one pass per stream) must not read them before these kernels have finished
+            self.pack_event = torch.cuda.Event()
+            self.pack_event.record()
+            self.pack_waited = {torch.cuda.current_stream().cuda_stream}
+        elif getattr(self, "pack_event", None) is not None:
+            st = torch.cuda.current_stream()
+            if st.cuda_stream not in self.pack_waited:
+                st.wait_event(self.pack_event)
+                self.pack_waited.add(st.cuda_stream)
         return self.packed
 
     def _tables(self, packed):

@@ -254,6 +254,20 @@ def pack_conv_weight_wino(w_oihw):
     return out
 
 
+def pack_conv_weight_bf16x6(w_oihw, bn):
+    """1x1 OIHW weights -> the split-bf16 image of capnet_conv1x1_fwd_bf16x6 for tile width bn
+    (three bf16 pieces per weight, laid out as the kernel's LDS image)."""
+    _need_cuda(w_oihw)
+    w = _c(w_oihw)
+    co, ci, kh, kw = w.shape
+    if (kh, kw) != (1, 1):
+        raise CapnetError("pack_conv_weight_bf16x6: 1x1 weights only")
+    out = torch.empty(_lib.lib().capnet_conv1x1_bf16x6_weight_words(ci, co), dtype=torch.int32, device=w.device)
+    check(_lib.lib().capnet_conv1x1_bf16x6_pack(ptr(w), ptr(out), co, ci, int(bn), current_stream()),
+          "capnet_conv1x1_bf16x6_pack")
+    return out
+
+
 def clamp_adam(params, grads, exp_avg, exp_avg_sq, steps, lr, beta1, beta2, eps, clip,
                write_grad=True):
     """Fused element-wise clamp + Adam over a list of tensors (in place)."""

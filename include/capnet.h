@@ -124,8 +124,11 @@ int capnet_trunk_collect_timing(capnet_trunk_t* t, double* conv_ms, long* conv_l
  * 2 = Winograd F(2x2,3x3) (capnet_pack_conv_weight_wino: the 3x3 / stride-1 convolutions on even
  * maps, unless the trunk was created with CAPNET_NO_WINOGRAD=1 in the environment),
  * 3 = the 1x1 weight as stored, [Cout][Cin] (capnet_conv1x1_fwd_dma; only when the trunk was
- * created with CAPNET_DMA1X1=1: an experiment, slower than image 1 in the pipelined step). */
+ * created with CAPNET_DMA1X1=1: an experiment, slower than image 1 in the pipelined step),
+ * 4 = the split-bf16 image of a 1x1 convolution (capnet_conv1x1_bf16x6_pack with tile width
+ * capnet_trunk_conv_x6_bn(t, i); every 1x1 convolution unless CAPNET_NO_X6=1). */
 int capnet_trunk_conv_kmajor(const capnet_trunk_t* t, int i);
+int capnet_trunk_conv_x6_bn(const capnet_trunk_t* t, int i);
 int capnet_pack_conv_weight_kmajor(const float* w_oihw, float* out, int Cout, int Cin, int KH,
                                    int KW, int k_rows, capnet_stream_t stream);
 /* OIHW (torch Conv2d.weight) -> packed rows */
@@ -159,6 +162,23 @@ int capnet_conv1x1_fwd_dma(const float* x, long sxb, long sxh, long sxw, const f
                            float* part_sum, float* part_sq, int B, int H, int W, int Cin, int Cout,
                            int stride, const float* out_scale, const float* out_shift, const float* res,
                            int relu_out, capnet_stream_t stream);
+
+/* 1x1 convolution with fp32-grade results on the bf16 matrix cores (csrc/conv_bf16x6.hip): both
+ * operands split into three bf16 pieces, six partial products per multiply, fp32 accumulation; rms
+ * error against fp64 at or below the f32-MFMA kernels'. Weights: capnet_conv1x1_bf16x6_pack of the
+ * [Cout][Cin] matrix for tile width bn = capnet_conv1x1_bf16x6_bn(M, Cout)
+ * (capnet_conv1x1_bf16x6_weight_words 32-bit words). Statistics rows: capnet_conv1x1_tiles_m(M).
+ * in_scale / in_shift / relu_in: BatchNorm + ReLU of the producer applied on load; out_scale / out_shift /
+ * res / relu_out: folded inference epilogue (then no statistics). */
+size_t capnet_conv1x1_bf16x6_weight_words(int Cin, int Cout);
+int capnet_conv1x1_bf16x6_bn(long M, int Cout);
+int capnet_conv1x1_bf16x6_pack(const float* w_oi, unsigned* image, int Cout, int Cin, int bn,
+                               capnet_stream_t stream);
+int capnet_conv1x1_fwd_bf16x6(const float* x, long sxb, long sxh, long sxw, const unsigned* image, int bn,
+                              float* y, const float* in_scale, const float* in_shift, int relu_in,
+                              float* part_sum, float* part_sq, int B, int H, int W, int Cin, int Cout,
+                              int stride, const float* out_scale, const float* out_shift,
+                              const float* res, int relu_out, capnet_stream_t stream);
 
 /* the low-VALU kernel used for every trunk convolution with Cin % 16 == 0 and Cout % 64 == 0:
  * NHWC channel-contiguous input, K-major weights, k_rows == KH*KW*Cin */

@@ -566,3 +566,68 @@ def test_attention_loss_matches_torch(dev):
     assert abs(got.item() - want.item()) < 1e-6 * abs(want.item())
     assert rel_err(a_d.grad, a_ref.grad) < 1e-6
     assert abs(n_d.grad.item() - 1.5) < 1e-7
+
+
+# ---- 1x1 convolution as six bf16 products of 3-way split operands (csrc/conv_bf16x6.hip) ---------
+@pytest.mark.parametrize("bn", [64, 128])
+@pytest.mark.parametrize("B,H,W,Cin,Cout,stride,pre,epi", [
+    (2, 8, 8, 128, 256, 1, False, 0),       # M = 128
+    (3, 7, 7, 128, 128, 1, True, 0),        # ragged last M tile (147 rows), folded BatchNorm + ReLU on load
+    (2, 8, 8, 64, 128, 2, False, 0),        # stride 2 (downsample branch)
+    (4, 14, 14, 1024, 256, 1, False, 0),    # stage-3 conv1 at batch 4: 64 k-tiles
+    (4, 14, 14, 256, 1024, 1, True, 0),     # stage-3 conv3
+    (5, 14, 14, 16, 128, 1, True, 0),       # one k-tile
+    (2, 7, 7, 64, 128, 1, False, 1),        # folded inference epilogue with residual + ReLU
+])
+def test_conv1x1_bf16x6_has_fp32_accuracy(dev, bn, B, H, W, Cin, Cout, stride, pre, epi):
+    g = torch.Generator().manual_seed(B + H + Cin + Cout + stride + bn)
+    # values spread over many binades, as activations and weights are
+    x = torch.randn(B, Cin, H, W, generator=g) * torch.exp(torch.randn(B, Cin, H, W, generator=g))
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) * 0.1 * torch.exp(torch.randn(Cout, Cin, 1, 1, generator=g))
+    scale = torch.rand(Cin, generator=g) - 0.3 if pre else None
+    shift = torch.randn(Cin, generator=g) if pre else None
+    xin = x.double()
+    if pre:
+        xin = torch.relu(x * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)).double()   # the fold is an fp32 fma + max
+    ref = torch.nn.functional.conv2d(xin, w.double(), stride=stride)
+    OH, OW = ref.shape[2], ref.shape[3]
+    M = B * OH * OW
+    ref = ref.permute(0, 2, 3, 1).reshape(M, Cout)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    wd = w.reshape(Cout, Cin).contiguous().to(dev)
+    L = lib()
+    img = torch.empty(L.capnet_conv1x1_bf16x6_weight_words(Cin, Cout), dtype=torch.int32, device=dev)
+    check(L.capnet_conv1x1_bf16x6_pack(ptr(wd), ptr(img), Cout, Cin, bn, current_stream()))
+    y = torch.full((M, Cout), float("nan"), device=dev)
+    tiles = L.capnet_conv1x1_tiles_m(M)
+    sd, hd = (scale.to(dev), shift.to(dev)) if pre else (None, None)
+    if epi:
+        sc, sh = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
+        res = torch.randn(M, Cout, generator=g)
+        scd, shd, rd = sc.to(dev), sh.to(dev), res.to(dev)
+        check(L.capnet_conv1x1_fwd_bf16x6(ptr(xd), H * W * Cin, W * Cin, Cin, ptr(img), bn, ptr(y), ptr(sd), ptr(hd),
+                                          int(pre), None, None, B, H, W, Cin, Cout, stride, ptr(scd), ptr(shd),
+                                          ptr(rd), 1, current_stream()))
+        want = torch.relu(ref * sc.double() + sh.double() + res.double())
+        assert rel_err(y, want) < 3e-6
+        return
+    psum = torch.full((tiles, Cout), float("nan"), device=dev)
+    psq = torch.full((tiles, Cout), float("nan"), device=dev)
+    check(L.capnet_conv1x1_fwd_bf16x6(ptr(xd), H * W * Cin, W * Cin, Cin, ptr(img), bn, ptr(y), ptr(sd), ptr(hd),
+                                      int(pre), ptr(psum), ptr(psq), B, H, W, Cin, Cout, stride, None, None, None, 0,
+                                      current_stream()))
+    assert rel_err(y, ref) < 3e-6                      # the bound the f32-MFMA conv kernels are held to
+    # fp32-grade: rms error against fp64 not above that of the f32-MFMA kernel on the same operands
+    # (an fp32 dot product of these lengths and this dynamic range sits at 1e-7 .. 6e-7)
+    rms = lambda t: (((t.double().cpu() - ref) ** 2).mean().sqrt() / (ref ** 2).mean().sqrt()).item()
+    wk = ops.pack_conv_weight(w.to(dev), Cin, kmajor=True)
+    y32 = torch.empty((M, Cout), device=dev)
+    t32 = lib().capnet_conv_kmajor_tiles_m(M, Cout, Cin, 0)
+    p1, p2 = torch.empty(t32, Cout, device=dev), torch.empty(t32, Cout, device=dev)
+    check(lib().capnet_conv2d_fwd_kmajor(ptr(xd), H * W * Cin, W * Cin, Cin, ptr(wk), Cin, ptr(y32), ptr(sd), ptr(hd),
+                                         int(pre), ptr(p1), ptr(p2), B, H, W, Cin, Cout, 1, 1, stride, 0, 0, None,
+                                         current_stream()))
+    print("rms vs fp64: split-bf16 %.2e, f32 MFMA %.2e" % (rms(y), rms(y32)))
+    assert rms(y) < 1.25 * rms(y32) + 2e-8
+    assert rel_err(psum.sum(0), ref.sum(0)) < 1e-5
+    assert rel_err(psq.sum(0), (ref ** 2).sum(0)) < 1e-5

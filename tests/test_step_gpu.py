@@ -474,3 +474,41 @@ def test_pipelined_loop_keeps_each_batch_with_its_captions(dev):
     assert min(abs(seq[i] - seq[j]) for i in range(n) for j in range(i)) > 0.1     # distinguishable
     for a, b in zip(got, seq):
         assert abs(a - b) / abs(b) < 2e-5
+
+
+def test_decoder_beside_trunk_passes_is_reproducible(dev):
+    """The trainable half runs on its own stream beside the trunk passes of the following batches
+    (TrunkPipeline), i.e. its workgroups share CUs with the conv kernels. A decoder forward beside three
+    trunk passes must return exactly what it returns alone -- a first split-bf16 conv kernel that
+    streamed its weights by LDS-DMA changed single attention scores of co-resident workgroups
+    (csrc/conv_bf16x6.hip, tools/victim2.py); this keeps watch over every conv kernel of the trunk."""
+    from capnet import model_att
+    V, B = 1000, 4
+    enc, _, dec, _ = _att_modules(V, dev)
+    enc.to(dev).train()
+    dec.to(dev).train()
+    imgs, caps, lens = synthetic.make_batch(B, V, seed=40)
+    feats = enc(imgs.to(dev))
+    lens1 = [l - 1 for l in lens]
+    random.seed(6)
+    tf = [random.random() < 0.8 for _ in range(24)]
+    cin = caps[:, :-1].contiguous().to(dev)
+
+    def fwd():
+        with torch.no_grad():
+            return dec(cin, lens1, feats, tf_mask=tf)
+    ref_out, ref_al = fwd()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream(priority=-1)
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    other = [synthetic.make_batch(B, V, seed=50 + k)[0].to(dev) for k in range(3)]
+    for rep in range(6):
+        for k, st in enumerate(streams):
+            st.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st):
+                enc(other[k], slot=k, defer_stats=True)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            out, al = fwd()
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref_out) and torch.equal(al, ref_al), rep

@@ -1,0 +1,69 @@
+import sys, torch, ctypes as C
+sys.path.insert(0, '/root/repo')
+import capnet
+from capnet import ops
+from capnet._lib import check, lib, ptr
+dev = torch.device('cuda:0'); L = lib()
+side = torch.cuda.Stream(priority=-1); other = torch.cuda.Stream()
+Bc, H, Cin, Cout = 64, 28, 512, 128
+M = Bc * H * H
+x = torch.randn(Bc, H, H, Cin, device=dev); w = torch.randn(Cout, Cin, device=dev) * 0.05
+y = torch.empty(M, Cout, device=dev)
+t = L.capnet_conv1x1_tiles_m(M)
+ps, pq = torch.empty(t, Cout, device=dev), torch.empty(t, Cout, device=dev)
+img = torch.empty(L.capnet_conv1x1_bf16x6_weight_words(Cin, Cout), dtype=torch.int32, device=dev)
+check(L.capnet_conv1x1_bf16x6_pack(ptr(w), ptr(img), Cout, Cin, 64, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+KIND = sys.argv[1] if len(sys.argv) > 1 else "x6"
+from capnet import ops as _ops
+Ag = torch.randn(999, 512, device=dev); Wg = torch.randn(8192, 512, device=dev) * 0.05; Og = torch.empty(999, 8192, device=dev)
+wk = _ops.pack_conv_weight(w.reshape(Cout, Cin, 1, 1), Cin, kmajor=True)
+def noise():
+    s = C.c_void_p(other.cuda_stream)
+    if KIND == "dma_gemm":
+        for _ in range(40):
+            check(L.capnet_sgemm_nt_dma(999, 8192, 512, ptr(Ag), 512, ptr(Wg), ptr(Og), None, s))
+        return
+    if KIND == "kmajor":
+        for _ in range(60):
+            check(L.capnet_conv2d_fwd_kmajor(ptr(x), H * H * Cin, H * Cin, Cin, ptr(wk), Cin, ptr(y), None, None, 0, ptr(ps), ptr(pq),
+                                             Bc, H, H, Cin, Cout, 1, 1, 1, 0, 12864, None, s))
+        return
+    if KIND == "wino":
+        return
+    for _ in range(60):
+        check(L.capnet_conv1x1_fwd_bf16x6(ptr(x), H * H * Cin, H * Cin, Cin, ptr(img), 64, ptr(y), None, None, 0, ptr(ps), ptr(pq),
+                                          Bc, H, H, Cin, Cout, 1, None, None, None, 0, s))
+g = torch.Generator().manual_seed(1)
+att1 = torch.randn(4, 196, 512, generator=g).to(dev); feat = torch.rand(4, 196, 2048, generator=g).to(dev)
+z0 = torch.randn(4, 512 + 2048, generator=g).to(dev); wf = (torch.randn(1, 512, generator=g) * 0.1).to(dev); bfv = torch.zeros(1, device=dev)
+# raw C calls with persistent buffers (no torch kernels on the side stream besides the copy of z)
+s_rows, P, A, Cd = 4, 196, 512, 2048
+def run(stream, bufs):
+    z, alpha, abt, awe, xa, esc = bufs
+    z.copy_(z0)
+    check(L.capnet_att_step_fwd(ptr(att1), ptr(feat), ptr(z), C.c_void_p(z.data_ptr() + 4 * A), z.shape[1], ptr(wf.reshape(-1)), ptr(bfv), s_rows, P, A, Cd,
+                                ptr(alpha), ptr(abt), 1, 0, ptr(awe), ptr(xa), Cd, ptr(esc), C.c_void_p(stream.cuda_stream)))
+def mk():
+    return (torch.empty_like(z0), torch.empty(s_rows, P, device=dev), torch.empty(s_rows, 1, P, device=dev), torch.empty(s_rows, Cd, device=dev),
+            torch.empty(s_rows, Cd, device=dev), torch.empty(s_rows, P, device=dev))
+ref = mk(); run(torch.cuda.current_stream(), ref); torch.cuda.synchronize()
+names = ["z(gate)", "alpha", "alphas_bt", "awe", "xa", "escore"]
+tot = {n: 0 for n in names}
+for rep in range(5):
+    other.wait_stream(torch.cuda.current_stream()); side.wait_stream(torch.cuda.current_stream())
+    sets = [mk() for _ in range(20)]
+    with torch.cuda.stream(other):
+        noise()
+    with torch.cuda.stream(side):
+        for b in sets:
+            run(side, b)
+    torch.cuda.synchronize()
+    for b in sets:
+        for n, a, r in zip(names, b, ref):
+            if not torch.equal(a, r):
+                tot[n] += 1
+                if tot[n] <= 2:
+                    d = (a - r).abs()
+                    idx = torch.nonzero(d > 0)
+                    print("  ", n, "differs in", idx.shape[0], "elements; first", idx[0].tolist(), "got", float(a[tuple(idx[0])]), "want", float(r[tuple(idx[0])]))
+print("mismatching buffers out of 100:", tot)
