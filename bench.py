@@ -25,6 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_F32_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: FP32 matrix peak (dense)
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # same guide: BF16 MFMA, dense
 
 
 def parse():
@@ -330,12 +331,15 @@ def main():
         if n.value > 0:
             achieved = fl.value / (ms.value * 1e-3) / 1e12
             roofline = {"bound": "mfma",
-                        "kernel": "the trunk's 155 conv launches: conv_f32_v2_kernel (implicit GEMM, "
-                                  "v_mfma_f32_32x32x2_f32) for the 1x1 / strided convs, conv_wino_kernel "
-                                  "(Winograd F(2x2,3x3), v_mfma_f32_16x16x4_f32) for the 45 stride-1 3x3 convs, "
-                                  "conv_f32_kernel for the 7x7 stem; a launch includes its tail fix-up if any",
-                        "flops": "ALGORITHMIC: 2*M*Cout*KH*KW*Cin of the direct sum (SURVEY 8d: 23.02 GFLOP per image); "
-                                 "the Winograd launches execute 2.25x fewer multiplies than counted",
+                        "kernel": "the trunk's 155 conv launches: conv1x1_bf16x6_kernel (the 104 1x1 convs: six "
+                                  "v_mfma_f32_32x32x16_bf16 products of 3-way split fp32 operands, fp32-grade "
+                                  "results), conv_wino_kernel (Winograd F(2x2,3x3), v_mfma_f32_16x16x4_f32) for the "
+                                  "45 stride-1 3x3 convs, conv_f32_v2_kernel (implicit GEMM, v_mfma_f32_32x32x2_f32) "
+                                  "for the strided / 7x7-map 3x3 convs, conv_f32_kernel for the 7x7 stem; a launch "
+                                  "includes its tail fix-up if any",
+                        "flops": "ALGORITHMIC: 2*M*Cout*KH*KW*Cin of the direct sum (SURVEY 8d: 23.02 GFLOP per image), "
+                                 "priced against the f32 matrix peak the reference's arithmetic would need; what the "
+                                 "pipes executed is in `executed`",
                         "how": "HIP events around every conv launch of the timed region, on its launch stream; "
                                "duration = time with at least one conv launch running (union of the "
                                "intervals: two trunk passes are in flight, their launches overlap)",
@@ -344,17 +348,30 @@ def main():
                         "traffic_source": pmc_traffic()[1],
                         "launches": n.value, "avg_launch_us": round(ms.value * 1e3 / n.value, 2),
                         "flops_per_launch": fl.value / n.value}
-            # multiplies actually issued: the Winograd launches (weight image kind 2) do 16 per 2x2
-            # outputs and input channel instead of 36
-            algo = execd = 0.0
+            # What the matrix pipes executed. Weight image kind 2 = Winograd: 16 multiplies per 2x2
+            # outputs and input channel instead of 36, f32 MFMA. Kind 4 = split-bf16 1x1 conv: six
+            # bf16 products per multiply on the bf16 pipe (peak 2.5 PFLOP/s dense). Everything else:
+            # f32 MFMA as counted. `frac` = time the two pipes would need at their peaks / conv time.
+            algo = f32x = bf16x = 0.0
             for i in range(lib.capnet_trunk_num_convs(plan["handle"])):
                 fi = lib.capnet_trunk_conv_flops(plan["handle"], i)
+                kind = lib.capnet_trunk_conv_kmajor(plan["handle"], i)
                 algo += fi
-                execd += fi / (2.25 if lib.capnet_trunk_conv_kmajor(plan["handle"], i) == 2 else 1.0)
-            roofline["executed"] = {"achieved": round(achieved * execd / algo, 2),
-                                    "frac": round(achieved * execd / algo / MFMA_F32_PEAK_TFLOPS, 4),
-                                    "note": "MFMA flops issued per second (Winograd layers counted at 16/36 of "
-                                            "their direct-sum flops): what the matrix pipe itself sustains"}
+                if kind == 4:
+                    bf16x += 6.0 * fi
+                else:
+                    f32x += fi / (2.25 if kind == 2 else 1.0)
+            per_s = achieved / algo          # TFLOP/s per algorithmic flop of a pass
+            roofline["executed"] = {
+                "f32_mfma": {"achieved": round(f32x * per_s, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "share_of_algorithmic_flops": round((algo - bf16x / 6.0) / algo, 4)},
+                "bf16_mfma": {"achieved": round(bf16x * per_s, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                              "share_of_algorithmic_flops": round(bf16x / 6.0 / algo, 4)},
+                "frac": round(f32x * per_s / MFMA_F32_PEAK_TFLOPS + bf16x * per_s / MFMA_BF16_PEAK_TFLOPS, 4),
+                "note": "flops the matrix pipes issued per second of conv time: Winograd layers at 16/36 of "
+                        "their direct-sum flops on the f32 pipe, the 1x1 layers at 6 bf16 products per multiply "
+                        "on the bf16 pipe (fp32-grade results, csrc/conv_bf16x6.hip); frac = sum over the two "
+                        "pipes of issued / peak"}
             if pipe is not None:
                 # In the timed region the convolutions share the chip with the previous batch's
                 # decoder (that is where the throughput comes from, and it lengthens each conv a

@@ -30,9 +30,12 @@ def test_bench_prints_one_json_line():
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["unit"] == "images/sec" and d["scaling"] == "weak"
     assert d["value"] > 0 and math.isfinite(d["loss_last"]) and d["dtype"] == "f32"
     r = d["roofline"]
-    # `frac` credits the Winograd launches with the direct sum's flops; `executed` is what the
-    # matrix pipe issued: neither may reach the peak
-    assert r["bound"] == "mfma" and 0 < r["executed"]["frac"] < r["frac"] < 1
+    # `frac` prices the direct sum's flops against the f32 matrix peak (the Winograd layers issue 16/36
+    # of them, the split-bf16 1x1 layers run on the bf16 pipe at up to 2.67x the f32 rate, so it is not
+    # bounded by 1); `executed.frac` = issued / peak summed over the two pipes, which is
+    e = r["executed"]
+    assert r["bound"] == "mfma" and 0 < e["frac"] < 1 and 0 < r["frac"] < 2.67
+    assert e["f32_mfma"]["achieved"] < e["f32_mfma"]["peak"] and e["bf16_mfma"]["achieved"] < e["bf16_mfma"]["peak"]
     assert r["traffic"] is None or "offline" in r["traffic_source"]
     assert d["roofline_lstm_step"]["bound"] == "hbm"
 
