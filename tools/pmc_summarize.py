@@ -3,7 +3,7 @@ tools/pmc_traffic.sh. Corrections per /opt/skills/guides/MI355X_MICROARCH.md (HB
 FETCH_SIZE is reported in KB and counts 64 B per 128-B request on gfx950 for wide coalesced
 reads -> doubled; WRITE_SIZE (KB) is exact for 16-B-per-lane stores.
 
-usage: python tools/pmc_summarize.py gpurun_out/pmc > profiles/round1_pmc_traffic.json
+usage: python tools/pmc_summarize.py gpurun_out/pmc > profiles/round2_pmc_traffic.json
 """
 import csv
 import glob
@@ -20,7 +20,7 @@ def collect(d, counter):
     for r in csv.DictReader(open(path[0])):
         if r["Counter_Name"] != counter:
             continue
-        name = r["Kernel_Name"].split("(")[0]
+        name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
         a = per.setdefault(name, [0, 0.0])
         a[0] += 1
         a[1] += float(r["Counter_Value"])
@@ -32,7 +32,7 @@ def main():
     fetch = collect(os.path.join(root, "fetch"), "FETCH_SIZE")
     write = collect(os.path.join(root, "write"), "WRITE_SIZE")
     if len(sys.argv) > 2 and sys.argv[2] == "--per-kernel":
-        # raw per-kernel sums (profiles/round1_pmc_per_kernel.csv)
+        # raw per-kernel sums (profiles/round2_pmc_per_kernel.csv)
         print("# rocprofv3 --kernel-trace --pmc FETCH_SIZE (pass 1) / WRITE_SIZE (pass 2) -- python3 bench.py "
               "--steps 2 --warmup 1 --no-cpu-baseline --no-conv-events --no-lstm-roofline")
         print("# raw counter sums in KB over the run (pipelined: 3 + 3 trunk passes, 3 decoder steps); FETCH_SIZE "
@@ -41,14 +41,21 @@ def main():
         for k, v in sorted(fetch.items(), key=lambda kv: -(2 * kv[1][1] + write.get(kv[0], [0, 0])[1]))[:14]:
             print("%s,%d,%.0f,%.0f" % (k.replace(",", ";"), v[0], v[1], write.get(k, [0, 0])[1]))
         return
-    conv = lambda n: "conv_f32" in n or "conv_wino" in n or "conv_tail_fixup" in n
-    launches = sum(v[0] for k, v in fetch.items() if "conv_f32" in k or "conv_wino" in k)   # fix-ups belong to a conv
+    conv = lambda n: "conv_f32" in n or "conv_wino" in n or "conv_tail_fixup" in n or "conv1x1_bf16x6_kernel" in n
+    launches = sum(v[0] for k, v in fetch.items()
+                   if "conv_f32" in k or "conv_wino" in k or "conv1x1_bf16x6_kernel" in k)   # fix-ups belong to a conv
     wino = lambda n: "conv_wino" in n
     wino_n = sum(v[0] for k, v in fetch.items() if wino(k))
     wino_bytes = (2.0 * sum(v[1] for k, v in fetch.items() if wino(k)) +
                   sum(v[1] for k, v in write.items() if wino(k))) * 1024.0
     fetch_kb = sum(v[1] for k, v in fetch.items() if conv(k))
     write_kb = sum(v[1] for k, v in write.items() if conv(k))
+    x6 = lambda n: "conv1x1_bf16x6_kernel" in n
+    x6_n = sum(v[0] for k, v in fetch.items() if x6(k))
+    x6_bytes = (2.0 * sum(v[1] for k, v in fetch.items() if x6(k)) + sum(v[1] for k, v in write.items() if x6(k))) * 1024.0
+    lp = lambda n: "lstm_persist_kernel" in n
+    lp_n = sum(v[0] for k, v in fetch.items() if lp(k))
+    lp_bytes = (2.0 * sum(v[1] for k, v in fetch.items() if lp(k)) + sum(v[1] for k, v in write.items() if lp(k))) * 1024.0
     ls = lambda n: "lstm_step_fused_kernel" in n
     ls_n = sum(v[0] for k, v in fetch.items() if ls(k))
     ls_bytes = (2.0 * sum(v[1] for k, v in fetch.items() if ls(k)) +
@@ -63,6 +70,10 @@ def main():
         "algorithmic_bytes_per_launch": round((232e6 + 2 * 90e6 * 64) / 155),
         "winograd_launches": wino_n,
         "winograd_bytes_per_launch": round(wino_bytes / max(wino_n, 1)),
+        "bf16x6_launches": x6_n,
+        "bf16x6_bytes_per_launch": round(x6_bytes / max(x6_n, 1)),
+        "lstm_persist_launches": lp_n,
+        "lstm_persist_bytes_per_launch": round(lp_bytes / max(lp_n, 1)),
         "lstm_step_launches": ls_n,
         "lstm_step_bytes_per_launch": round(ls_bytes / max(ls_n, 1)),
         "note": "FETCH_SIZE doubled (gfx950 tallies 128-B read requests at 64 B); per conv launch incl. "

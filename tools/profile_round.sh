@@ -11,6 +11,9 @@ mkdir -p $OUT
 cd $ROOT
 timeout -k 10 400 python bench.py 2> $OUT/bench_default.log | tail -1 > $OUT/bench_default.json || exit 1
 timeout -k 10 300 python bench.py --decoder att --no-cpu-baseline 2> $OUT/bench_att.log | tail -1 > $OUT/bench_att.json || exit 1
+# SURVEY 8(d) Config 4: the attention decoder at 12 images per GPU (global 96 on 8 GPUs) and at 96 per GPU
+timeout -k 10 300 python bench.py --decoder att --batch 12 --no-cpu-baseline --no-lstm-roofline 2> $OUT/bench_att_b12.log | tail -1 > $OUT/bench_att_b12.json || exit 1
+timeout -k 10 300 python bench.py --decoder att --batch 96 --steps 40 --no-cpu-baseline --no-lstm-roofline 2> $OUT/bench_att_b96.log | tail -1 > $OUT/bench_att_b96.json || exit 1
 timeout -k 10 300 python bench.py --decoder nic --no-cpu-baseline 2> $OUT/bench_nic.log | tail -1 > $OUT/bench_nic.json || exit 1
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- \

@@ -16,7 +16,7 @@ def main():
     print(f"# MI355X (gfx950); all kernels of the run, total kernel time {total / 1e6:.3f} ms")
     print("# columns: kernel, calls, total_ms, avg_us, pct")
     for r in rows:
-        name = re.sub(r"\(.*", "", r["Name"]).replace(",", ";").strip()
+        name = re.sub(r"\(.*", "", r["Name"].replace("(anonymous namespace)::", "")).replace(",", ";").strip()
         print(f"{name},{int(r['Calls'])},{float(r['TotalDurationNs']) / 1e6:.3f},"
               f"{float(r['AverageNs']) / 1e3:.2f},{float(r['Percentage']):.2f}")
 
