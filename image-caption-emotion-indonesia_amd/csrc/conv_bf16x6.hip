@@ -67,8 +67,9 @@ struct XArgs {
   const float* res;
   int relu_out;
   int M, Cin, Cout, relu_in;
-  int abl;   // diagnostics (CAPNET_X6_ABLATE): 1 no DMA, 2 no A cell writes, 4 no statistics, 8 no output stores
+  int abl;   // diagnostics (CAPNET_X6_ABLATE, persistent kernel): 4 no statistics, 8 no output stores
   int tiles_m, tiles_n;
+  long long* stamps;   // diagnostics (CAPNET_X6_STAMPS = device address): workgroup 0 records 4 clock values per step
   unsigned tn_mul, tn_sh;
   int OW, OHW, stride, sxb, sxh, sxw;
   unsigned ohw_mul, ohw_sh, ow_mul, ow_sh;
@@ -280,6 +281,310 @@ __global__ __launch_bounds__(256, 3) void conv1x1_bf16x6_kernel(const XArgs g) {
   }
 }
 
+// ---- persistent version -------------------------------------------------------------------------
+// Same tile, LDS image and MFMA order; what changes is the pipeline around them (SQ counters of the
+// kernel above on 14x14x256 -> 1024: matrix pipe busy 30 % of the time, waves waiting on vmcnt half
+// of theirs -- one k-tile of MFMAs, 0.3 us, does not cover a global load issued one tile ahead):
+//   * a workgroup walks tiles w = blockIdx.x, + gridDim.x, ...; the (tile, k-tile) steps form ONE
+//     software pipeline, so the first loads of the next tile are in flight during the last k-tiles and
+//     the epilogue of this one;
+//   * loads run TWO steps ahead in two register sets; waits are counted (vmcnt retires in issue
+//     order, stores included): vmcnt(NLD) leaves exactly the younger set in flight. After an epilogue
+//     of 64 stores the next two waits use vmcnt(63) (the wanted loads are older than the stores), the
+//     third finds the stores retired;
+//   * fold + split of step s+1 (VALU) is interleaved with the MFMAs of step s by the scheduler hints.
+template <int NBR, bool PRE>
+struct XRegs {
+  f32x4 a0, a1, b[NBR], sc0, sc1, sh0, sh1;
+};
+
+template <int N> __device__ __forceinline__ void x_wait_vmcnt_plain() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int BN, bool PRE>
+__global__ __launch_bounds__(256, 2) void conv1x1_bf16x6_p_kernel(const XArgs g) {
+  constexpr int NT = BN / 64;
+  constexpr int kPlaneB = BN * 2 * 16;
+  constexpr int kImgA = 3 * kPlaneA, kImgB = 3 * kPlaneB;
+  constexpr int kStage = kImgA + kImgB;
+  constexpr int NBR = (kImgB / 16 + 255) / 256;     // 16-B cells of the B image per thread
+  constexpr int NLD = NBR + 2 + (PRE ? 4 : 0);      // loads of one step
+  // the wait that must leave one step's loads AND a plain epilogue's 32 NT stores in flight (6-bit counter)
+  constexpr int kWaitEpi = NLD + 32 * NT > 63 ? 63 : NLD + 32 * NT;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kStage + 4 * BN * 4];
+  float* scratch = reinterpret_cast<float*>(lds + 2 * kStage);
+  __shared__ long long st[4 * 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+  const bool diag = g.stamps != nullptr && blockIdx.x == 0;
+  auto stamp = [&](int it, int j) {
+    if (diag && it < 64) {
+      const long long t = __builtin_readcyclecounter();
+      if (tid == 0) st[4 * it + j] = t;
+    }
+  };
+  const int total = g.tiles_m * g.tiles_n, G = (int)gridDim.x;
+  const int nk = g.Cin / XBK;
+  const int my_tiles = (total - 1 - (int)blockIdx.x) / G + 1;
+  const int n_it = my_tiles * nk;
+
+  const int arow = tid >> 1, ac = tid & 1;
+  const unsigned awr = x_cell(arow, ac);
+  const float lo = g.relu_in ? 0.f : -__builtin_inff();
+
+  // ---- issue cursor: two steps ahead of the MFMAs
+  int iw = (int)blockIdx.x, ikt = 0;
+  unsigned i_avoff = 0;
+  const float* i_sA = g.x;
+  const float* i_sB = nullptr;
+  const float* i_sS = g.in_scale;
+  const float* i_sT = g.in_shift;
+  auto i_tile = [&]() {
+    const int id = xcd_remap(iw, total);
+    const int tm = (int)fast_div((unsigned)id, g.tn_mul, g.tn_sh), tn = id - tm * g.tiles_n;
+    const int am = tm * XBM + arow;
+    i_avoff = (x_row_offset(g, am < g.M ? am : g.M - 1) + 8u * ac) * 4u;   // rows past M: a valid row, zeroed in the epilogue
+    i_sA = g.x;
+    i_sB = reinterpret_cast<const float*>(g.wimg) + ((long)tn * nk) * (kImgB / 4);
+    i_sS = g.in_scale;
+    i_sT = g.in_shift;
+  };
+  i_tile();
+  auto issue = [&](XRegs<NBR, PRE>& R) {
+#pragma unroll
+    for (int q = 0; q < NBR; ++q) {
+      const int cell = tid + 256 * q;
+      gload16(R.b[q], i_sB, (unsigned)((cell < kImgB / 16 ? cell : 0) * 16));
+    }
+    gload16(R.a0, i_sA, i_avoff);
+    gload16(R.a1, i_sA + 4, i_avoff);
+    if (PRE) {
+      gload16(R.sc0, i_sS, (unsigned)(32 * ac));
+      gload16(R.sc1, i_sS + 4, (unsigned)(32 * ac));
+      gload16(R.sh0, i_sT, (unsigned)(32 * ac));
+      gload16(R.sh1, i_sT + 4, (unsigned)(32 * ac));
+      i_sS += XBK;
+      i_sT += XBK;
+    }
+    i_sB += kImgB / 4;
+    i_sA += XBK;
+    if (++ikt == nk) {          // next tile (past the last one: the same tile again, loads nobody uses)
+      ikt = 0;
+      if (iw + G < total) iw += G;
+      i_tile();
+    }
+  };
+  // the registers of R become defined for the compiler HERE (they were written by asm loads)
+  auto landed = [&](XRegs<NBR, PRE>& R) {
+    if (PRE) asm volatile("" : "+v"(R.a0), "+v"(R.a1), "+v"(R.sc0), "+v"(R.sc1), "+v"(R.sh0), "+v"(R.sh1)::"memory");
+    else asm volatile("" : "+v"(R.a0), "+v"(R.a1)::"memory");
+#pragma unroll
+    for (int q = 0; q < NBR; ++q) asm volatile("" : "+v"(R.b[q]));
+  };
+  auto store = [&](XRegs<NBR, PRE>& R, int stage) {
+#pragma unroll
+    for (int q = 0; q < NBR; ++q) {
+      const int cell = tid + 256 * q;
+      if ((kImgB / 16) % 256 == 0 || cell < kImgB / 16)
+        *reinterpret_cast<f32x4*>(lds + stage * kStage + kImgA + cell * 16) = R.b[q];
+    }
+    float x[8] = {R.a0[0], R.a0[1], R.a0[2], R.a0[3], R.a1[0], R.a1[1], R.a1[2], R.a1[3]};
+    if (PRE) {
+      const float s[8] = {R.sc0[0], R.sc0[1], R.sc0[2], R.sc0[3], R.sc1[0], R.sc1[1], R.sc1[2], R.sc1[3]};
+      const float t[8] = {R.sh0[0], R.sh0[1], R.sh0[2], R.sh0[3], R.sh1[0], R.sh1[1], R.sh1[2], R.sh1[3]};
+#pragma unroll
+      for (int i = 0; i < 8; ++i) x[i] = fmaxf(fmaf(x[i], s[i], t[i]), lo);
+    }
+    u32x4 ph, pm, pl;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      unsigned h, m, l;
+      split_pair(x[2 * i], x[2 * i + 1], h, m, l);
+      ph[i] = h; pm[i] = m; pl[i] = l;
+    }
+    unsigned char* d = lds + stage * kStage + awr;
+    *reinterpret_cast<u32x4*>(d) = ph;
+    *reinterpret_cast<u32x4*>(d + kPlaneA) = pm;
+    *reinterpret_cast<u32x4*>(d + 2 * kPlaneA) = pl;
+  };
+
+  f32x16 acc[2][NT];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+  };
+  zero_acc();
+
+  const unsigned char* a_rd = lds + x_cell(wm * 64 + li, lh);
+  const unsigned char* b_rd = lds + kImgA + x_cell(wn * (BN / 2) + li, lh);
+  auto compute = [&](int stage) {
+    bf16x8 af[2][3], bf[NT][3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+        af[mt][p] = *reinterpret_cast<const bf16x8*>(a_rd + stage * kStage + p * kPlaneA + mt * 1024);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        bf[nt][p] = *reinterpret_cast<const bf16x8*>(b_rd + stage * kStage + p * kPlaneB + nt * 1024);
+    }
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
+    constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+    for (int term = 0; term < 6; ++term)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt][PA[term]], bf[nt][PB[term]], acc[mt][nt], 0, 0, 0);
+  };
+
+  // ---- compute cursor
+  int cw = (int)blockIdx.x, ckt = 0;
+  int after_epi = 0;         // waits still to be taken with the epilogue's 64 stores counted in
+  auto epilogue = [&]() {
+    const int id = xcd_remap(cw, total);
+    const int tm = (int)fast_div((unsigned)id, g.tn_mul, g.tn_sh), tn = id - tm * g.tiles_n;
+    const int m0 = tm * XBM, n0 = tn * BN;
+    const bool ragged = m0 + XBM > g.M;
+    const bool plain = !ragged && !g.out_scale;
+    const unsigned rstep = (unsigned)g.Cout * 4u;
+    if (ragged) {
+      // rows past M were computed from a clamped row: keep them out of the statistics
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const int row0 = m0 + wm * 64 + mt * 32 + 4 * lh;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = row0 + (r & 3) + 8 * (r >> 2);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[mt][nt][r] = row < g.M ? acc[mt][nt][r] : 0.f;
+        }
+      }
+    }
+    if (plain && (g.abl & 8)) {
+    } else if (plain) {
+      // 32 NT unconditional stores (the count the waits after this epilogue rely on)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int n = n0 + wn * (BN / 2) + nt * 32 + li;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          unsigned off = ((unsigned)(m0 + wm * 64 + mt * 32 + 4 * lh) * (unsigned)g.Cout + (unsigned)n) * 4u;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            asm volatile("global_store_dword %0, %1, %2" ::"v"(off), "v"(acc[mt][nt][r]), "s"(g.y) : "memory");
+            off += ((r & 3) == 3 ? 5u : 1u) * rstep;
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int n = n0 + wn * (BN / 2) + nt * 32 + li;
+        const float osc = g.out_scale ? g.out_scale[n] : 1.f, osh = g.out_scale ? g.out_shift[n] : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          int row = m0 + wm * 64 + mt * 32 + 4 * lh;
+          unsigned off = ((unsigned)row * (unsigned)g.Cout + (unsigned)n) * 4u;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            if (row < g.M) {
+              float v = acc[mt][nt][r];
+              if (g.out_scale) {
+                v = fmaf(v, osc, osh);
+                if (g.res) v += *reinterpret_cast<const float*>(reinterpret_cast<const char*>(g.res) + off);
+                if (g.relu_out) v = fmaxf(v, 0.f);
+              }
+              asm volatile("global_store_dword %0, %1, %2" ::"v"(off), "v"(v), "s"(g.y) : "memory");
+            }
+            if ((r & 3) == 3) { row += 5; off += 5u * rstep; } else { row += 1; off += rstep; }
+          }
+        }
+      }
+    }
+    if (g.part_sum && !(g.abl & 4)) {
+      using T = TileCfg<XBM, BN, 16>;
+      block_col_stats<T>(acc, scratch, g.part_sum + (long)tm * g.Cout, g.part_sq + (long)tm * g.Cout, n0, g.Cout);
+      __syncthreads();       // scratch is reused by the next tile's statistics
+    }
+    zero_acc();
+    // a plain tile put exactly 16 * 2 * NT stores behind the loads in flight; anything else (ragged rows,
+    // the folded epilogue's own loads) is not counted on: the next wait drains the queue
+    after_epi = (plain && !(g.abl & 8)) ? 2 : -1;
+  };
+
+  // Loads are only ever issued for steps that exist: a register written by a load nobody consumes is free
+  // for the compiler to reuse at once, and the load would land in whatever lives there by then.
+  XRegs<NBR, PRE> R0, R1;
+  issue(R0);
+  if (n_it > 1) {
+    issue(R1);
+    x_wait_vmcnt_plain<NLD>();
+  } else {
+    x_wait_vmcnt_plain<0>();
+  }
+  landed(R0);
+  store(R0, 0);
+  if (n_it > 2) issue(R0);
+  __syncthreads();
+
+  // nk is even (the launcher sends odd k-tile counts to the one-tile kernel), so a tile ends only behind
+  // the second step of a pair: one copy of the epilogue. landed + store are unconditional -- the last
+  // step of a workgroup re-stores stale registers into the stage nobody reads again -- because a branch
+  // there splits the block and the scheduler can no longer put the split's VALU between the MFMAs.
+  auto step = [&](XRegs<NBR, PRE>& R, int stage, int it, bool tile_may_end) {
+    // LDS[stage] holds step `it`; R holds step it + 1 (issued two steps ago) and goes to LDS[1 - stage]
+    stamp(it, 0);
+    if (it + 2 >= n_it) { x_wait_vmcnt_plain<0>(); after_epi = 0; }     // nothing younger in flight
+    else if (after_epi > 0) { x_wait_vmcnt_plain<kWaitEpi>(); --after_epi; }
+    else if (after_epi < 0) { x_wait_vmcnt_plain<0>(); after_epi = 0; }
+    else x_wait_vmcnt_plain<NLD>();
+    stamp(it, 1);
+    landed(R);
+    compute(stage);
+    store(R, 1 - stage);
+    // All fragment reads first (read just in time, every MFMA that opens a new plane waited ~100 cycles for
+    // the LDS); then one MFMA (8 of its 32 cycles hold the vector issue) and the VALU that fits in the rest.
+    __builtin_amdgcn_sched_group_barrier(0x100, 6 + 3 * NT, 0);
+    __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);      // (the fold, while the fragments are on their way)
+#pragma unroll
+    for (int i = 0; i < 12 * NT; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, NT == 2 ? 4 : 8, 0);
+      if (i == 6 * NT) __builtin_amdgcn_sched_group_barrier(0x200, NBR, 0);     // the weight cells, mid-way
+    }
+    __builtin_amdgcn_sched_group_barrier(0x200, 3, 0);
+    stamp(it, 2);
+    if (it + 3 < n_it) issue(R);
+    stamp(it, 3);
+    __syncthreads();
+    ++ckt;
+    if (tile_may_end && ckt == nk) {
+      epilogue();
+      ckt = 0;
+      cw += G;
+    }
+  };
+  for (int it = 0; it < n_it; it += 2) {
+    step(R1, 0, it, false);
+    step(R0, 1, it + 1, true);
+  }
+  if (diag) {
+    __syncthreads();
+    if (tid < 64) {
+      for (int j = 0; j < 4; ++j) g.stamps[4 * tid + j] = st[4 * tid + j];
+    }
+  }
+  x_wait_vmcnt_plain<0>();       // nothing of this workgroup may still be in flight when its LDS is handed on
+}
+
 // One thread per (tn, kt, plane, row, pos): 8 consecutive k of output channel n -> one 16-B cell.
 template <int BN>
 __global__ __launch_bounds__(256) void conv1x1_bf16x6_pack_kernel(const float* __restrict__ w, unsigned* __restrict__ img,
@@ -368,6 +673,7 @@ int conv1x1_fwd_bf16x6(const float* x, long sxb, long sxh, long sxw, const unsig
   a.out_scale = out_scale; a.out_shift = out_shift; a.res = res; a.relu_out = relu_out;
   CAPNET_REQUIRE(!out_scale || (out_shift && !part_sum), "conv1x1_fwd_bf16x6: folded epilogue takes no statistics");
   { const char* e = getenv("CAPNET_X6_ABLATE"); a.abl = e ? atoi(e) : 0; }
+  { const char* e = getenv("CAPNET_X6_STAMPS"); a.stamps = e ? reinterpret_cast<long long*>(strtoull(e, nullptr, 0)) : nullptr; }
   a.M = Bn * OH * OW; a.Cin = Cin; a.Cout = Cout; a.relu_in = relu_in;
   a.tiles_m = cdiv(a.M, XBM); a.tiles_n = Cout / bn;
   magic_div((unsigned)a.tiles_n, &a.tn_mul, &a.tn_sh);
@@ -375,7 +681,26 @@ int conv1x1_fwd_bf16x6(const float* x, long sxb, long sxh, long sxw, const unsig
   a.sxb = (int)sxb; a.sxh = (int)sxh; a.sxw = (int)sxw;
   magic_div((unsigned)(OH * OW), &a.ohw_mul, &a.ohw_sh);
   magic_div((unsigned)OW, &a.ow_mul, &a.ow_sh);
-  const dim3 grid(a.tiles_m * a.tiles_n), block(256);
+  const dim3 block(256);
+  const char* v1 = getenv("CAPNET_X6_V1");         // A/B: the one-tile-per-workgroup kernel
+  if (!(v1 && v1[0] == '1') && (Cin / XBK) % 2 == 0) {
+    // persistent: two workgroups per CU walk the tiles (a multiple of 8, so that a workgroup stays on its XCD's
+    // share of the tile order)
+    const char* ge = getenv("CAPNET_X6_WGS");
+    const int cap = ge ? atoi(ge) : 512;
+    const int total = a.tiles_m * a.tiles_n;
+    const dim3 pgrid(total <= cap ? total : cap);
+    if (bn == 128) {
+      if (in_scale) hipLaunchKernelGGL((conv1x1_bf16x6_p_kernel<128, true>), pgrid, block, 0, stream, a);
+      else hipLaunchKernelGGL((conv1x1_bf16x6_p_kernel<128, false>), pgrid, block, 0, stream, a);
+    } else {
+      if (in_scale) hipLaunchKernelGGL((conv1x1_bf16x6_p_kernel<64, true>), pgrid, block, 0, stream, a);
+      else hipLaunchKernelGGL((conv1x1_bf16x6_p_kernel<64, false>), pgrid, block, 0, stream, a);
+    }
+    CAPNET_LAUNCH_CHECK();
+    return kOk;
+  }
+  const dim3 grid(a.tiles_m * a.tiles_n);
   if (bn == 128) {
     if (in_scale) hipLaunchKernelGGL((conv1x1_bf16x6_kernel<128, true>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((conv1x1_bf16x6_kernel<128, false>), grid, block, 0, stream, a);

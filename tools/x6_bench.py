@@ -16,9 +16,11 @@ B = 64
 SH = {"s1c1": (56, 256, 64, 1, 0), "s1c3": (56, 64, 256, 1, 1), "s2c1": (28, 512, 128, 1, 0), "s2c3": (28, 128, 512, 1, 1),
       "s3c1": (14, 1024, 256, 1, 0), "s3c3": (14, 256, 1024, 1, 1), "s4c1": (7, 2048, 512, 1, 0), "s4c3": (7, 512, 2048, 1, 1),
       "s2ds": (56, 256, 512, 2, 0), "s3ds": (28, 512, 1024, 2, 0), "s4ds": (14, 1024, 2048, 2, 0)}
+ONLY = os.environ.get("X6_ONLY")
 bns = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [64, 128]
 tot = {}
 for name, (H, Cin, Cout, stride, pre) in SH.items():
+    if ONLY and name not in ONLY.split(","): continue
     OH = (H - 1) // stride + 1
     M = B * OH * OH
     x = torch.randn(B, H, H, Cin, device=dev); w = torch.randn(Cout, Cin, device=dev) * 0.05
