@@ -89,10 +89,11 @@ __host__ __device__ inline unsigned x_cell(int row, int c) {
   return (unsigned)(((rg * 16 + r) * 2 + (c ^ ((r >> 3) & 1))) * 16);
 }
 
-__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
-  unsigned p;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(p) : "v"(a), "v"(b));
-  return p;
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {      // v_cvt_pk_bf16_f32 (round to nearest even)
+  const f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
 }
 
 // (x0, x1) -> packed bf16 pairs of the three pieces; the subtractions are exact in fp32
@@ -293,10 +294,11 @@ __global__ __launch_bounds__(256, 3) void conv1x1_bf16x6_kernel(const XArgs g) {
 //     of 64 stores the next two waits use vmcnt(63) (the wanted loads are older than the stores), the
 //     third finds the stores retired;
 //   * fold + split of step s+1 (VALU) is interleaved with the MFMAs of step s by the scheduler hints.
-template <int NBR, bool PRE>
+template <int NBR>
 struct XRegs {
-  f32x4 a0, a1, b[NBR], sc0, sc1, sh0, sh1;
+  f32x4 a0, a1, b[NBR];
 };
+constexpr int kFoldMax = 512;      // input channels whose BatchNorm scale / shift the persistent kernel keeps in LDS
 
 template <int N> __device__ __forceinline__ void x_wait_vmcnt_plain() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -309,11 +311,15 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16x6_p_kernel(const XArgs g)
   constexpr int kImgA = 3 * kPlaneA, kImgB = 3 * kPlaneB;
   constexpr int kStage = kImgA + kImgB;
   constexpr int NBR = (kImgB / 16 + 255) / 256;     // 16-B cells of the B image per thread
-  constexpr int NLD = NBR + 2 + (PRE ? 4 : 0);      // loads of one step
-  // the wait that must leave one step's loads AND a plain epilogue's 32 NT stores in flight (6-bit counter)
-  constexpr int kWaitEpi = NLD + 32 * NT > 63 ? 63 : NLD + 32 * NT;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kStage + 4 * BN * 4];
+  constexpr int NLD = NBR + 2;                      // loads of one step
+  // the wait that must leave one step's loads AND a plain epilogue's 8 NT stores in flight
+  constexpr int kWaitEpi = NLD + 8 * NT;
+  constexpr int kFold = PRE ? 2 * kFoldMax * 4 : 0;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kStage + 4 * BN * 4 + kFold];
   float* scratch = reinterpret_cast<float*>(lds + 2 * kStage);
+  // the previous BatchNorm's scale | shift, once per workgroup (every step re-read them through the
+  // vector memory path before: 4 of 9 loads, 16 KB of the 36 KB a step moved into registers)
+  const float* fold = reinterpret_cast<const float*>(lds + 2 * kStage + 4 * BN * 4);
   __shared__ long long st[4 * 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -339,8 +345,6 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16x6_p_kernel(const XArgs g)
   unsigned i_avoff = 0;
   const float* i_sA = g.x;
   const float* i_sB = nullptr;
-  const float* i_sS = g.in_scale;
-  const float* i_sT = g.in_shift;
   auto i_tile = [&]() {
     const int id = xcd_remap(iw, total);
     const int tm = (int)fast_div((unsigned)id, g.tn_mul, g.tn_sh), tn = id - tm * g.tiles_n;
@@ -348,11 +352,17 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16x6_p_kernel(const XArgs g)
     i_avoff = (x_row_offset(g, am < g.M ? am : g.M - 1) + 8u * ac) * 4u;   // rows past M: a valid row, zeroed in the epilogue
     i_sA = g.x;
     i_sB = reinterpret_cast<const float*>(g.wimg) + ((long)tn * nk) * (kImgB / 4);
-    i_sS = g.in_scale;
-    i_sT = g.in_shift;
   };
   i_tile();
-  auto issue = [&](XRegs<NBR, PRE>& R) {
+  if (PRE) {
+    float* f = reinterpret_cast<float*>(lds + 2 * kStage + 4 * BN * 4);
+    for (int i = tid; i < g.Cin; i += 256) {
+      f[i] = g.in_scale[i];
+      f[kFoldMax + i] = g.in_shift[i];
+    }
+    __syncthreads();
+  }
+  auto issue = [&](XRegs<NBR>& R) {
 #pragma unroll
     for (int q = 0; q < NBR; ++q) {
       const int cell = tid + 256 * q;
@@ -360,14 +370,6 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16x6_p_kernel(const XArgs g)
     }
     gload16(R.a0, i_sA, i_avoff);
     gload16(R.a1, i_sA + 4, i_avoff);
-    if (PRE) {
-      gload16(R.sc0, i_sS, (unsigned)(32 * ac));
-      gload16(R.sc1, i_sS + 4, (unsigned)(32 * ac));
-      gload16(R.sh0, i_sT, (unsigned)(32 * ac));
-      gload16(R.sh1, i_sT + 4, (unsigned)(32 * ac));
-      i_sS += XBK;
-      i_sT += XBK;
-    }
     i_sB += kImgB / 4;
     i_sA += XBK;
     if (++ikt == nk) {          // next tile (past the last one: the same tile again, loads nobody uses)
@@ -377,13 +379,13 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16x6_p_kernel(const XArgs g)
     }
   };
   // the registers of R become defined for the compiler HERE (they were written by asm loads)
-  auto landed = [&](XRegs<NBR, PRE>& R) {
-    if (PRE) asm volatile("" : "+v"(R.a0), "+v"(R.a1), "+v"(R.sc0), "+v"(R.sc1), "+v"(R.sh0), "+v"(R.sh1)::"memory");
-    else asm volatile("" : "+v"(R.a0), "+v"(R.a1)::"memory");
+  auto landed = [&](XRegs<NBR>& R) {
+    asm volatile("" : "+v"(R.a0), "+v"(R.a1)::"memory");
 #pragma unroll
     for (int q = 0; q < NBR; ++q) asm volatile("" : "+v"(R.b[q]));
   };
-  auto store = [&](XRegs<NBR, PRE>& R, int stage) {
+  int st_k = 8 * ac;           // this thread's first channel of the step being staged
+  auto store = [&](XRegs<NBR>& R, int stage) {
 #pragma unroll
     for (int q = 0; q < NBR; ++q) {
       const int cell = tid + 256 * q;
@@ -392,8 +394,13 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16x6_p_kernel(const XArgs g)
     }
     float x[8] = {R.a0[0], R.a0[1], R.a0[2], R.a0[3], R.a1[0], R.a1[1], R.a1[2], R.a1[3]};
     if (PRE) {
-      const float s[8] = {R.sc0[0], R.sc0[1], R.sc0[2], R.sc0[3], R.sc1[0], R.sc1[1], R.sc1[2], R.sc1[3]};
-      const float t[8] = {R.sh0[0], R.sh0[1], R.sh0[2], R.sh0[3], R.sh1[0], R.sh1[1], R.sh1[2], R.sh1[3]};
+      const f32x4 sc0 = *reinterpret_cast<const f32x4*>(fold + st_k), sc1 = *reinterpret_cast<const f32x4*>(fold + st_k + 4);
+      const f32x4 sh0 = *reinterpret_cast<const f32x4*>(fold + kFoldMax + st_k);
+      const f32x4 sh1 = *reinterpret_cast<const f32x4*>(fold + kFoldMax + st_k + 4);
+      st_k += XBK;
+      if (st_k >= g.Cin) st_k -= g.Cin;
+      const float s[8] = {sc0[0], sc0[1], sc0[2], sc0[3], sc1[0], sc1[1], sc1[2], sc1[3]};
+      const float t[8] = {sh0[0], sh0[1], sh0[2], sh0[3], sh1[0], sh1[1], sh1[2], sh1[3]};
 #pragma unroll
       for (int i = 0; i < 8; ++i) x[i] = fmaxf(fmaf(x[i], s[i], t[i]), lo);
     }
@@ -423,26 +430,112 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16x6_p_kernel(const XArgs g)
 
   const unsigned char* a_rd = lds + x_cell(wm * 64 + li, lh);
   const unsigned char* b_rd = lds + kImgA + x_cell(wn * (BN / 2) + li, lh);
-  auto compute = [&](int stage) {
-    bf16x8 af[2][3], bf[NT][3];
+  // One step = the 12 NT MFMAs of LDS[stage] + fold and split of the next step's A cells (R -> LDS[1 - stage]),
+  // laid out by hand:
+  //   * the fragment reads go first, and the LAST two terms of the PREVIOUS step (h m', h h': 4 NT MFMAs whose
+  //     three planes stayed in registers, XTail) run while they are on their way -- a lone workgroup on a CU
+  //     otherwise idles its matrix pipe through every LDS round trip behind the barrier (clock stamps: 1 150
+  //     cycles for 768 of MFMA);
+  //   * then 12 phases of one or two MFMAs and the 5 VALU of one third of a pair's split (an MFMA holds the
+  //     vector issue for 8 of its 32 cycles; 5 more instructions of 4 fit in the rest). sched_barrier(0) pins
+  //     the phases and a volatile use pins each phase's VALU (pure IR otherwise sinks to the final ds_write;
+  //     sched_group_barrier hints lost the pattern as soon as the fold read its scale from LDS);
+  //   * the last two MFMAs of the head cover the A-cell writes and the issue of the loads two steps ahead.
+  struct XTail { bf16x8 ah[2], bm[NT], bh[NT]; };
+  auto tail = [&](const XTail& T) {
 #pragma unroll
-    for (int p = 0; p < 3; ++p) {
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-        af[mt][p] = *reinterpret_cast<const bf16x8*>(a_rd + stage * kStage + p * kPlaneA + mt * 1024);
+    for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
-        bf[nt][p] = *reinterpret_cast<const bf16x8*>(b_rd + stage * kStage + p * kPlaneB + nt * 1024);
-    }
-    constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
-    constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(T.ah[mt], T.bm[nt], acc[mt][nt], 0, 0, 0);
 #pragma unroll
-    for (int term = 0; term < 6; ++term)
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(T.ah[mt], T.bh[nt], acc[mt][nt], 0, 0, 0);
+  };
+  auto body = [&](XRegs<NBR>& R, int stage, XTail& Tc, const XTail& Tp, bool pending, bool do_issue) {
+    constexpr int PA[4] = {2, 0, 1, 1};       // small terms first: (l h', h l', m m'), (m h', [tail: h m']), [h h']
+    constexpr int PB[4] = {0, 2, 1, 0};
+    f32x4 sc0, sc1, sh0, sh1;
+    if (PRE) {
+      sc0 = *reinterpret_cast<const f32x4*>(fold + st_k); sc1 = *reinterpret_cast<const f32x4*>(fold + st_k + 4);
+      sh0 = *reinterpret_cast<const f32x4*>(fold + kFoldMax + st_k);
+      sh1 = *reinterpret_cast<const f32x4*>(fold + kFoldMax + st_k + 4);
+      st_k += XBK;
+      if (st_k >= g.Cin) st_k -= g.Cin;
+    }
+    bf16x8 af[2][3], bf[NT][3];
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+      const int pa = o == 0 ? 2 : o == 1 ? 0 : 1, pb = o == 0 ? 0 : o == 1 ? 2 : 1;   // in the order the terms need them
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
+        af[mt][pa] = *reinterpret_cast<const bf16x8*>(a_rd + stage * kStage + pa * kPlaneA + mt * 1024);
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt][PA[term]], bf[nt][PB[term]], acc[mt][nt], 0, 0, 0);
+      for (int nt = 0; nt < NT; ++nt)
+        bf[nt][pb] = *reinterpret_cast<const bf16x8*>(b_rd + stage * kStage + pb * kPlaneB + nt * 1024);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (pending) tail(Tp);
+    __builtin_amdgcn_sched_barrier(0);
+    float x[8] = {R.a0[0], R.a0[1], R.a0[2], R.a0[3], R.a1[0], R.a1[1], R.a1[2], R.a1[3]};
+    const float fs[8] = {sc0[0], sc0[1], sc0[2], sc0[3], sc1[0], sc1[1], sc1[2], sc1[3]};
+    const float ft[8] = {sh0[0], sh0[1], sh0[2], sh0[3], sh1[0], sh1[1], sh1[2], sh1[3]};
+    u32x4 ph, pm, pl;
+    float r0 = 0.f, r1 = 0.f;
+    unsigned char* const dB = lds + (1 - stage) * kStage + kImgA;
+    constexpr int HP = 8 * NT - 2;          // head MFMAs spread over the phases (the last two cover writes + issue)
+    auto head = [&](int idx) {
+      const int term = idx / (2 * NT), mt = (idx % (2 * NT)) / NT, nt = idx % NT;
+      acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt][PA[term]], bf[nt][PB[term]], acc[mt][nt], 0, 0, 0);
+    };
+#pragma unroll
+    for (int phase = 0; phase < 12; ++phase) {
+      const int p = phase / 3, sub = phase % 3;
+      if (sub == 0) {
+        if (PRE) {
+          x[2 * p] = fmaxf(fmaf(x[2 * p], fs[2 * p], ft[2 * p]), lo);
+          x[2 * p + 1] = fmaxf(fmaf(x[2 * p + 1], fs[2 * p + 1], ft[2 * p + 1]), lo);
+        }
+        unsigned h = cvt_pk_bf16(x[2 * p], x[2 * p + 1]);
+        asm volatile("" : "+v"(h));
+        ph[p] = h;
+      } else if (sub == 1) {
+        r0 = x[2 * p] - __uint_as_float(ph[p] << 16);
+        r1 = x[2 * p + 1] - __uint_as_float(ph[p] & 0xffff0000u);
+        unsigned m = cvt_pk_bf16(r0, r1);
+        asm volatile("" : "+v"(m), "+v"(r0), "+v"(r1));
+        pm[p] = m;
+      } else {
+        r0 -= __uint_as_float(pm[p] << 16);
+        r1 -= __uint_as_float(pm[p] & 0xffff0000u);
+        unsigned l = cvt_pk_bf16(r0, r1);
+        asm volatile("" : "+v"(l));
+        pl[p] = l;
+      }
+#pragma unroll
+      for (int idx = (phase * HP) / 12; idx < ((phase + 1) * HP) / 12; ++idx) head(idx);
+      if (phase >= 1 && phase <= NBR) {
+        const int q = phase - 1;
+        const int cell = tid + 256 * q;
+        if ((kImgB / 16) % 256 == 0 || cell < kImgB / 16) *reinterpret_cast<f32x4*>(dB + cell * 16) = R.b[q];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    head(HP);
+    unsigned char* d = lds + (1 - stage) * kStage + awr;
+    *reinterpret_cast<u32x4*>(d) = ph;
+    *reinterpret_cast<u32x4*>(d + kPlaneA) = pm;
+    *reinterpret_cast<u32x4*>(d + 2 * kPlaneA) = pl;
+    __builtin_amdgcn_sched_barrier(0);
+    head(HP + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (do_issue) issue(R);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) Tc.ah[mt] = af[mt][0];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { Tc.bm[nt] = bf[nt][1]; Tc.bh[nt] = bf[nt][0]; }
   };
 
   // ---- compute cursor
@@ -470,20 +563,27 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16x6_p_kernel(const XArgs g)
     }
     if (plain && (g.abl & 8)) {
     } else if (plain) {
-      // 32 NT unconditional stores (the count the waits after this epilogue rely on)
+      // Every wave turns its 32 x 32 blocks through its own 4.5 KB of the stage the finished step read (a
+      // tile ends behind the second step of a pair: stage 1; the other stage already holds the next step),
+      // so that a lane stores 16 B and an instruction 8 rows x 128 B: 8 NT stores per lane where one dword
+      // each took 32 NT (the stamps put 3 200 of a tile's 5 400 epilogue cycles on their issue).
+      float* W = reinterpret_cast<float*>(lds + kStage) + wave * (32 * 36);
+      const int trow = lane >> 3, tc4 = (lane & 7) * 4;
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const int n = n0 + wn * (BN / 2) + nt * 32 + li;
+      for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
-          unsigned off = ((unsigned)(m0 + wm * 64 + mt * 32 + 4 * lh) * (unsigned)g.Cout + (unsigned)n) * 4u;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            asm volatile("global_store_dword %0, %1, %2" ::"v"(off), "v"(acc[mt][nt][r]), "s"(g.y) : "memory");
-            off += ((r & 3) == 3 ? 5u : 1u) * rstep;
+          for (int r = 0; r < 16; ++r) W[(4 * lh + (r & 3) + 8 * (r >> 2)) * 36 + li] = acc[mt][nt][r];
+          unsigned off = ((unsigned)(m0 + wm * 64 + mt * 32 + trow) * (unsigned)g.Cout +
+                          (unsigned)(n0 + wn * (BN / 2) + nt * 32 + tc4)) * 4u;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(W + (8 * q + trow) * 36 + tc4);
+            asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(off), "v"(v), "s"(g.y) : "memory");
+            off += 8u * rstep;
           }
         }
-      }
     } else {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
@@ -513,16 +613,18 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16x6_p_kernel(const XArgs g)
       using T = TileCfg<XBM, BN, 16>;
       block_col_stats<T>(acc, scratch, g.part_sum + (long)tm * g.Cout, g.part_sq + (long)tm * g.Cout, n0, g.Cout);
       __syncthreads();       // scratch is reused by the next tile's statistics
+    } else if (plain) {
+      __syncthreads();       // the next step refills the stage the waves transposed through
     }
     zero_acc();
-    // a plain tile put exactly 16 * 2 * NT stores behind the loads in flight; anything else (ragged rows,
+    // a plain tile put exactly 8 NT stores behind the loads in flight; anything else (ragged rows,
     // the folded epilogue's own loads) is not counted on: the next wait drains the queue
     after_epi = (plain && !(g.abl & 8)) ? 2 : -1;
   };
 
   // Loads are only ever issued for steps that exist: a register written by a load nobody consumes is free
   // for the compiler to reuse at once, and the load would land in whatever lives there by then.
-  XRegs<NBR, PRE> R0, R1;
+  XRegs<NBR> R0, R1;
   issue(R0);
   if (n_it > 1) {
     issue(R1);
@@ -539,7 +641,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16x6_p_kernel(const XArgs g)
   // the second step of a pair: one copy of the epilogue. landed + store are unconditional -- the last
   // step of a workgroup re-stores stale registers into the stage nobody reads again -- because a branch
   // there splits the block and the scheduler can no longer put the split's VALU between the MFMAs.
-  auto step = [&](XRegs<NBR, PRE>& R, int stage, int it, bool tile_may_end) {
+  XTail T0, T1;
+  auto step = [&](XRegs<NBR>& R, int stage, int it, XTail& Tc, const XTail& Tp, bool second) {
     // LDS[stage] holds step `it`; R holds step it + 1 (issued two steps ago) and goes to LDS[1 - stage]
     stamp(it, 0);
     if (it + 2 >= n_it) { x_wait_vmcnt_plain<0>(); after_epi = 0; }     // nothing younger in flight
@@ -548,33 +651,22 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16x6_p_kernel(const XArgs g)
     else x_wait_vmcnt_plain<NLD>();
     stamp(it, 1);
     landed(R);
-    compute(stage);
-    store(R, 1 - stage);
-    // All fragment reads first (read just in time, every MFMA that opens a new plane waited ~100 cycles for
-    // the LDS); then one MFMA (8 of its 32 cycles hold the vector issue) and the VALU that fits in the rest.
-    __builtin_amdgcn_sched_group_barrier(0x100, 6 + 3 * NT, 0);
-    __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);      // (the fold, while the fragments are on their way)
-#pragma unroll
-    for (int i = 0; i < 12 * NT; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, NT == 2 ? 4 : 8, 0);
-      if (i == 6 * NT) __builtin_amdgcn_sched_group_barrier(0x200, NBR, 0);     // the weight cells, mid-way
-    }
-    __builtin_amdgcn_sched_group_barrier(0x200, 3, 0);
+    // a tile starts with the first step of a pair only (nk is even): the second always has a tail to run
+    body(R, stage, Tc, Tp, second || ckt > 0, it + 3 < n_it);
     stamp(it, 2);
-    if (it + 3 < n_it) issue(R);
-    stamp(it, 3);
     __syncthreads();
+    stamp(it, 3);
     ++ckt;
-    if (tile_may_end && ckt == nk) {
+    if (second && ckt == nk) {
+      tail(Tc);
       epilogue();
       ckt = 0;
       cw += G;
     }
   };
   for (int it = 0; it < n_it; it += 2) {
-    step(R1, 0, it, false);
-    step(R0, 1, it + 1, true);
+    step(R1, 0, it, T0, T1, false);
+    step(R0, 1, it + 1, T1, T0, true);
   }
   if (diag) {
     __syncthreads();
@@ -683,7 +775,7 @@ int conv1x1_fwd_bf16x6(const float* x, long sxb, long sxh, long sxw, const unsig
   magic_div((unsigned)OW, &a.ow_mul, &a.ow_sh);
   const dim3 block(256);
   const char* v1 = getenv("CAPNET_X6_V1");         // A/B: the one-tile-per-workgroup kernel
-  if (!(v1 && v1[0] == '1') && (Cin / XBK) % 2 == 0) {
+  if (!(v1 && v1[0] == '1') && (Cin / XBK) % 2 == 0 && (!in_scale || Cin <= kFoldMax)) {
     // persistent: two workgroups per CU walk the tiles (a multiple of 8, so that a workgroup stays on its XCD's
     // share of the tile order)
     const char* ge = getenv("CAPNET_X6_WGS");
