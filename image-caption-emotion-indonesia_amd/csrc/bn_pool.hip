@@ -15,6 +15,13 @@ namespace capnet {
 // thread keeps 16 independent loads in flight -- the kernel is pure latency otherwise.
 constexpr int kFinCh = 16, kFinRows = 64;
 
+// running statistic <- (1 - momentum) running + momentum batch, with ONE rounding pattern wherever it is applied: the
+// update fused into bn_finalize and the deferred bn_running_update_kernel (TrunkPipeline) must agree bit for bit, and
+// left to the compiler the two kernels contracted different halves of the expression into an fma
+__device__ __forceinline__ float bn_running_blend(float running, float batch, float momentum) {
+  return __builtin_fmaf(momentum, batch, (1.f - momentum) * running);
+}
+
 __global__ __launch_bounds__(kFinCh* kFinRows) void bn_finalize_kernel(
     const float* __restrict__ part_sum, const float* __restrict__ part_sq, int tiles, int C,
     double inv_count, double unbias, const float* __restrict__ gamma,
@@ -63,8 +70,8 @@ __global__ __launch_bounds__(kFinCh* kFinRows) void bn_finalize_kernel(
     scale[c] = sc;
     shift[c] = b - (float)mean * sc;
     if (running_mean) {
-      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
-      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(var * unbias);
+      running_mean[c] = bn_running_blend(running_mean[c], (float)mean, momentum);
+      running_var[c] = bn_running_blend(running_var[c], (float)(var * unbias), momentum);
     }
     if (batch_mean) {   // deferred running-statistics update (bn_running_update_multi)
       batch_mean[c] = (float)mean;
@@ -173,8 +180,8 @@ __global__ __launch_bounds__(256) void bn_running_update_kernel(BnRunTable t, fl
   const int k = blockIdx.y;
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= t.C[k]) return;
-  t.rm[k][c] = (1.f - momentum) * t.rm[k][c] + momentum * t.mean[k][c];
-  t.rv[k][c] = (1.f - momentum) * t.rv[k][c] + momentum * t.var[k][c];
+  t.rm[k][c] = bn_running_blend(t.rm[k][c], t.mean[k][c], momentum);
+  t.rv[k][c] = bn_running_blend(t.rv[k][c], t.var[k][c], momentum);
 }
 
 int bn_running_update_multi(int n, const float* const* mean, const float* const* var, float* const* rm,

@@ -312,8 +312,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16x6_p_kernel(const XArgs g)
   constexpr int kStage = kImgA + kImgB;
   constexpr int NBR = (kImgB / 16 + 255) / 256;     // 16-B cells of the B image per thread
   constexpr int NLD = NBR + 2;                      // loads of one step
-  // the wait that must leave one step's loads AND a plain epilogue's 8 NT stores in flight
-  constexpr int kWaitEpi = NLD + 8 * NT;
+  // the wait that must leave one step's loads AND a plain epilogue's 32 NT stores in flight (6-bit counter)
+  constexpr int kWaitEpi = NLD + 32 * NT > 63 ? 63 : NLD + 32 * NT;
   constexpr int kFold = PRE ? 2 * kFoldMax * 4 : 0;
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kStage + 4 * BN * 4 + kFold];
   float* scratch = reinterpret_cast<float*>(lds + 2 * kStage);
@@ -563,27 +563,22 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16x6_p_kernel(const XArgs g)
     }
     if (plain && (g.abl & 8)) {
     } else if (plain) {
-      // Every wave turns its 32 x 32 blocks through its own 4.5 KB of the stage the finished step read (a
-      // tile ends behind the second step of a pair: stage 1; the other stage already holds the next step),
-      // so that a lane stores 16 B and an instruction 8 rows x 128 B: 8 NT stores per lane where one dword
-      // each took 32 NT (the stamps put 3 200 of a tile's 5 400 epilogue cycles on their issue).
-      float* W = reinterpret_cast<float*>(lds + kStage) + wave * (32 * 36);
-      const int trow = lane >> 3, tc4 = (lane & 7) * 4;
+      // 32 NT unconditional stores (the count the waits after this epilogue rely on). A variant that turned the 32 x 32
+      // blocks through LDS to store 16 B per lane took the same 5 400 cycles per tile (the burst of every workgroup's
+      // 64 KB, not the instruction count, sets it) and is gone.
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
+      for (int nt = 0; nt < NT; ++nt) {
+        const int n = n0 + wn * (BN / 2) + nt * 32 + li;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
+          unsigned off = ((unsigned)(m0 + wm * 64 + mt * 32 + 4 * lh) * (unsigned)g.Cout + (unsigned)n) * 4u;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) W[(4 * lh + (r & 3) + 8 * (r >> 2)) * 36 + li] = acc[mt][nt][r];
-          unsigned off = ((unsigned)(m0 + wm * 64 + mt * 32 + trow) * (unsigned)g.Cout +
-                          (unsigned)(n0 + wn * (BN / 2) + nt * 32 + tc4)) * 4u;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(W + (8 * q + trow) * 36 + tc4);
-            asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(off), "v"(v), "s"(g.y) : "memory");
-            off += 8u * rstep;
+          for (int r = 0; r < 16; ++r) {
+            asm volatile("global_store_dword %0, %1, %2" ::"v"(off), "v"(acc[mt][nt][r]), "s"(g.y) : "memory");
+            off += ((r & 3) == 3 ? 5u : 1u) * rstep;
           }
         }
+      }
     } else {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
@@ -613,11 +608,9 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16x6_p_kernel(const XArgs g)
       using T = TileCfg<XBM, BN, 16>;
       block_col_stats<T>(acc, scratch, g.part_sum + (long)tm * g.Cout, g.part_sq + (long)tm * g.Cout, n0, g.Cout);
       __syncthreads();       // scratch is reused by the next tile's statistics
-    } else if (plain) {
-      __syncthreads();       // the next step refills the stage the waves transposed through
     }
     zero_acc();
-    // a plain tile put exactly 8 NT stores behind the loads in flight; anything else (ragged rows,
+    // a plain tile put exactly 32 NT stores behind the loads in flight; anything else (ragged rows,
     // the folded epilogue's own loads) is not counted on: the next wait drains the queue
     after_epi = (plain && !(g.abl & 8)) ? 2 : -1;
   };

@@ -76,6 +76,19 @@ int conv1x1_fwd_bf16x6(const float* x, long sxb, long sxh, long sxw, const unsig
                        hipStream_t stream, const float* out_scale = nullptr, const float* out_shift = nullptr,
                        const float* res = nullptr, int relu_out = 0);
 
+// conv_f16x3.hip: 1x1 convolution as three f16 MFMA products of 2-way split, power-of-two scaled fp32 operands
+// (fp32-grade results; the default for Cin % 64 == 0)
+bool conv1x1_f16x3_eligible(const float* x, long sxb, long sxh, long sxw, long sxc, int Bn, int H, int W,
+                            int Cin, int Cout, int stride, const float* in_scale, const float* in_shift);
+int conv1x1_f16x3_bn(long M, int Cout);
+size_t conv1x1_f16x3_weight_words(int Cin, int Cout);
+int conv1x1_f16x3_pack(const float* w, unsigned* img, int Cout, int Cin, int bn, hipStream_t stream);
+int conv1x1_fwd_f16x3(const float* x, long sxb, long sxh, long sxw, const unsigned* wimg, int bn, float* y,
+                      const float* in_scale, const float* in_shift, int relu_in, float* part_sum,
+                      float* part_sq, int Bn, int H, int W, int Cin, int Cout, int stride,
+                      hipStream_t stream, const float* out_scale = nullptr, const float* out_shift = nullptr,
+                      const float* res = nullptr, int relu_out = 0);
+
 // bn_pool.hip
 int bn_finalize(const float* part_sum, const float* part_sq, int tiles, int C, long count,
                 const float* gamma, const float* beta, float* running_mean, float* running_var,

@@ -32,6 +32,7 @@ struct TrunkConv {
   bool dma1x1; // 1x1 on an activated input (conv1, downsample): LDS-DMA NT core (gemm_dma.hip), weights as [Cout][Cin]
   bool x6;     // 1x1: six bf16 MFMA products of 3-way split fp32 operands (conv_bf16x6.hip), its own weight image
   int x6_bn;   // tile width that image was laid out for
+  bool h3;     // 1x1 with Cin % 64 == 0: three f16 MFMA products of 2-way split operands (conv_f16x3.hip); wins over x6
 };
 
 struct Trunk {
@@ -74,6 +75,10 @@ int trunk_create(int B, int H, int W, Trunk** out) {
   // CAPNET_NO_X6=1 keeps them on the f32-MFMA K-major kernel (A/B runs)
   const char* nox = getenv("CAPNET_NO_X6");
   const bool use_x6 = !(nox && nox[0] == '1');
+  // ... and, where Cin allows, on the f16 matrix cores with 2-way split operands: half the matrix work of the
+  // bf16 split at the same fp32-grade accuracy; CAPNET_NO_H3=1 keeps the bf16 split (A/B runs)
+  const char* noh = getenv("CAPNET_NO_H3");
+  const bool use_h3 = use_x6 && !(noh && noh[0] == '1');
   auto add = [&](int cin, int cout, int k, int stride, int pad, int h, int w, bool activated_input = false) {
     TrunkConv c;
     c.Cin = cin; c.Cout = cout; c.k = k; c.stride = stride; c.pad = pad; c.H = h; c.W = w;
@@ -84,7 +89,9 @@ int trunk_create(int B, int H, int W, Trunk** out) {
     c.wino = use_wino && c.kmajor && conv_wino_shape_ok(h, w, cin, cout, k, k, stride, pad);
     c.dma1x1 = use_dma && activated_input && k == 1 && pad == 0 && cin % 16 == 0 && cout % 64 == 0;
     c.x6 = use_x6 && !c.dma1x1 && k == 1 && pad == 0 && cin % 16 == 0 && cout % 64 == 0;
-    c.x6_bn = c.x6 ? conv1x1_bf16x6_bn((long)B * c.OH * c.OW, cout) : 0;
+    c.h3 = use_h3 && c.x6 && cin % 64 == 0 && (activated_input || cin <= 512);
+    if (c.h3) c.x6 = false;
+    c.x6_bn = c.x6 ? conv1x1_bf16x6_bn((long)B * c.OH * c.OW, cout) : c.h3 ? conv1x1_f16x3_bn((long)B * c.OH * c.OW, cout) : 0;
     t->convs.push_back(c);
     return c;
   };
@@ -131,7 +138,7 @@ int trunk_create(int B, int H, int W, Trunk** out) {
     const int tile = c.kmajor ? conv_v2_auto_tile((int)M, c.Cout, c.Kw) : conv_auto_tile((int)M, c.Cout);
     max_part = std::max(max_part, (size_t)conv_tiles_m((int)M, tile) * c.Cout);
     if (c.wino) max_part = std::max(max_part, (size_t)conv_wino_tiles_m(B, c.H, c.W) * c.Cout);
-    if (c.dma1x1 || c.x6) max_part = std::max(max_part, (size_t)conv1x1_tiles_m(M) * c.Cout);
+    if (c.dma1x1 || c.x6 || c.h3) max_part = std::max(max_part, (size_t)conv1x1_tiles_m(M) * c.Cout);
   }
   t->off_part = take(2 * max_part);
   size_t max_slab = 0;
@@ -212,7 +219,7 @@ int trunk_conv_shape(const Trunk* t, int i, int* cout, int* cin, int* k, int* st
 
 int trunk_conv_kmajor(const Trunk* t, int i) {
   if (i < 0 || i >= (int)t->convs.size()) return 0;
-  return t->convs[i].x6 ? 4 : t->convs[i].dma1x1 ? 3 : t->convs[i].wino ? 2 : (t->convs[i].kmajor ? 1 : 0);
+  return t->convs[i].h3 ? 5 : t->convs[i].x6 ? 4 : t->convs[i].dma1x1 ? 3 : t->convs[i].wino ? 2 : (t->convs[i].kmajor ? 1 : 0);
 }
 
 int trunk_conv_x6_bn(const Trunk* t, int i) {
@@ -263,7 +270,7 @@ int conv_bn(const Ctx& c, int i, const float* x, long sxb, long sxh, long sxw, l
   int tile = d.kmajor ? conv_v2_auto_tile((int)M, d.Cout, d.Kw) : conv_auto_tile((int)M, d.Cout);
   if (d.kmajor && !c.t->tail_balance && M >= 5000) tile = 12864;
   // rows of the statistics partials this conv writes
-  const int prows = (d.dma1x1 || d.x6) ? conv1x1_tiles_m(M) : d.wino ? conv_wino_tiles_m(c.t->B, d.H, d.W) : conv_tiles_m((int)M, tile);
+  const int prows = (d.dma1x1 || d.x6 || d.h3) ? conv1x1_tiles_m(M) : d.wino ? conv_wino_tiles_m(c.t->B, d.H, d.W) : conv_tiles_m((int)M, tile);
   float* psum = c.ws + c.t->off_part;
   float* psq = psum + (size_t)prows * d.Cout;
   hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -273,7 +280,13 @@ int conv_bn(const Ctx& c, int i, const float* x, long sxb, long sxh, long sxw, l
     CAPNET_HIP_CHECK(hipEventRecord(e0, c.s));
   }
   int rc;
-  if (d.x6) {
+  if (d.h3) {
+    CAPNET_REQUIRE(conv1x1_f16x3_eligible(x, sxb, sxh, sxw, sxc, c.t->B, d.H, d.W, d.Cin, d.Cout, d.stride, in_scale, in_shift),
+                   "trunk: conv %d planned for the split-f16 kernel but its operands are not eligible", i);
+    rc = conv1x1_fwd_f16x3(x, sxb, sxh, sxw, reinterpret_cast<const unsigned*>(c.w[i]), d.x6_bn, y, in_scale,
+                           in_shift, relu_in, c.train ? psum : nullptr, c.train ? psq : nullptr, c.t->B, d.H,
+                           d.W, d.Cin, d.Cout, d.stride, c.s);
+  } else if (d.x6) {
     CAPNET_REQUIRE(conv1x1_bf16x6_eligible(x, sxb, sxh, sxw, sxc, c.t->B, d.H, d.W, d.Cin, d.Cout, d.stride, in_scale, in_shift),
                    "trunk: conv %d planned for the split-bf16 kernel but its operands are not eligible", i);
     rc = conv1x1_fwd_bf16x6(x, sxb, sxh, sxw, reinterpret_cast<const unsigned*>(c.w[i]), d.x6_bn, y, in_scale,
@@ -322,7 +335,7 @@ int conv_folded(const Ctx& c, int i, const float* x, const float* res, int relu,
   const TrunkConv& d = c.t->convs[i];
   const long M = (long)c.t->B * d.OH * d.OW;
   const long sw = d.Cin, sh = (long)d.W * d.Cin, sb = (long)d.H * d.W * d.Cin;
-  CAPNET_REQUIRE(d.x6 || d.dma1x1 || (d.kmajor && conv_v2_eligible(x, sb, sh, sw, 1, c.t->B, d.Cin, d.Cout, nullptr, nullptr)),
+  CAPNET_REQUIRE(d.h3 || d.x6 || d.dma1x1 || (d.kmajor && conv_v2_eligible(x, sb, sh, sw, 1, c.t->B, d.Cin, d.Cout, nullptr, nullptr)),
                  "trunk: conv %d is not eligible for the folded-BN kernel", i);
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (c.t->timing) {
@@ -331,7 +344,11 @@ int conv_folded(const Ctx& c, int i, const float* x, const float* res, int relu,
     CAPNET_HIP_CHECK(hipEventRecord(e0, c.s));
   }
   int rc;
-  if (d.x6) {
+  if (d.h3) {
+    rc = conv1x1_fwd_f16x3(x, sb, sh, sw, reinterpret_cast<const unsigned*>(c.w[i]), d.x6_bn, y, nullptr, nullptr,
+                           0, nullptr, nullptr, c.t->B, d.H, d.W, d.Cin, d.Cout, d.stride, c.s, c.scale(i),
+                           c.shift(i), res, relu);
+  } else if (d.x6) {
     rc = conv1x1_fwd_bf16x6(x, sb, sh, sw, reinterpret_cast<const unsigned*>(c.w[i]), d.x6_bn, y, nullptr, nullptr,
                             0, nullptr, nullptr, c.t->B, d.H, d.W, d.Cin, d.Cout, d.stride, c.s, c.scale(i),
                             c.shift(i), res, relu);

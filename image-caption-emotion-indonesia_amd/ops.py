@@ -268,6 +268,21 @@ def pack_conv_weight_bf16x6(w_oihw, bn):
     return out
 
 
+def pack_conv_weight_f16x3(w_oihw, bn):
+    """1x1 OIHW weights -> header + the split-f16 image of capnet_conv1x1_fwd_f16x3 for tile width bn
+    (two f16 pieces per weight scaled by the per-tensor power of two in the header, laid out as the
+    kernel's LDS image)."""
+    _need_cuda(w_oihw)
+    w = _c(w_oihw)
+    co, ci, kh, kw = w.shape
+    if (kh, kw) != (1, 1):
+        raise CapnetError("pack_conv_weight_f16x3: 1x1 weights only")
+    out = torch.empty(_lib.lib().capnet_conv1x1_f16x3_weight_words(ci, co), dtype=torch.int32, device=w.device)
+    check(_lib.lib().capnet_conv1x1_f16x3_pack(ptr(w), ptr(out), co, ci, int(bn), current_stream()),
+          "capnet_conv1x1_f16x3_pack")
+    return out
+
+
 def clamp_adam(params, grads, exp_avg, exp_avg_sq, steps, lr, beta1, beta2, eps, clip,
                write_grad=True):
     """Fused element-wise clamp + Adam over a list of tensors (in place)."""

@@ -126,7 +126,9 @@ int capnet_trunk_collect_timing(capnet_trunk_t* t, double* conv_ms, long* conv_l
  * 3 = the 1x1 weight as stored, [Cout][Cin] (capnet_conv1x1_fwd_dma; only when the trunk was
  * created with CAPNET_DMA1X1=1: an experiment, slower than image 1 in the pipelined step),
  * 4 = the split-bf16 image of a 1x1 convolution (capnet_conv1x1_bf16x6_pack with tile width
- * capnet_trunk_conv_x6_bn(t, i); every 1x1 convolution unless CAPNET_NO_X6=1). */
+ * capnet_trunk_conv_x6_bn(t, i); 1x1 convolutions image 5 does not take, unless CAPNET_NO_X6=1),
+ * 5 = the split-f16 image of a 1x1 convolution (capnet_conv1x1_f16x3_pack with tile width
+ * capnet_trunk_conv_x6_bn(t, i); every 1x1 convolution with Cin % 64 == 0 unless CAPNET_NO_H3=1). */
 int capnet_trunk_conv_kmajor(const capnet_trunk_t* t, int i);
 int capnet_trunk_conv_x6_bn(const capnet_trunk_t* t, int i);
 int capnet_pack_conv_weight_kmajor(const float* w_oihw, float* out, int Cout, int Cin, int KH,
@@ -179,6 +181,22 @@ int capnet_conv1x1_fwd_bf16x6(const float* x, long sxb, long sxh, long sxw, cons
                               float* part_sum, float* part_sq, int B, int H, int W, int Cin, int Cout,
                               int stride, const float* out_scale, const float* out_shift,
                               const float* res, int relu_out, capnet_stream_t stream);
+
+/* 1x1 convolution with fp32-grade results from three f16 MFMA products per multiply (csrc/conv_f16x3.hip):
+ * both operands scaled by a power of two and split into two f16 pieces (activations by 2^4, weights by a
+ * per-tensor 2^ew kept in the image's header), fp32 accumulation, the accumulators scaled back exactly;
+ * rms error against fp64 at or below the f32-MFMA kernels' for |x| < 4094. Needs Cin % 64 == 0,
+ * Cout % 64 == 0 and, with a folded input (in_scale), Cin <= 512. Same arguments as the bf16x6 entry
+ * points; weights: capnet_conv1x1_f16x3_pack for tile width bn = capnet_conv1x1_f16x3_bn(M, Cout). */
+size_t capnet_conv1x1_f16x3_weight_words(int Cin, int Cout);
+int capnet_conv1x1_f16x3_bn(long M, int Cout);
+int capnet_conv1x1_f16x3_pack(const float* w_oi, unsigned* image, int Cout, int Cin, int bn,
+                              capnet_stream_t stream);
+int capnet_conv1x1_fwd_f16x3(const float* x, long sxb, long sxh, long sxw, const unsigned* image, int bn,
+                             float* y, const float* in_scale, const float* in_shift, int relu_in,
+                             float* part_sum, float* part_sq, int B, int H, int W, int Cin, int Cout,
+                             int stride, const float* out_scale, const float* out_shift,
+                             const float* res, int relu_out, capnet_stream_t stream);
 
 /* the low-VALU kernel used for every trunk convolution with Cin % 16 == 0 and Cout % 64 == 0:
  * NHWC channel-contiguous input, K-major weights, k_rows == KH*KW*Cin */

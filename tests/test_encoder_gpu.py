@@ -193,3 +193,45 @@ def test_winograd_trunk_agrees_with_the_direct_kernels(dev, monkeypatch):
     # train-mode BatchNorm over 8 images amplifies rounding differences (both variants are 9.2e-4
     # from the fp64 fixture at B=3, the fp32 oracle 7.4e-4): measured 5.8e-4 / 1e-6 / 3.4e-5
     assert errs[0] < TOL and errs[1] < 1e-4 and errs[2] < 2e-4
+
+
+def test_split_operand_trunks_are_as_close_to_fp64_as_the_f32_trunk(dev, monkeypatch):
+    """The 1x1 convolutions run on split operands (three f16 products, csrc/conv_f16x3.hip; six bf16
+    products where Cin % 64 != 0, csrc/conv_bf16x6.hip). Train-mode features of a batch of 8 against the
+    same network in fp64 on the CPU: neither split may sit further from fp64 than the all-f32-MFMA trunk
+    (CAPNET_NO_X6=1) does -- train-mode BatchNorm over 8 images amplifies every rounding difference, so
+    this is the comparison the whole-step parity tests feel."""
+    from oracle.resnet152_ref import EncoderCNNRef
+    L = capnet._lib.lib()
+    B = 8
+    imgs = synthetic.make_batch(B, 100, seed=2)[0]
+    enc0 = EncoderCNN(300)
+    st = _encoder_state(enc0)
+    ref = EncoderCNNRef(300)
+    ref.load_state_dict({k: v.clone() for k, v in st.items()})
+    ref.double().train()
+    torch.set_num_threads(16)
+    with torch.no_grad():
+        want = ref.resnet(imgs.double()).reshape(B, -1)
+
+    def run(env):
+        for k in ("CAPNET_NO_X6", "CAPNET_NO_H3"):
+            monkeypatch.delenv(k, raising=False)
+        for k in env:
+            monkeypatch.setenv(k, "1")
+        enc = EncoderCNN(300)
+        enc.load_state_dict({k: v.clone() for k, v in st.items()})
+        enc.to(dev).train()
+        runner = enc._trunk()
+        plan = runner._plan(B, 224, 224, dev)            # the environment is read here
+        kinds = [L.capnet_trunk_conv_kmajor(plan["handle"], i) for i in range(155)]
+        pooled, _ = runner.forward(imgs.to(dev), True, True, False)
+        return kinds, rel_err(pooled, want)
+
+    k32, e32 = run(["CAPNET_NO_X6"])
+    kb, eb = run(["CAPNET_NO_H3"])
+    kh, eh = run([])
+    print("train features vs fp64 at B=8: f32 MFMA %.2e, split bf16 %.2e, split f16 %.2e (1x1 layers on f16: %d)"
+          % (e32, eb, eh, kh.count(5)))
+    assert k32.count(4) == 0 and k32.count(5) == 0 and kb.count(5) == 0 and kb.count(4) > 90 and kh.count(5) > 90
+    assert eb < 1.5 * e32 + 1e-5 and eh < 1.5 * e32 + 1e-5

@@ -568,18 +568,8 @@ def test_attention_loss_matches_torch(dev):
     assert abs(n_d.grad.item() - 1.5) < 1e-7
 
 
-# ---- 1x1 convolution as six bf16 products of 3-way split operands (csrc/conv_bf16x6.hip) ---------
-@pytest.mark.parametrize("bn", [64, 128])
-@pytest.mark.parametrize("B,H,W,Cin,Cout,stride,pre,epi", [
-    (2, 8, 8, 128, 256, 1, False, 0),       # M = 128
-    (3, 7, 7, 128, 128, 1, True, 0),        # ragged last M tile (147 rows), folded BatchNorm + ReLU on load
-    (2, 8, 8, 64, 128, 2, False, 0),        # stride 2 (downsample branch)
-    (4, 14, 14, 1024, 256, 1, False, 0),    # stage-3 conv1 at batch 4: 64 k-tiles
-    (4, 14, 14, 256, 1024, 1, True, 0),     # stage-3 conv3
-    (5, 14, 14, 16, 128, 1, True, 0),       # one k-tile
-    (2, 7, 7, 64, 128, 1, False, 1),        # folded inference epilogue with residual + ReLU
-])
-def test_conv1x1_bf16x6_has_fp32_accuracy(dev, bn, B, H, W, Cin, Cout, stride, pre, epi):
+# ---- 1x1 convolutions on split operands: one case against fp64 and the f32-MFMA kernel ----
+def _split_conv1x1_case(dev, kind, bn, B, H, W, Cin, Cout, stride, pre, epi):
     g = torch.Generator().manual_seed(B + H + Cin + Cout + stride + bn)
     # values spread over many binades, as activations and weights are
     x = torch.randn(B, Cin, H, W, generator=g) * torch.exp(torch.randn(B, Cin, H, W, generator=g))
@@ -596,8 +586,8 @@ def test_conv1x1_bf16x6_has_fp32_accuracy(dev, bn, B, H, W, Cin, Cout, stride, p
     xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
     wd = w.reshape(Cout, Cin).contiguous().to(dev)
     L = lib()
-    img = torch.empty(L.capnet_conv1x1_bf16x6_weight_words(Cin, Cout), dtype=torch.int32, device=dev)
-    check(L.capnet_conv1x1_bf16x6_pack(ptr(wd), ptr(img), Cout, Cin, bn, current_stream()))
+    img = torch.empty(getattr(L, 'capnet_conv1x1_%s_weight_words' % kind)(Cin, Cout), dtype=torch.int32, device=dev)
+    check(getattr(L, 'capnet_conv1x1_%s_pack' % kind)(ptr(wd), ptr(img), Cout, Cin, bn, current_stream()))
     y = torch.full((M, Cout), float("nan"), device=dev)
     tiles = L.capnet_conv1x1_tiles_m(M)
     sd, hd = (scale.to(dev), shift.to(dev)) if pre else (None, None)
@@ -605,7 +595,7 @@ def test_conv1x1_bf16x6_has_fp32_accuracy(dev, bn, B, H, W, Cin, Cout, stride, p
         sc, sh = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
         res = torch.randn(M, Cout, generator=g)
         scd, shd, rd = sc.to(dev), sh.to(dev), res.to(dev)
-        check(L.capnet_conv1x1_fwd_bf16x6(ptr(xd), H * W * Cin, W * Cin, Cin, ptr(img), bn, ptr(y), ptr(sd), ptr(hd),
+        check(getattr(L, 'capnet_conv1x1_fwd_%s' % kind)(ptr(xd), H * W * Cin, W * Cin, Cin, ptr(img), bn, ptr(y), ptr(sd), ptr(hd),
                                           int(pre), None, None, B, H, W, Cin, Cout, stride, ptr(scd), ptr(shd),
                                           ptr(rd), 1, current_stream()))
         want = torch.relu(ref * sc.double() + sh.double() + res.double())
@@ -613,7 +603,7 @@ def test_conv1x1_bf16x6_has_fp32_accuracy(dev, bn, B, H, W, Cin, Cout, stride, p
         return
     psum = torch.full((tiles, Cout), float("nan"), device=dev)
     psq = torch.full((tiles, Cout), float("nan"), device=dev)
-    check(L.capnet_conv1x1_fwd_bf16x6(ptr(xd), H * W * Cin, W * Cin, Cin, ptr(img), bn, ptr(y), ptr(sd), ptr(hd),
+    check(getattr(L, 'capnet_conv1x1_fwd_%s' % kind)(ptr(xd), H * W * Cin, W * Cin, Cin, ptr(img), bn, ptr(y), ptr(sd), ptr(hd),
                                       int(pre), ptr(psum), ptr(psq), B, H, W, Cin, Cout, stride, None, None, None, 0,
                                       current_stream()))
     assert rel_err(y, ref) < 3e-6                      # the bound the f32-MFMA conv kernels are held to
@@ -627,7 +617,63 @@ def test_conv1x1_bf16x6_has_fp32_accuracy(dev, bn, B, H, W, Cin, Cout, stride, p
     check(lib().capnet_conv2d_fwd_kmajor(ptr(xd), H * W * Cin, W * Cin, Cin, ptr(wk), Cin, ptr(y32), ptr(sd), ptr(hd),
                                          int(pre), ptr(p1), ptr(p2), B, H, W, Cin, Cout, 1, 1, stride, 0, 0, None,
                                          current_stream()))
-    print("rms vs fp64: split-bf16 %.2e, f32 MFMA %.2e" % (rms(y), rms(y32)))
+    print("rms vs fp64: %s %.2e, f32 MFMA %.2e" % (kind, rms(y), rms(y32)))
     assert rms(y) < 1.25 * rms(y32) + 2e-8
     assert rel_err(psum.sum(0), ref.sum(0)) < 1e-5
     assert rel_err(psq.sum(0), (ref ** 2).sum(0)) < 1e-5
+
+
+
+# ---- 1x1 convolution as six bf16 products of 3-way split operands (csrc/conv_bf16x6.hip) ---------
+@pytest.mark.parametrize("bn", [64, 128])
+@pytest.mark.parametrize("B,H,W,Cin,Cout,stride,pre,epi", [
+    (2, 8, 8, 128, 256, 1, False, 0),       # M = 128
+    (3, 7, 7, 128, 128, 1, True, 0),        # ragged last M tile (147 rows), folded BatchNorm + ReLU on load
+    (2, 8, 8, 64, 128, 2, False, 0),        # stride 2 (downsample branch)
+    (4, 14, 14, 1024, 256, 1, False, 0),    # stage-3 conv1 at batch 4: 64 k-tiles
+    (4, 14, 14, 256, 1024, 1, True, 0),     # stage-3 conv3
+    (5, 14, 14, 16, 128, 1, True, 0),       # one k-tile
+    (2, 7, 7, 64, 128, 1, False, 1),        # folded inference epilogue with residual + ReLU
+])
+def test_conv1x1_bf16x6_has_fp32_accuracy(dev, bn, B, H, W, Cin, Cout, stride, pre, epi):
+    _split_conv1x1_case(dev, "bf16x6", bn, B, H, W, Cin, Cout, stride, pre, epi)
+
+
+# ---- 1x1 convolution as three f16 products of 2-way split, power-of-two scaled operands (csrc/conv_f16x3.hip) ----
+@pytest.mark.parametrize("bn", [64, 128])
+@pytest.mark.parametrize("B,H,W,Cin,Cout,stride,pre,epi", [
+    (2, 8, 8, 128, 256, 1, False, 0),       # M = 128, 4 k-tiles
+    (3, 7, 7, 128, 128, 1, True, 0),        # ragged last M tile (147 rows), folded BatchNorm + ReLU on load
+    (2, 8, 8, 64, 128, 2, False, 0),        # stride 2 (downsample branch), one pair of k-tiles
+    (4, 14, 14, 1024, 256, 1, False, 0),    # stage-3 conv1 at batch 4: 32 k-tiles
+    (4, 14, 14, 256, 1024, 1, True, 0),     # stage-3 conv3
+    (9, 14, 14, 512, 128, 1, True, 0),      # 14 M tiles x 1 / 2 N tiles: workgroups walking several tiles need more
+    (2, 7, 7, 64, 128, 1, False, 1),        # folded inference epilogue with residual + ReLU
+])
+def test_conv1x1_f16x3_has_fp32_accuracy(dev, bn, B, H, W, Cin, Cout, stride, pre, epi):
+    _split_conv1x1_case(dev, "f16x3", bn, B, H, W, Cin, Cout, stride, pre, epi)
+
+
+def test_conv1x1_f16x3_walks_several_tiles_per_workgroup(dev, monkeypatch):
+    """The persistent loop with more tiles than workgroups (CAPNET_H3_WGS caps the grid): cross-tile prefetch,
+    the counted waits behind an epilogue and the accumulator reset must leave the result bit-identical."""
+    B, H, W, Cin, Cout, bn = 6, 14, 14, 128, 256, 128
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, H, W, Cin, generator=g).to(dev); w = (torch.randn(Cout, Cin, generator=g) * 0.05).to(dev)
+    sc, sh = (torch.rand(Cin, generator=g) + 0.5).to(dev), torch.randn(Cin, generator=g).to(dev)
+    L = lib()
+    img = torch.empty(L.capnet_conv1x1_f16x3_weight_words(Cin, Cout), dtype=torch.int32, device=dev)
+    check(L.capnet_conv1x1_f16x3_pack(ptr(w), ptr(img), Cout, Cin, bn, current_stream()))
+    M = B * H * W
+    t = L.capnet_conv1x1_tiles_m(M)
+    outs = []
+    for wgs in ("512", "8", "24"):
+        monkeypatch.setenv("CAPNET_H3_WGS", wgs)
+        y = torch.full((M, Cout), float("nan"), device=dev)
+        ps = torch.full((t, Cout), float("nan"), device=dev); pq = torch.full((t, Cout), float("nan"), device=dev)
+        check(L.capnet_conv1x1_fwd_f16x3(ptr(x), H * W * Cin, W * Cin, Cin, ptr(img), bn, ptr(y), ptr(sc), ptr(sh), 1,
+                                         ptr(ps), ptr(pq), B, H, W, Cin, Cout, 1, None, None, None, 0, current_stream()))
+        outs.append((y, ps, pq))
+    for y, ps, pq in outs[1:]:
+        assert torch.equal(y, outs[0][0]) and torch.equal(ps, outs[0][1]) and torch.equal(pq, outs[0][2])
+    assert torch.isfinite(outs[0][0]).all()

@@ -5,6 +5,7 @@ import capnet
 from capnet import ops
 from capnet._lib import check, current_stream, lib, ptr
 dev = torch.device("cuda:0"); L = lib()
+KIND = os.environ.get("X6_KIND", "f16x3")      # bf16x6 | f16x3
 def timed(fn, iters=30):
     for _ in range(3): fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -32,9 +33,9 @@ for name, (H, Cin, Cout, stride, pre) in SH.items():
     line = "%s M=%6d N=%4d K=%4d s%d pre%d:" % (name, M, Cout, Cin, stride, pre)
     for bn in bns:
         if Cout % bn: continue
-        img = torch.empty(L.capnet_conv1x1_bf16x6_weight_words(Cin, Cout), dtype=torch.int32, device=dev)
-        check(L.capnet_conv1x1_bf16x6_pack(ptr(w), ptr(img), Cout, Cin, bn, current_stream()))
-        us = timed(lambda: check(L.capnet_conv1x1_fwd_bf16x6(ptr(x), H * H * Cin, H * Cin, Cin, ptr(img), bn, ptr(y), ptr(sc), ptr(sh), pre,
+        img = torch.empty(getattr(L, 'capnet_conv1x1_%s_weight_words' % KIND)(Cin, Cout), dtype=torch.int32, device=dev)
+        check(getattr(L, 'capnet_conv1x1_%s_pack' % KIND)(ptr(w), ptr(img), Cout, Cin, bn, current_stream()))
+        us = timed(lambda: check(getattr(L, 'capnet_conv1x1_fwd_%s' % KIND)(ptr(x), H * H * Cin, H * Cin, Cin, ptr(img), bn, ptr(y), ptr(sc), ptr(sh), pre,
                                                               ptr(ps), ptr(pq), B, H, H, Cin, Cout, stride, None, None, None, 0, current_stream())))
         tot[bn] = tot.get(bn, 0) + us
         line += " x6/%d %6.1f us %6.1f TF/s |" % (bn, us, fl / us / 1e6)
