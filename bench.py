@@ -330,48 +330,57 @@ def main():
         capnet._lib.check(lib.capnet_trunk_collect_timing(plan["handle"], C.byref(ms), C.byref(n), C.byref(fl)))
         if n.value > 0:
             achieved = fl.value / (ms.value * 1e-3) / 1e12
-            roofline = {"bound": "mfma",
-                        "kernel": "the trunk's 155 conv launches: conv1x1_bf16x6_kernel (the 104 1x1 convs: six "
-                                  "v_mfma_f32_32x32x16_bf16 products of 3-way split fp32 operands, fp32-grade "
-                                  "results), conv_wino_kernel (Winograd F(2x2,3x3), v_mfma_f32_16x16x4_f32) for the "
-                                  "45 stride-1 3x3 convs, conv_f32_v2_kernel (implicit GEMM, v_mfma_f32_32x32x2_f32) "
-                                  "for the strided / 7x7-map 3x3 convs, conv_f32_kernel for the 7x7 stem; a launch "
-                                  "includes its tail fix-up if any",
-                        "flops": "ALGORITHMIC: 2*M*Cout*KH*KW*Cin of the direct sum (SURVEY 8d: 23.02 GFLOP per image), "
-                                 "priced against the f32 matrix peak the reference's arithmetic would need; what the "
-                                 "pipes executed is in `executed`",
-                        "how": "HIP events around every conv launch of the timed region, on its launch stream; "
-                               "duration = time with at least one conv launch running (union of the "
-                               "intervals: two trunk passes are in flight, their launches overlap)",
-                        "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": pmc_traffic()[0],
-                        "traffic_source": pmc_traffic()[1],
-                        "launches": n.value, "avg_launch_us": round(ms.value * 1e3 / n.value, 2),
-                        "flops_per_launch": fl.value / n.value}
-            # What the matrix pipes executed. Weight image kind 2 = Winograd: 16 multiplies per 2x2
-            # outputs and input channel instead of 36, f32 MFMA. Kind 4 = split-bf16 1x1 conv: six
-            # bf16 products per multiply on the bf16 pipe (peak 2.5 PFLOP/s dense). Everything else:
-            # f32 MFMA as counted. `frac` = time the two pipes would need at their peaks / conv time.
-            algo = f32x = bf16x = 0.0
+            # What the matrix pipes are asked to issue for one pass. Weight image kind 2 = Winograd: 16 multiplies
+            # per 2x2 outputs and input channel instead of 36, f32 MFMA. Kind 5 = split-f16 1x1 conv: three f16
+            # products per multiply; kind 4 = split-bf16: six bf16 products (both on the 16-bit matrix pipe, peak
+            # 2.5 PFLOP/s dense). Everything else: f32 MFMA as counted. The peak the union of the conv launches is
+            # priced against is the rate at which BOTH pipes, each at its own peak, would get through that work:
+            # algorithmic flops / (f32-issued / 157.3 + 16-bit-issued / 2500).
+            algo = f32x = bf16x = f16x = 0.0
             for i in range(lib.capnet_trunk_num_convs(plan["handle"])):
                 fi = lib.capnet_trunk_conv_flops(plan["handle"], i)
                 kind = lib.capnet_trunk_conv_kmajor(plan["handle"], i)
                 algo += fi
-                if kind == 4:
+                if kind == 5:
+                    f16x += 3.0 * fi
+                elif kind == 4:
                     bf16x += 6.0 * fi
                 else:
                     f32x += fi / (2.25 if kind == 2 else 1.0)
+            t_peak = f32x / MFMA_F32_PEAK_TFLOPS + (bf16x + f16x) / MFMA_BF16_PEAK_TFLOPS     # per pass, in 1e-12 s
+            peak_equiv = algo / t_peak
             per_s = achieved / algo          # TFLOP/s per algorithmic flop of a pass
+            roofline = {"bound": "mfma",
+                        "kernel": "the trunk's 155 conv launches: conv1x1_f16x3_kernel (the 104 1x1 convs: three "
+                                  "v_mfma_f32_32x32x16_f16 products of 2-way split, power-of-two scaled fp32 operands, "
+                                  "fp32-grade results), conv_wino_kernel (Winograd F(2x2,3x3), v_mfma_f32_16x16x4_f32) "
+                                  "for the 45 stride-1 3x3 convs, conv_f32_v2_kernel (implicit GEMM, "
+                                  "v_mfma_f32_32x32x2_f32) for the strided / 7x7-map 3x3 convs, conv_f32_kernel for the "
+                                  "7x7 stem; a launch includes its tail fix-up if any",
+                        "flops": "ALGORITHMIC: 2*M*Cout*KH*KW*Cin of the direct sum (SURVEY 8d: 23.02 GFLOP per image)",
+                        "peak_is": "algorithmic flops / (time the f32 matrix pipe needs for what is issued on it at "
+                                   "157.3 TFLOP/s + time the 16-bit matrix pipe needs for its share at 2500 TFLOP/s): "
+                                   "Winograd issues 16/36 of its direct-sum flops on the f32 pipe, a split-f16 1x1 conv "
+                                   "3 f16 products per multiply, the rest f32 as counted (breakdown in `executed`)",
+                        "how": "HIP events around every conv launch of the timed region, on its launch stream; "
+                               "duration = time with at least one conv launch running (union of the "
+                               "intervals: two trunk passes are in flight, their launches overlap)",
+                        "achieved": round(achieved, 2), "peak": round(peak_equiv, 2), "unit": "TFLOP/s",
+                        "frac": round(achieved / peak_equiv, 4), "traffic": pmc_traffic()[0],
+                        "traffic_source": pmc_traffic()[1],
+                        "launches": n.value, "avg_launch_us": round(ms.value * 1e3 / n.value, 2),
+                        "flops_per_launch": fl.value / n.value,
+                        "vs_f32_matrix_peak": round(achieved / MFMA_F32_PEAK_TFLOPS, 4)}
             roofline["executed"] = {
                 "f32_mfma": {"achieved": round(f32x * per_s, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                             "share_of_algorithmic_flops": round((algo - bf16x / 6.0) / algo, 4)},
+                             "share_of_algorithmic_flops": round((algo - bf16x / 6.0 - f16x / 3.0) / algo, 4)},
+                "f16_mfma": {"achieved": round(f16x * per_s, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "share_of_algorithmic_flops": round(f16x / 3.0 / algo, 4)},
                 "bf16_mfma": {"achieved": round(bf16x * per_s, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "share_of_algorithmic_flops": round(bf16x / 6.0 / algo, 4)},
-                "frac": round(f32x * per_s / MFMA_F32_PEAK_TFLOPS + bf16x * per_s / MFMA_BF16_PEAK_TFLOPS, 4),
-                "note": "flops the matrix pipes issued per second of conv time: Winograd layers at 16/36 of "
-                        "their direct-sum flops on the f32 pipe, the 1x1 layers at 6 bf16 products per multiply "
-                        "on the bf16 pipe (fp32-grade results, csrc/conv_bf16x6.hip); frac = sum over the two "
-                        "pipes of issued / peak"}
+                "frac": round(f32x * per_s / MFMA_F32_PEAK_TFLOPS + (bf16x + f16x) * per_s / MFMA_BF16_PEAK_TFLOPS, 4),
+                "note": "flops the matrix pipes issued per second of conv time; frac = sum over the pipes of issued / "
+                        "peak = roofline.frac"}
             if pipe is not None:
                 # In the timed region the convolutions share the chip with the previous batch's
                 # decoder (that is where the throughput comes from, and it lengthens each conv a
@@ -388,7 +397,7 @@ def main():
                 if n.value > 0:
                     alone = fl.value / (ms.value * 1e-3) / 1e12
                     roofline["alone"] = {"achieved": round(alone, 2),
-                                         "frac": round(alone / MFMA_F32_PEAK_TFLOPS, 4),
+                                         "frac": round(alone / peak_equiv, 4),
                                          "note": "same conv launches without the overlapped decoder"}
 
     # secondary roofline: the recurrent LSTM step (5.77 MB of algorithmic HBM
