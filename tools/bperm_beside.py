@@ -21,13 +21,15 @@ if name:
 P.launch_vmcnt_probe.argtypes = [C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
 vscr = torch.zeros(16 * 256 * 24, device=dev)
 vbuf = torch.arange(4 * 1024 * 1024, device=dev, dtype=torch.float32)
+P.launch_first_use_probe.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+fbuf = torch.arange(4 * 196 * 512, device=dev, dtype=torch.float32); ibuf = torch.arange(4 * 196 * 512, device=dev, dtype=torch.int32)
 P.launch_valu_probe.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
 P.launch_mfma_aggr.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
 dummy = torch.zeros(4, device=dev)
 P.launch_load_probe.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
 lbuf = torch.arange(4 * 196 * 512, device=dev, dtype=torch.float32)
 other = torch.cuda.Stream(); side = torch.cuda.Stream(priority=-1)
-out = torch.zeros(16, dtype=torch.int32, device=dev)
+out = torch.zeros(32, dtype=torch.int32, device=dev)
 torch.cuda.synchronize()
 for rep in range(5):
     other.wait_stream(torch.cuda.current_stream()); side.wait_stream(torch.cuda.current_stream())
@@ -40,12 +42,16 @@ for rep in range(5):
             P.launch_mfma_aggr(int(KIND[4:]), dummy.data_ptr(), 512, 20000, other.cuda_stream)
     for _ in range(40):
         P.launch_valu_probe(out.data_ptr(), 16, 2000, side.cuda_stream)
+        for _ in range(10):
+            P.launch_first_use_probe(fbuf.data_ptr(), ibuf.data_ptr(), 4, 196, 512, out.data_ptr(), side.cuda_stream)
         P.launch_vmcnt_probe(vbuf.data_ptr(), vbuf.numel(), 16, 200, out.data_ptr(), vscr.data_ptr(), side.cuda_stream)
         P.launch_probe(0, out.data_ptr(), 16, 2000, side.cuda_stream)
         P.launch_probe(1, out.data_ptr(), 16, 2000, side.cuda_stream)
         P.launch_load_probe(lbuf.data_ptr(), 4, 196, 512, out.data_ptr(), side.cuda_stream)
     torch.cuda.synchronize()
 o = out.cpu().tolist()
+print("first consumers of loaded registers (wrong of %d each): v_fma_f32 %d, v_pk_fma_f32 %d, v_mul_lo_u32 %d, v_exp_f32 %d, v_rcp_f32 %d, v_lshl_add_u64 %d, v_cvt_f32_u32 %d, v_cvt_f64_f32 %d"
+      % ((5 * 40 * 10 * 4 * 196 * 512 // 4,) + tuple(o[16:24])))
 print("counted-wait probe: wrong copies behind vmcnt(4) %d, (3) %d, (2) %d, (1) %d, (0) %d  (of %d loads each)" % (o[8], o[9], o[10], o[11], o[12], 5 * 40 * 16 * 256 * 200))
 print("valu probe (of %d each): wrong v_pk_fma_f32 %d, v_pk_fma_f32 op_sel_hi %d, v_pk_mul_f32 %d, v_pk_add_f32 %d, v_fma_f32 %d" % (5 * 40 * 16 * 256 * 2000, o[6], o[13], o[14], o[15], o[7]))
 print("load probe: wrong elements %d (first index %d got bits 0x%08x = %s)" % (o[2], o[3], o[4] & 0xffffffff, torch.tensor([o[4]], dtype=torch.int32).view(torch.float32).item()))

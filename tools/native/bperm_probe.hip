@@ -223,6 +223,60 @@ __global__ __launch_bounds__(256) void vmcnt_probe(const float* __restrict__ buf
 extern "C" void launch_vmcnt_probe(const float* buf, long n, int blocks, int iters, int* out, float* scratch, void* stream) {
   hipLaunchKernelGGL(vmcnt_probe, dim3(blocks), dim3(256), 0, (hipStream_t)stream, buf, n, iters, out, scratch);
 }
+// Which instructions are unsafe as FIRST consumers of freshly loaded registers beside an MFMA+VALU wave?  buf[i] == (float)i
+// (ibuf[i] == i). Same access pattern as att_scores; each loaded value goes straight into ONE instruction of the kind under
+// test and the result is compared with the value computed from the known index. out[16 + k]: k = 0 v_fma_f32, 1 v_pk_fma_f32,
+// 2 v_mul_lo_u32, 3 v_exp_f32, 4 v_rcp_f32, 5 v_lshl_add_u64, 6 v_cvt_f32_u32, 7 v_mul_f64 (via cvt)
+__global__ __launch_bounds__(256) void first_use_probe(const float* __restrict__ buf, const unsigned* __restrict__ ibuf, int rows, int A,
+                                                       int* out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int pc = (rows + 3) / 4;
+  const int p0 = blockIdx.y * pc, p1 = min(rows, p0 + pc);
+  const long rb = (long)blockIdx.x * rows * A;
+  int bad[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int p = p0 + 4 * wave; p < p1; p += 16) {
+    for (int a = lane * 4; a < A; a += 256) {
+      float4 x[4]; uint4 xi[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long e = rb + (long)min(p + u, p1 - 1) * A + a;
+        x[u] = *reinterpret_cast<const float4*>(buf + e);
+        xi[u] = *reinterpret_cast<const uint4*>(ibuf + e);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long e = rb + (long)min(p + u, p1 - 1) * A + a;
+        const float g0 = (float)e, g1 = (float)(e + 1), g2 = (float)(e + 2), g3 = (float)(e + 3);
+        float r0, r3, r4, r6; f2 r1; unsigned r2; unsigned long long r5; double r7;
+        const f2 pk = {x[u].y, x[u].z}; const f2 one = {1.f, 1.f}, three = {3.f, 3.f};
+        { const float c3 = 3.f, c1 = 1.f; asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(r0) : "v"(x[u].x), "v"(c3), "v"(c1)); }
+        asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r1) : "v"(pk), "v"(three), "v"(one));
+        { const unsigned c7 = 7u; asm volatile("v_mul_lo_u32 %0, %1, %2" : "=v"(r2) : "v"(xi[u].x), "v"(c7)); }
+        asm volatile("v_exp_f32 %0, %1" : "=v"(r3) : "v"(x[u].w));
+        asm volatile("v_rcp_f32 %0, %1" : "=v"(r4) : "v"(x[u].w));
+        const unsigned long long base = 0x100000000ull;
+        asm volatile("v_lshl_add_u64 %0, %1, 2, %2" : "=v"(r5) : "v"((unsigned long long)xi[u].y | ((unsigned long long)xi[u].z << 32)), "v"(base));
+        asm volatile("v_cvt_f32_u32 %0, %1" : "=v"(r6) : "v"(xi[u].w));
+        asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(r7) : "v"(x[u].x));
+        float w3, w4;
+        asm volatile("v_exp_f32 %0, %1" : "=v"(w3) : "v"(g3));
+        asm volatile("v_rcp_f32 %0, %1" : "=v"(w4) : "v"(g3));
+        if (r0 != g0 * 3.f + 1.f) ++bad[0];
+        if (r1[0] != g1 * 3.f + 1.f || r1[1] != g2 * 3.f + 1.f) ++bad[1];
+        if (r2 != (unsigned)e * 7u) ++bad[2];
+        if (__float_as_uint(r3) != __float_as_uint(w3)) ++bad[3];
+        if (__float_as_uint(r4) != __float_as_uint(w4)) ++bad[4];
+        if (r5 != ((((unsigned long long)(unsigned)(e + 1)) | ((unsigned long long)(unsigned)(e + 2) << 32)) << 2) + base) ++bad[5];
+        if (r6 != g3) ++bad[6];
+        if (r7 != (double)g0) ++bad[7];
+      }
+    }
+  }
+  for (int k = 0; k < 8; ++k) if (bad[k]) atomicAdd(out + 16 + k, bad[k]);
+}
+extern "C" void launch_first_use_probe(const float* buf, const unsigned* ibuf, int batch, int rows, int A, int* out, void* stream) {
+  hipLaunchKernelGGL(first_use_probe, dim3(batch, 4), dim3(256), 0, (hipStream_t)stream, buf, ibuf, rows, A, out);
+}
 extern "C" void launch_probe(int dpp, int* out, int blocks, int iters, void* stream) {
   if (dpp) hipLaunchKernelGGL(probe<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, out, iters);
   else hipLaunchKernelGGL(probe<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, out, iters);
