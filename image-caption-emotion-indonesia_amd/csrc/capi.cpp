@@ -78,6 +78,22 @@ int capnet_conv1x1_fwd_f16x3(const float* x, long sxb, long sxh, long sxw, const
                            H, W, Cin, Cout, stride, S(stream), out_scale, out_shift, res, relu_out);
 }
 
+size_t capnet_conv_f16x3_weight_words(int Cin, int Cout, int k) { return conv_f16x3_weight_words(Cin, Cout, k); }
+int capnet_conv_f16x3_pack(const float* w_oihw, unsigned* image, int Cout, int Cin, int k, int bn,
+                           capnet_stream_t stream) {
+  return conv_f16x3_pack(w_oihw, image, Cout, Cin, k, bn, S(stream));
+}
+int capnet_conv2d_fwd_f16x3(const float* x, long sxb, long sxh, long sxw, const unsigned* image, int bn, float* y,
+                            const float* in_scale, const float* in_shift, int relu_in, float* part_sum,
+                            float* part_sq, int B, int H, int W, int Cin, int Cout, int k, int stride, int pad,
+                            const float* out_scale, const float* out_shift, const float* res, int relu_out,
+                            capnet_stream_t stream) {
+  CAPNET_REQUIRE(conv_f16x3_eligible(x, sxb, sxh, sxw, 1, B, H, W, Cin, Cout, k, stride, pad, in_scale, in_shift),
+                 "capnet_conv2d_fwd_f16x3: operands not eligible (k = 1 / pad 0 or k = 3 / pad 1, Cin %% 64, Cout %% 64, 16-B aligned rows, Cin <= 512 with a folded input)");
+  return conv_fwd_f16x3(x, sxb, sxh, sxw, image, bn, y, in_scale, in_shift, relu_in, part_sum, part_sq, B, H, W,
+                        Cin, Cout, k, stride, pad, S(stream), out_scale, out_shift, res, relu_out);
+}
+
 int capnet_sgemm_splitk(int transA, int transB, int M, int N, int K, const float* A, long lda,
                         const float* B, long ldb, float* C, long ldc, const float* bias,
                         int accumulate, float* workspace, size_t workspace_floats,

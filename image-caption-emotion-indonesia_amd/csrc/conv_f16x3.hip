@@ -9,10 +9,16 @@
 // shapes (tests/test_kernels_gpu.py): at or below the f32-MFMA kernels' -- the fp32 accumulation of K
 // products, not the 2^-23 of the operands, sets it (numpy model of all three: tools/split_error.py).
 //
-// Scales. Activations: 2^4 (h of an O(1) activation keeps a normal residual down to |x| = 2^-6; smaller
-// ones have a subnormal l, exact to 2^-28; the range ends at |x| = 4094, far beyond what a BatchNorm
-// leaves). Weights: 2^ew chosen per tensor at pack time so that max |w| 2^ew lies in [2^13, 2^14)
-// (stored in the image's header). The epilogue multiplies the accumulators by 2^-(4 + ew): exact.
+// Scales. Weights: 2^ew chosen per tensor at pack time so that max |w| 2^ew lies in [2^13, 2^14) (stored in
+// the image's header): their residuals are normal f16 numbers. Activations are split as they are: the
+// residual of an activation below 0.25 is a subnormal f16, exact to 2^-25 absolute, which the MFMA keeps
+// (a 2^4 prescale changed no digit of the rms error in the model or on the GPU and cost two VALU per pair);
+// the range ends at |x| = 65504. The epilogue multiplies the accumulators by 2^-ew: exact.
+//
+// The same kernel runs the 3x3 convolutions (TAPS = 9) as an implicit GEMM over k = (tap, channel): a step is
+// 32 channels of one tap, the A loader moves to the next tap's pixel every Cin / 32 steps and zeroes what
+// falls into the padding (med3 bounds of the fold, or a 0 / 1 factor) -- three f16 products on the 16-bit pipe
+// (27 Cin f16 MACs per output) need 2.4x less matrix time than Winograd's 4 Cin f32 MACs on the f32 pipe.
 //
 // Replaces conv_bf16x6.hip on the 1x1 convolutions of the ResNet-152 bottlenecks in train mode
 // (torchvision Bottleneck conv1 / conv3 / downsample, call sites stylenet/model.py:15-18,24) whenever
@@ -31,7 +37,7 @@
 //     arrive] then 8 phases of 2..3 MFMAs with one pair-of-pairs of the next step's fold + split between them
 //     (sched_barrier pins the phases, a volatile use pins each phase's VALU), the last two MFMAs cover the
 //     LDS writes and the issue of the loads two steps ahead;
-//   * epilogue: accumulators x 2^-(4+ew), stored straight from the MFMA layout (2 rows x 128 B per instruction);
+//   * epilogue: accumulators x 2^-ew, stored straight from the MFMA layout (2 rows x 128 B per instruction);
 //     column statistics as everywhere (block_col_stats).
 #include <cstdlib>
 
@@ -49,7 +55,6 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int HBM = 128, HBK = 32;
-constexpr int kActShift = 4;                     // activations are split as x 2^4
 constexpr int kSubA = HBM * 2 * 16;              // bytes of one (plane, k16 group) of the A image: 128 rows x 2 cells
 constexpr int kHdrWords = 4;                     // image header: [0] ew, [1] bits of max |w| (pack scratch)
 constexpr int kFoldMaxH = 512;                   // input channels whose BatchNorm scale / shift live in LDS
@@ -68,7 +73,8 @@ struct HArgs {
   const float* res;
   int relu_out;
   int M, Cin, Cout, relu_in;
-  int abl;   // diagnostics (CAPNET_H3_ABLATE): 4 no statistics, 8 no output stores, 32 every wait vmcnt(0), 64 no MFMAs, 256 no loads in the loop
+  int H, W, pad;             // input map and zero padding (3x3 convolutions)
+  int abl;   // diagnostics (CAPNET_H3_ABLATE): 4 no statistics, 8 no output stores, 32 every wait vmcnt(0), 256 no loads in the loop
   int tiles_m, tiles_n;
   long long* stamps;   // diagnostics (CAPNET_H3_STAMPS = device address): workgroup 0 records 4 clock values per step
   unsigned tn_mul, tn_sh;
@@ -76,12 +82,15 @@ struct HArgs {
   unsigned ohw_mul, ohw_sh, ow_mul, ow_sh;
 };
 
-__device__ __forceinline__ unsigned h_row_offset(const HArgs& g, int m) {
+// output row m -> image offset (floats) and the input coordinates of tap (0, 0)
+__device__ __forceinline__ void h_row_origin(const HArgs& g, int m, int& boff, int& ih0, int& iw0) {
   const int b = (int)fast_div((unsigned)m, g.ohw_mul, g.ohw_sh);
   const int rem = m - b * g.OHW;
   const int oh = (int)fast_div((unsigned)rem, g.ow_mul, g.ow_sh);
   const int ow = rem - oh * g.OW;
-  return (unsigned)(b * g.sxb + oh * g.stride * g.sxh + ow * g.stride * g.sxw);
+  boff = b * g.sxb;
+  ih0 = oh * g.stride - g.pad;
+  iw0 = ow * g.stride - g.pad;
 }
 
 // byte offset of cell (row, c) inside one (plane, group) sub-image
@@ -102,14 +111,15 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned& h, unsigned
 template <int NBR>
 struct HRegs {
   f32x4 a[4], b[NBR];
+  float lo, hi;      // TAPS > 1: the fold's bounds for this step's tap (0, 0 in the padding; PRE) or the factor 0 / 1 in hi
 };
 
 template <int N> __device__ __forceinline__ void h_wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BN, bool PRE>
-__global__ __launch_bounds__(256, 2) void conv1x1_f16x3_kernel(const HArgs g) {
+template <int BN, bool PRE, int TAPS>
+__global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const HArgs g) {
   constexpr int NT = BN / 64;
   constexpr int kSubB = BN * 2 * 16;
   constexpr int kImgA = 4 * kSubA, kImgB = 4 * kSubB;
@@ -134,38 +144,50 @@ __global__ __launch_bounds__(256, 2) void conv1x1_f16x3_kernel(const HArgs g) {
     }
   };
   const int total = g.tiles_m * g.tiles_n, G = (int)gridDim.x;
-  const int nk = g.Cin / HBK;
+  const int nkc = g.Cin / HBK;               // steps per tap
+  const int nk = TAPS * nkc;
   const int my_tiles = (total - 1 - (int)blockIdx.x) / G + 1;
   const int n_it = my_tiles * nk;
   const float* wimg = reinterpret_cast<const float*>(g.wimg + kHdrWords);
-  const float oscale = ldexpf(1.f, -(kActShift + (int)g.wimg[0]));
-  const float ascale = (float)(1 << kActShift);
+  const float oscale = ldexpf(1.f, -(int)g.wimg[0]);
 
   const int arow = tid >> 1, ag = tid & 1;          // A staging: this thread's row and k16 group
-  const float lo = g.relu_in ? 0.f : -__builtin_inff();
 
   // ---- issue cursor: two steps ahead of the MFMAs
-  int iw = (int)blockIdx.x, ikt = 0;
+  int iw = (int)blockIdx.x, ikc = 0, itap = 0;
   unsigned i_avoff = 0;
+  int i_boff = 0, i_ih0 = 0, i_iw0 = 0;
+  bool i_ok = true;
   const float* i_sA = g.x;
   const float* i_sB = nullptr;
+  // this thread's pixel of the current tap: clamped into the map (the load is always legal), i_ok says whether it counts
+  auto i_tap = [&]() {
+    const int kh = TAPS == 1 ? 0 : itap / 3, kw = TAPS == 1 ? 0 : itap - 3 * (itap / 3);
+    const int ih = i_ih0 + kh, iwp = i_iw0 + kw;
+    if (TAPS > 1) i_ok = (unsigned)ih < (unsigned)g.H && (unsigned)iwp < (unsigned)g.W;
+    const int ihc = TAPS == 1 ? ih : min(max(ih, 0), g.H - 1), iwc = TAPS == 1 ? iwp : min(max(iwp, 0), g.W - 1);
+    i_avoff = (unsigned)(i_boff + ihc * g.sxh + iwc * g.sxw + 16 * ag) * 4u;
+    i_sA = g.x;
+  };
   auto i_tile = [&]() {
     const int id = xcd_remap(iw, total);
     const int tm = (int)fast_div((unsigned)id, g.tn_mul, g.tn_sh), tn = id - tm * g.tiles_n;
     const int am = tm * HBM + arow;
-    i_avoff = (h_row_offset(g, am < g.M ? am : g.M - 1) + 16u * ag) * 4u;   // rows past M: a valid row, zeroed in the epilogue
-    i_sA = g.x;
+    h_row_origin(g, am < g.M ? am : g.M - 1, i_boff, i_ih0, i_iw0);   // rows past M: a valid row, zeroed in the epilogue
+    itap = 0;
+    i_tap();
     i_sB = wimg + ((long)tn * nk) * (kImgB / 4);
   };
   i_tile();
   if (PRE) {
     float* f = reinterpret_cast<float*>(lds + 2 * kStage + 4 * BN * 4);
     for (int i = tid; i < g.Cin; i += 256) {
-      f[i] = g.in_scale[i] * ascale;            // (power of two: the fold rounds exactly as without it)
-      f[kFoldMaxH + i] = g.in_shift[i] * ascale;
+      f[i] = g.in_scale[i];
+      f[kFoldMaxH + i] = g.in_shift[i];
     }
     __syncthreads();
   }
+  const float lo = g.relu_in ? 0.f : -__builtin_inff();
   // Loads are only ever issued for steps that exist and every issued set is consumed (landed): a register
   // written by a load nobody consumes is free for the compiler to reuse at once, and the load would land in
   // whatever lives there by then.
@@ -174,12 +196,20 @@ __global__ __launch_bounds__(256, 2) void conv1x1_f16x3_kernel(const HArgs g) {
     for (int q = 0; q < NBR; ++q) gload16(R.b[q], i_sB, (unsigned)((tid + 256 * q) * 16));
 #pragma unroll
     for (int q = 0; q < 4; ++q) gload16(R.a[q], i_sA + 4 * q, i_avoff);
+    if (TAPS > 1) {
+      R.lo = i_ok ? lo : 0.f;
+      R.hi = i_ok ? (PRE ? __builtin_inff() : 1.f) : 0.f;
+    }
     i_sB += kImgB / 4;
     i_sA += HBK;
-    if (++ikt == nk) {
-      ikt = 0;
-      if (iw + G < total) iw += G;
-      i_tile();
+    if (++ikc == nkc) {
+      ikc = 0;
+      if (++itap == TAPS) {
+        if (iw + G < total) iw += G;
+        i_tile();
+      } else {
+        i_tap();
+      }
     }
   };
   auto landed = [&](HRegs<NBR>& R) {
@@ -202,14 +232,23 @@ __global__ __launch_bounds__(256, 2) void conv1x1_f16x3_kernel(const HArgs g) {
   int st_k = 16 * ag;            // this thread's first channel of the step being staged (PRE)
   const unsigned awr0 = h_cell(arow, 0), awr1 = h_cell(arow, 1);
   // fold + split of one pair of the staged step (pair p = floats 2p, 2p + 1 of the thread's 16)
-  auto stage_pair = [&](const float* x, const float* fs, const float* ft, int p, unsigned& h, unsigned& l) {
+  // (blo, bhi: the fold's bounds -- [lo, inf) inside the map, [0, 0] in the padding of a 3x3 convolution; without a
+  //  fold bhi is the factor 1 / 0)
+  auto stage_pair = [&](const float* x, const float* fs, const float* ft, int p, float blo, float bhi, unsigned& h, unsigned& l) {
     float x0 = x[2 * p], x1 = x[2 * p + 1];
     if (PRE) {
-      x0 = fmaxf(fmaf(x0, fs[2 * p], ft[2 * p]), lo);
-      x1 = fmaxf(fmaf(x1, fs[2 * p + 1], ft[2 * p + 1]), lo);
-    } else {
-      x0 *= ascale;
-      x1 *= ascale;
+      x0 = fmaf(x0, fs[2 * p], ft[2 * p]);
+      x1 = fmaf(x1, fs[2 * p + 1], ft[2 * p + 1]);
+      if (TAPS > 1) {
+        x0 = __builtin_amdgcn_fmed3f(x0, blo, bhi);
+        x1 = __builtin_amdgcn_fmed3f(x1, blo, bhi);
+      } else {
+        x0 = fmaxf(x0, lo);
+        x1 = fmaxf(x1, lo);
+      }
+    } else if (TAPS > 1) {
+      x0 *= bhi;
+      x1 *= bhi;
     }
     split2(x0, x1, h, l);
   };
@@ -242,7 +281,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_f16x3_kernel(const HArgs g) {
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
       unsigned h, l;
-      stage_pair(x, fs, ft, p, h, l);
+      stage_pair(x, fs, ft, p, R.lo, R.hi, h, l);
       ph[p >> 2][p & 3] = h; pl[p >> 2][p & 3] = l;
     }
     unsigned char* d = lds + stage * kStage + ag * kSubA;
@@ -284,7 +323,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_f16x3_kernel(const HArgs g) {
       if (st_k >= g.Cin) st_k -= g.Cin;
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (pending && !(g.abl & 64)) tail(Tp);
+    if (pending) tail(Tp);
     __builtin_amdgcn_sched_barrier(0);
     float x[16];
 #pragma unroll
@@ -298,7 +337,6 @@ __global__ __launch_bounds__(256, 2) void conv1x1_f16x3_kernel(const HArgs g) {
     constexpr int NH = 5 * 2 * NT;            // 20 / 10
     constexpr int HP = NH - 2;                // spread over the 8 phases; the last two cover writes + issue
     auto head = [&](int idx) {
-      if (g.abl & 64) return;
       const int t5 = idx / (2 * NT), mt = (idx % (2 * NT)) / NT, nt = idx % NT;
       const int gq = t5 < 3 ? 0 : 1, term = t5 < 3 ? t5 : t5 - 3;          // term 0: l h', 1: h l', 2: h h'
       const int pa = term == 0 ? 1 : 0, pb = term == 1 ? 1 : 0;
@@ -313,7 +351,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_f16x3_kernel(const HArgs g) {
         const int p = phase & 3;
         const float fs[8] = {fsv[0][0], fsv[0][1], fsv[0][2], fsv[0][3], fsv[1][0], fsv[1][1], fsv[1][2], fsv[1][3]};
         const float ft[8] = {ftv[0][0], ftv[0][1], ftv[0][2], ftv[0][3], ftv[1][0], ftv[1][1], ftv[1][2], ftv[1][3]};
-        stage_pair(x + 8 * (phase >> 2), fs, ft, p, h, l);
+        stage_pair(x + 8 * (phase >> 2), fs, ft, p, R.lo, R.hi, h, l);
       }
       asm volatile("" : "+v"(h), "+v"(l));        // (a volatile use keeps the phase's VALU here: pure IR sinks to its ds_write)
       ph[phase >> 2][phase & 3] = h;
@@ -355,7 +393,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_f16x3_kernel(const HArgs g) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mt][nt][r] *= oscale;          // 2^-(4 + ew): exact
+        for (int r = 0; r < 16; ++r) acc[mt][nt][r] *= oscale;          // 2^-ew: exact
     if (ragged) {
       // rows past M were computed from a clamped row: keep them out of the statistics
 #pragma unroll
@@ -490,14 +528,15 @@ __device__ __forceinline__ int h_weight_shift(unsigned absmax_bits) {
   return ew < -100 ? -100 : (ew > 100 ? 100 : ew);
 }
 
-// One thread per (tn, kt, plane, group, row, pos): 8 consecutive k of output channel n -> one 16-B cell.
+// One thread per (tn, kt, plane, group, row, pos): 8 consecutive channels of output channel n and tap kt / (Cin / 32)
+// -> one 16-B cell. w is OIHW: [Cout][Cin][taps].
 template <int BN>
-__global__ __launch_bounds__(256) void conv1x1_f16x3_pack_kernel(const float* __restrict__ w, unsigned* __restrict__ img,
-                                                                 int Cout, int Cin) {
+__global__ __launch_bounds__(256) void conv_f16x3_pack_kernel(const float* __restrict__ w, unsigned* __restrict__ img,
+                                                              int Cout, int Cin, int taps) {
   const int ew = h_weight_shift(img[1]);
   if (blockIdx.x == 0 && threadIdx.x == 0) img[0] = (unsigned)ew;
   const float ws = ldexpf(1.f, ew);
-  const int nk = Cin / HBK, tiles_n = Cout / BN;
+  const int nkc = Cin / HBK, nk = taps * nkc, tiles_n = Cout / BN;
   const long cells = (long)tiles_n * nk * 4 * BN * 2;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < cells; i += (long)gridDim.x * blockDim.x) {
     long r = i;
@@ -508,11 +547,12 @@ __global__ __launch_bounds__(256) void conv1x1_f16x3_pack_kernel(const float* __
     const int tn = (int)(r / nk);
     const int plane = sub >> 1, gq = sub & 1;
     const int c = pos ^ (((row & 15) >> 3) & 1);
-    const float* src = w + (long)(tn * BN + row) * Cin + kt * HBK + gq * 16 + 8 * c;
+    const int tap = kt / nkc, c0 = (kt - tap * nkc) * HBK + gq * 16 + 8 * c;
+    const float* src = w + ((long)(tn * BN + row) * Cin + c0) * taps + tap;
     unsigned out[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const float x0 = src[2 * q] * ws, x1 = src[2 * q + 1] * ws;
+      const float x0 = src[(2 * q) * taps] * ws, x1 = src[(2 * q + 1) * taps] * ws;
       const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
       const _Float16 l0 = (_Float16)(x0 - (float)h0), l1 = (_Float16)(x1 - (float)h1);
       const f16x2 p = plane == 0 ? f16x2{h0, h1} : f16x2{l0, l1};
@@ -525,58 +565,67 @@ __global__ __launch_bounds__(256) void conv1x1_f16x3_pack_kernel(const float* __
 
 }  // namespace
 
-bool conv1x1_f16x3_eligible(const float* x, long sxb, long sxh, long sxw, long sxc, int Bn, int H, int W,
-                            int Cin, int Cout, int stride, const float* in_scale, const float* in_shift) {
-  const long OH = (H - 1) / stride + 1, OW = (W - 1) / stride + 1;
+bool conv_f16x3_eligible(const float* x, long sxb, long sxh, long sxw, long sxc, int Bn, int H, int W, int Cin,
+                         int Cout, int k, int stride, int pad, const float* in_scale, const float* in_shift) {
+  if (!((k == 1 && pad == 0) || (k == 3 && pad == 1))) return false;
+  const long OH = (H + 2 * pad - k) / stride + 1, OW = (W + 2 * pad - k) / stride + 1;
   return sxc == 1 && Cin % (2 * HBK) == 0 && Cout % 64 == 0 && aligned16(x) && sxb % 4 == 0 && sxh % 4 == 0 &&
-         sxw % 4 == 0 && (long)Bn * sxb * 4 < (1l << 32) && (long)Bn * OH * OW < (1l << 24) &&
+         sxw % 4 == 0 && (long)Bn * sxb * 4 < (1l << 31) && (long)Bn * OH * OW < (1l << 24) &&
          (long)Bn * OH * OW * Cout * 4 < (1l << 32) &&
          (!in_scale || (aligned16(in_scale) && aligned16(in_shift) && Cin <= kFoldMaxH));
+}
+bool conv1x1_f16x3_eligible(const float* x, long sxb, long sxh, long sxw, long sxc, int Bn, int H, int W,
+                            int Cin, int Cout, int stride, const float* in_scale, const float* in_shift) {
+  return conv_f16x3_eligible(x, sxb, sxh, sxw, sxc, Bn, H, W, Cin, Cout, 1, stride, 0, in_scale, in_shift);
 }
 
 int conv1x1_f16x3_bn(long M, int Cout) {
   (void)M;
   return Cout % 128 == 0 ? 128 : 64;
 }
-size_t conv1x1_f16x3_weight_words(int Cin, int Cout) { return (size_t)kHdrWords + (size_t)Cout * Cin; }
+size_t conv_f16x3_weight_words(int Cin, int Cout, int k) { return (size_t)kHdrWords + (size_t)Cout * Cin * k * k; }
+size_t conv1x1_f16x3_weight_words(int Cin, int Cout) { return conv_f16x3_weight_words(Cin, Cout, 1); }
 
-// w [Cout][Cin] fp32 -> header + the split f16 image for tile width bn
-int conv1x1_f16x3_pack(const float* w, unsigned* img, int Cout, int Cin, int bn, hipStream_t stream) {
-  CAPNET_REQUIRE(w && img && Cin % HBK == 0 && (bn == 64 || bn == 128) && Cout % bn == 0 && aligned16(img),
-                 "conv1x1_f16x3_pack: bad argument (Cin=%d Cout=%d bn=%d)", Cin, Cout, bn);
+// w OIHW fp32 ([Cout][Cin][k][k]) -> header + the split f16 image for tile width bn
+int conv_f16x3_pack(const float* w, unsigned* img, int Cout, int Cin, int k, int bn, hipStream_t stream) {
+  CAPNET_REQUIRE(w && img && Cin % HBK == 0 && (k == 1 || k == 3) && (bn == 64 || bn == 128) && Cout % bn == 0 && aligned16(img),
+                 "conv_f16x3_pack: bad argument (Cin=%d Cout=%d k=%d bn=%d)", Cin, Cout, k, bn);
   CAPNET_HIP_CHECK(hipMemsetAsync(img, 0, kHdrWords * 4, stream));
-  const long n = (long)Cout * Cin;
+  const long n = (long)Cout * Cin * k * k;
   hipLaunchKernelGGL(conv1x1_f16x3_absmax_kernel, dim3((int)(cdiv(n, 256 * 8) > 1024 ? 1024 : cdiv(n, 256 * 8))), dim3(256), 0,
                      stream, w, img, n);
   CAPNET_LAUNCH_CHECK();
   const long cells = n / 2;
   const int grid = (int)(cdiv(cells, 256) > 4096 ? 4096 : cdiv(cells, 256));
-  if (bn == 128) hipLaunchKernelGGL(conv1x1_f16x3_pack_kernel<128>, dim3(grid), dim3(256), 0, stream, w, img, Cout, Cin);
-  else hipLaunchKernelGGL(conv1x1_f16x3_pack_kernel<64>, dim3(grid), dim3(256), 0, stream, w, img, Cout, Cin);
+  if (bn == 128) hipLaunchKernelGGL(conv_f16x3_pack_kernel<128>, dim3(grid), dim3(256), 0, stream, w, img, Cout, Cin, k * k);
+  else hipLaunchKernelGGL(conv_f16x3_pack_kernel<64>, dim3(grid), dim3(256), 0, stream, w, img, Cout, Cin, k * k);
   CAPNET_LAUNCH_CHECK();
   return kOk;
 }
+int conv1x1_f16x3_pack(const float* w, unsigned* img, int Cout, int Cin, int bn, hipStream_t stream) {
+  return conv_f16x3_pack(w, img, Cout, Cin, 1, bn, stream);
+}
 
-int conv1x1_fwd_f16x3(const float* x, long sxb, long sxh, long sxw, const unsigned* wimg, int bn, float* y,
-                      const float* in_scale, const float* in_shift, int relu_in, float* part_sum,
-                      float* part_sq, int Bn, int H, int W, int Cin, int Cout, int stride,
-                      hipStream_t stream, const float* out_scale, const float* out_shift, const float* res,
-                      int relu_out) {
-  CAPNET_REQUIRE(x && wimg && y && stride >= 1, "conv1x1_fwd_f16x3: bad argument");
-  CAPNET_REQUIRE(conv1x1_f16x3_eligible(x, sxb, sxh, sxw, 1, Bn, H, W, Cin, Cout, stride, in_scale, in_shift) &&
+int conv_fwd_f16x3(const float* x, long sxb, long sxh, long sxw, const unsigned* wimg, int bn, float* y,
+                   const float* in_scale, const float* in_shift, int relu_in, float* part_sum, float* part_sq, int Bn,
+                   int H, int W, int Cin, int Cout, int k, int stride, int pad, hipStream_t stream,
+                   const float* out_scale, const float* out_shift, const float* res, int relu_out) {
+  CAPNET_REQUIRE(x && wimg && y && stride >= 1, "conv_fwd_f16x3: bad argument");
+  CAPNET_REQUIRE(conv_f16x3_eligible(x, sxb, sxh, sxw, 1, Bn, H, W, Cin, Cout, k, stride, pad, in_scale, in_shift) &&
                      aligned16(wimg) && (bn == 64 || bn == 128) && Cout % bn == 0,
-                 "conv1x1_fwd_f16x3: operands not eligible");
-  CAPNET_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv1x1_fwd_f16x3: scale/shift pair");
-  CAPNET_REQUIRE((part_sum == nullptr) == (part_sq == nullptr), "conv1x1_fwd_f16x3: stats pair");
-  CAPNET_REQUIRE(!out_scale || (out_shift && !part_sum), "conv1x1_fwd_f16x3: folded epilogue takes no statistics");
+                 "conv_fwd_f16x3: operands not eligible");
+  CAPNET_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv_fwd_f16x3: scale/shift pair");
+  CAPNET_REQUIRE((part_sum == nullptr) == (part_sq == nullptr), "conv_fwd_f16x3: stats pair");
+  CAPNET_REQUIRE(!out_scale || (out_shift && !part_sum), "conv_fwd_f16x3: folded epilogue takes no statistics");
   HArgs a{};
-  const int OH = (H - 1) / stride + 1, OW = (W - 1) / stride + 1;
+  const int OH = (H + 2 * pad - k) / stride + 1, OW = (W + 2 * pad - k) / stride + 1;
   a.x = x; a.wimg = wimg; a.y = y; a.in_scale = in_scale; a.in_shift = in_shift;
   a.part_sum = part_sum; a.part_sq = part_sq;
   a.out_scale = out_scale; a.out_shift = out_shift; a.res = res; a.relu_out = relu_out;
   { const char* e = getenv("CAPNET_H3_ABLATE"); a.abl = e ? atoi(e) : 0; }
   { const char* e = getenv("CAPNET_H3_STAMPS"); a.stamps = e ? reinterpret_cast<long long*>(strtoull(e, nullptr, 0)) : nullptr; }
   a.M = Bn * OH * OW; a.Cin = Cin; a.Cout = Cout; a.relu_in = relu_in;
+  a.H = H; a.W = W; a.pad = pad;
   a.tiles_m = cdiv(a.M, HBM); a.tiles_n = Cout / bn;
   magic_div((unsigned)a.tiles_n, &a.tn_mul, &a.tn_sh);
   a.OW = OW; a.OHW = OH * OW; a.stride = stride;
@@ -589,15 +638,25 @@ int conv1x1_fwd_f16x3(const float* x, long sxb, long sxh, long sxw, const unsign
   const int cap = ge ? atoi(ge) : 512;
   const int total = a.tiles_m * a.tiles_n;
   const dim3 grid(total <= cap ? total : cap), block(256);
-  if (bn == 128) {
-    if (in_scale) hipLaunchKernelGGL((conv1x1_f16x3_kernel<128, true>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((conv1x1_f16x3_kernel<128, false>), grid, block, 0, stream, a);
+#define CAPNET_H3_LAUNCH(BN_, PRE_, TAPS_) hipLaunchKernelGGL((conv_f16x3_kernel<BN_, PRE_, TAPS_>), grid, block, 0, stream, a)
+  if (k == 1) {
+    if (bn == 128) { if (in_scale) CAPNET_H3_LAUNCH(128, true, 1); else CAPNET_H3_LAUNCH(128, false, 1); }
+    else { if (in_scale) CAPNET_H3_LAUNCH(64, true, 1); else CAPNET_H3_LAUNCH(64, false, 1); }
   } else {
-    if (in_scale) hipLaunchKernelGGL((conv1x1_f16x3_kernel<64, true>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((conv1x1_f16x3_kernel<64, false>), grid, block, 0, stream, a);
+    if (bn == 128) { if (in_scale) CAPNET_H3_LAUNCH(128, true, 9); else CAPNET_H3_LAUNCH(128, false, 9); }
+    else { if (in_scale) CAPNET_H3_LAUNCH(64, true, 9); else CAPNET_H3_LAUNCH(64, false, 9); }
   }
+#undef CAPNET_H3_LAUNCH
   CAPNET_LAUNCH_CHECK();
   return kOk;
+}
+int conv1x1_fwd_f16x3(const float* x, long sxb, long sxh, long sxw, const unsigned* wimg, int bn, float* y,
+                      const float* in_scale, const float* in_shift, int relu_in, float* part_sum,
+                      float* part_sq, int Bn, int H, int W, int Cin, int Cout, int stride,
+                      hipStream_t stream, const float* out_scale, const float* out_shift, const float* res,
+                      int relu_out) {
+  return conv_fwd_f16x3(x, sxb, sxh, sxw, wimg, bn, y, in_scale, in_shift, relu_in, part_sum, part_sq, Bn, H, W, Cin,
+                        Cout, 1, stride, 0, stream, out_scale, out_shift, res, relu_out);
 }
 
 }  // namespace capnet

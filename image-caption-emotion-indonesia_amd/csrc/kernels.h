@@ -81,6 +81,16 @@ int conv1x1_fwd_bf16x6(const float* x, long sxb, long sxh, long sxw, const unsig
 bool conv1x1_f16x3_eligible(const float* x, long sxb, long sxh, long sxw, long sxc, int Bn, int H, int W,
                             int Cin, int Cout, int stride, const float* in_scale, const float* in_shift);
 int conv1x1_f16x3_bn(long M, int Cout);
+// ... and the 3x3 (pad 1) convolutions as an implicit GEMM over (tap, channel) in the same kernel: k = 1 or 3
+bool conv_f16x3_eligible(const float* x, long sxb, long sxh, long sxw, long sxc, int Bn, int H, int W, int Cin,
+                         int Cout, int k, int stride, int pad, const float* in_scale, const float* in_shift);
+size_t conv_f16x3_weight_words(int Cin, int Cout, int k);
+int conv_f16x3_pack(const float* w_oihw, unsigned* img, int Cout, int Cin, int k, int bn, hipStream_t stream);
+int conv_fwd_f16x3(const float* x, long sxb, long sxh, long sxw, const unsigned* wimg, int bn, float* y,
+                   const float* in_scale, const float* in_shift, int relu_in, float* part_sum, float* part_sq, int Bn,
+                   int H, int W, int Cin, int Cout, int k, int stride, int pad, hipStream_t stream,
+                   const float* out_scale = nullptr, const float* out_shift = nullptr, const float* res = nullptr,
+                   int relu_out = 0);
 size_t conv1x1_f16x3_weight_words(int Cin, int Cout);
 int conv1x1_f16x3_pack(const float* w, unsigned* img, int Cout, int Cin, int bn, hipStream_t stream);
 int conv1x1_fwd_f16x3(const float* x, long sxb, long sxh, long sxw, const unsigned* wimg, int bn, float* y,

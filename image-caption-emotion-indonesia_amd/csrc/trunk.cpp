@@ -14,6 +14,8 @@
 //   OUT = relu(bn3(Y3) + (bnD(D) | X))         (bn_add_relu)
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
+#include <cstdio>
 #include <utility>
 #include <vector>
 
@@ -32,7 +34,7 @@ struct TrunkConv {
   bool dma1x1; // 1x1 on an activated input (conv1, downsample): LDS-DMA NT core (gemm_dma.hip), weights as [Cout][Cin]
   bool x6;     // 1x1: six bf16 MFMA products of 3-way split fp32 operands (conv_bf16x6.hip), its own weight image
   int x6_bn;   // tile width that image was laid out for
-  bool h3;     // 1x1 with Cin % 64 == 0: three f16 MFMA products of 2-way split operands (conv_f16x3.hip); wins over x6
+  bool h3;     // Cin % 64 == 0, 1x1 or 3x3: three f16 MFMA products of 2-way split operands (conv_f16x3.hip); wins over x6 / Winograd
 };
 
 struct Trunk {
@@ -79,6 +81,22 @@ int trunk_create(int B, int H, int W, Trunk** out) {
   // bf16 split at the same fp32-grade accuracy; CAPNET_NO_H3=1 keeps the bf16 split (A/B runs)
   const char* noh = getenv("CAPNET_NO_H3");
   const bool use_h3 = use_x6 && !(noh && noh[0] == '1');
+  // the 3x3 convolutions through the same kernel (implicit GEMM over (tap, channel)): CAPNET_H3_3X3 = a string of map
+  // sides, e.g. "56,28,7" = where the input map has that side; "all" / "none"; default: see below
+  const char* h33 = getenv("CAPNET_H3_3X3");
+  auto h3_3x3_on = [&](int side, int stride) {
+    if (!use_h3) return false;
+    if (h33) {
+      if (!strcmp(h33, "all")) return true;
+      if (!strcmp(h33, "none")) return false;
+      char key[16];
+      snprintf(key, sizeof key, "%d", side);
+      const char* f = strstr(h33, key);
+      return f != nullptr;
+    }
+    (void)stride;
+    return true;
+  };
   auto add = [&](int cin, int cout, int k, int stride, int pad, int h, int w, bool activated_input = false) {
     TrunkConv c;
     c.Cin = cin; c.Cout = cout; c.k = k; c.stride = stride; c.pad = pad; c.H = h; c.W = w;
@@ -91,6 +109,10 @@ int trunk_create(int B, int H, int W, Trunk** out) {
     c.x6 = use_x6 && !c.dma1x1 && k == 1 && pad == 0 && cin % 16 == 0 && cout % 64 == 0;
     c.h3 = use_h3 && c.x6 && cin % 64 == 0 && (activated_input || cin <= 512);
     if (c.h3) c.x6 = false;
+    if (k == 3 && pad == 1 && cin % 64 == 0 && cout % 64 == 0 && cin <= 512 && h3_3x3_on(h, stride)) {
+      c.h3 = true;
+      c.wino = false;
+    }
     c.x6_bn = c.x6 ? conv1x1_bf16x6_bn((long)B * c.OH * c.OW, cout) : c.h3 ? conv1x1_f16x3_bn((long)B * c.OH * c.OW, cout) : 0;
     t->convs.push_back(c);
     return c;
@@ -281,11 +303,11 @@ int conv_bn(const Ctx& c, int i, const float* x, long sxb, long sxh, long sxw, l
   }
   int rc;
   if (d.h3) {
-    CAPNET_REQUIRE(conv1x1_f16x3_eligible(x, sxb, sxh, sxw, sxc, c.t->B, d.H, d.W, d.Cin, d.Cout, d.stride, in_scale, in_shift),
+    CAPNET_REQUIRE(conv_f16x3_eligible(x, sxb, sxh, sxw, sxc, c.t->B, d.H, d.W, d.Cin, d.Cout, d.k, d.stride, d.pad, in_scale, in_shift),
                    "trunk: conv %d planned for the split-f16 kernel but its operands are not eligible", i);
-    rc = conv1x1_fwd_f16x3(x, sxb, sxh, sxw, reinterpret_cast<const unsigned*>(c.w[i]), d.x6_bn, y, in_scale,
-                           in_shift, relu_in, c.train ? psum : nullptr, c.train ? psq : nullptr, c.t->B, d.H,
-                           d.W, d.Cin, d.Cout, d.stride, c.s);
+    rc = conv_fwd_f16x3(x, sxb, sxh, sxw, reinterpret_cast<const unsigned*>(c.w[i]), d.x6_bn, y, in_scale,
+                        in_shift, relu_in, c.train ? psum : nullptr, c.train ? psq : nullptr, c.t->B, d.H,
+                        d.W, d.Cin, d.Cout, d.k, d.stride, d.pad, c.s);
   } else if (d.x6) {
     CAPNET_REQUIRE(conv1x1_bf16x6_eligible(x, sxb, sxh, sxw, sxc, c.t->B, d.H, d.W, d.Cin, d.Cout, d.stride, in_scale, in_shift),
                    "trunk: conv %d planned for the split-bf16 kernel but its operands are not eligible", i);
@@ -345,9 +367,9 @@ int conv_folded(const Ctx& c, int i, const float* x, const float* res, int relu,
   }
   int rc;
   if (d.h3) {
-    rc = conv1x1_fwd_f16x3(x, sb, sh, sw, reinterpret_cast<const unsigned*>(c.w[i]), d.x6_bn, y, nullptr, nullptr,
-                           0, nullptr, nullptr, c.t->B, d.H, d.W, d.Cin, d.Cout, d.stride, c.s, c.scale(i),
-                           c.shift(i), res, relu);
+    rc = conv_fwd_f16x3(x, sb, sh, sw, reinterpret_cast<const unsigned*>(c.w[i]), d.x6_bn, y, nullptr, nullptr,
+                        0, nullptr, nullptr, c.t->B, d.H, d.W, d.Cin, d.Cout, d.k, d.stride, d.pad, c.s, c.scale(i),
+                        c.shift(i), res, relu);
   } else if (d.x6) {
     rc = conv1x1_fwd_bf16x6(x, sb, sh, sw, reinterpret_cast<const unsigned*>(c.w[i]), d.x6_bn, y, nullptr, nullptr,
                             0, nullptr, nullptr, c.t->B, d.H, d.W, d.Cin, d.Cout, d.stride, c.s, c.scale(i),

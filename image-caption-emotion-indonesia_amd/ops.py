@@ -269,17 +269,17 @@ def pack_conv_weight_bf16x6(w_oihw, bn):
 
 
 def pack_conv_weight_f16x3(w_oihw, bn):
-    """1x1 OIHW weights -> header + the split-f16 image of capnet_conv1x1_fwd_f16x3 for tile width bn
+    """1x1 or 3x3 OIHW weights -> header + the split-f16 image of capnet_conv2d_fwd_f16x3 for tile width bn
     (two f16 pieces per weight scaled by the per-tensor power of two in the header, laid out as the
-    kernel's LDS image)."""
+    kernel's LDS image, k = (tap, channel))."""
     _need_cuda(w_oihw)
     w = _c(w_oihw)
     co, ci, kh, kw = w.shape
-    if (kh, kw) != (1, 1):
-        raise CapnetError("pack_conv_weight_f16x3: 1x1 weights only")
-    out = torch.empty(_lib.lib().capnet_conv1x1_f16x3_weight_words(ci, co), dtype=torch.int32, device=w.device)
-    check(_lib.lib().capnet_conv1x1_f16x3_pack(ptr(w), ptr(out), co, ci, int(bn), current_stream()),
-          "capnet_conv1x1_f16x3_pack")
+    if (kh, kw) not in ((1, 1), (3, 3)):
+        raise CapnetError("pack_conv_weight_f16x3: 1x1 or 3x3 weights only")
+    out = torch.empty(_lib.lib().capnet_conv_f16x3_weight_words(ci, co, kh), dtype=torch.int32, device=w.device)
+    check(_lib.lib().capnet_conv_f16x3_pack(ptr(w), ptr(out), co, ci, kh, int(bn), current_stream()),
+          "capnet_conv_f16x3_pack")
     return out
 
 

@@ -198,6 +198,18 @@ int capnet_conv1x1_fwd_f16x3(const float* x, long sxb, long sxh, long sxw, const
                              int stride, const float* out_scale, const float* out_shift,
                              const float* res, int relu_out, capnet_stream_t stream);
 
+/* The same kernel as an implicit GEMM over (tap, channel): k = 1 (pad 0) or k = 3 (pad 1), any stride. Weights:
+ * capnet_conv_f16x3_pack of the OIHW tensor (capnet_conv_f16x3_weight_words(Cin, Cout, k) words) for tile width
+ * bn = capnet_conv1x1_f16x3_bn(M, Cout); statistics rows capnet_conv1x1_tiles_m(M), M = B * OH * OW. */
+size_t capnet_conv_f16x3_weight_words(int Cin, int Cout, int k);
+int capnet_conv_f16x3_pack(const float* w_oihw, unsigned* image, int Cout, int Cin, int k, int bn,
+                           capnet_stream_t stream);
+int capnet_conv2d_fwd_f16x3(const float* x, long sxb, long sxh, long sxw, const unsigned* image, int bn, float* y,
+                            const float* in_scale, const float* in_shift, int relu_in, float* part_sum,
+                            float* part_sq, int B, int H, int W, int Cin, int Cout, int k, int stride, int pad,
+                            const float* out_scale, const float* out_shift, const float* res, int relu_out,
+                            capnet_stream_t stream);
+
 /* the low-VALU kernel used for every trunk convolution with Cin % 16 == 0 and Cout % 64 == 0:
  * NHWC channel-contiguous input, K-major weights, k_rows == KH*KW*Cin */
 int capnet_conv2d_fwd_kmajor(const float* x, long sxb, long sxh, long sxw, const float* w_kmajor,

@@ -677,3 +677,50 @@ def test_conv1x1_f16x3_walks_several_tiles_per_workgroup(dev, monkeypatch):
     for y, ps, pq in outs[1:]:
         assert torch.equal(y, outs[0][0]) and torch.equal(ps, outs[0][1]) and torch.equal(pq, outs[0][2])
     assert torch.isfinite(outs[0][0]).all()
+
+# ---- 3x3 convolutions through the split-f16 kernel (implicit GEMM over (tap, channel), csrc/conv_f16x3.hip) ----
+@pytest.mark.parametrize("bn", [64, 128])
+@pytest.mark.parametrize("B,H,W,Cin,Cout,stride,pre,epi", [
+    (2, 8, 8, 64, 128, 1, True, 0),         # 128 rows, 18 steps; padding on every side, folded BatchNorm + ReLU
+    (3, 7, 7, 128, 128, 1, True, 0),        # odd map, ragged last M tile
+    (2, 14, 14, 64, 128, 2, True, 0),       # stride 2 (first block of a stage): 7x7 outputs
+    (2, 9, 11, 64, 256, 2, False, 0),       # odd rectangular map, stride 2, activated input (the 0 / 1 factor)
+    (4, 14, 14, 256, 256, 1, True, 0),      # stage-3 conv2 at batch 4: 72 steps, several tiles per workgroup at bn = 64
+    (2, 7, 7, 64, 128, 1, False, 1),        # folded inference epilogue (+ ReLU), activated input
+])
+def test_conv3x3_f16x3_matches_fp64(dev, bn, B, H, W, Cin, Cout, stride, pre, epi):
+    g = torch.Generator().manual_seed(7 * B + H + Cin + Cout + stride + bn)
+    x = torch.randn(B, Cin, H, W, generator=g) * torch.exp(0.5 * torch.randn(B, Cin, H, W, generator=g))
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05 * torch.exp(0.5 * torch.randn(Cout, Cin, 3, 3, generator=g))
+    scale = torch.rand(Cin, generator=g) - 0.3 if pre else None
+    shift = torch.randn(Cin, generator=g) if pre else None
+    xin = torch.relu(x * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)).double() if pre else x.double()
+    ref = torch.nn.functional.conv2d(xin, w.double(), stride=stride, padding=1)
+    OH, OW = ref.shape[2], ref.shape[3]
+    M = B * OH * OW
+    ref = ref.permute(0, 2, 3, 1).reshape(M, Cout)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    L = lib()
+    img = ops.pack_conv_weight_f16x3(w.to(dev), bn)
+    y = torch.full((M, Cout), float("nan"), device=dev)
+    tiles = L.capnet_conv1x1_tiles_m(M)
+    sd, hd = (scale.to(dev), shift.to(dev)) if pre else (None, None)
+    if epi:
+        sc, sh = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
+        scd, shd = sc.to(dev), sh.to(dev)
+        check(L.capnet_conv2d_fwd_f16x3(ptr(xd), H * W * Cin, W * Cin, Cin, ptr(img), bn, ptr(y), ptr(sd), ptr(hd), int(pre),
+                                        None, None, B, H, W, Cin, Cout, 3, stride, 1, ptr(scd), ptr(shd), None, 1,
+                                        current_stream()))
+        assert rel_err(y, torch.relu(ref * sc.double() + sh.double())) < 3e-6
+        return
+    psum = torch.full((tiles, Cout), float("nan"), device=dev)
+    psq = torch.full((tiles, Cout), float("nan"), device=dev)
+    check(L.capnet_conv2d_fwd_f16x3(ptr(xd), H * W * Cin, W * Cin, Cin, ptr(img), bn, ptr(y), ptr(sd), ptr(hd), int(pre),
+                                    ptr(psum), ptr(psq), B, H, W, Cin, Cout, 3, stride, 1, None, None, None, 0,
+                                    current_stream()))
+    assert rel_err(y, ref) < 3e-6
+    rms = (((y.double().cpu() - ref) ** 2).mean().sqrt() / (ref ** 2).mean().sqrt()).item()
+    print("3x3 split-f16 rms vs fp64: %.2e" % rms)
+    assert rms < 6e-7
+    assert rel_err(psum.sum(0), ref.sum(0)) < 1e-5
+    assert rel_err(psq.sum(0), (ref ** 2).sum(0)) < 1e-5

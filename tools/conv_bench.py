@@ -17,6 +17,7 @@ SHAPES = {  # name: (H, Cin, Cout, k, stride)
     "s2c1": (28, 512, 128, 1, 1), "s2c2": (28, 128, 128, 3, 1), "s2c3": (28, 128, 512, 1, 1),
     "s3c1": (14, 1024, 256, 1, 1), "s3c2": (14, 256, 256, 3, 1), "s3c3": (14, 256, 1024, 1, 1),
     "s4c1": (7, 2048, 512, 1, 1), "s4c2": (7, 512, 512, 3, 1), "s4c3": (7, 512, 2048, 1, 1),
+    "s2c2s": (56, 128, 128, 3, 2), "s3c2s": (28, 256, 256, 3, 2), "s4c2s": (14, 512, 512, 3, 2),
 }
 
 
@@ -29,6 +30,7 @@ def main():
     ap.add_argument("--no-pre", action="store_true")
     ap.add_argument("--no-tail", action="store_true", help="disable the K-sliced tail balancing")
     ap.add_argument("--wino", action="store_true", help="Winograd F(2x2,3x3) kernel on the 3x3 stride-1 shapes")
+    ap.add_argument("--h3", action="store_true", help="split-f16 kernel (1x1 and 3x3 shapes with Cin % 64 == 0)")
     ap.add_argument("--v1", action="store_true", help="row-major-weight kernel (conv_f32.hip)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -59,7 +61,21 @@ def main():
             ps = torch.empty(wt, Cout, device=dev)
             pq = torch.empty(wt, Cout, device=dev)
 
+        use_h3 = args.h3 and Cin % 64 == 0 and Cout % 64 == 0 and k in (1, 3)
+        if use_h3:
+            bn = 128 if Cout % 128 == 0 else 64
+            img = ops.pack_conv_weight_f16x3(w, bn)
+            t1 = lib().capnet_conv1x1_tiles_m(M)
+            ps = torch.empty(t1, Cout, device=dev)
+            pq = torch.empty(t1, Cout, device=dev)
+
         def run():
+            if use_h3:
+                check(lib().capnet_conv2d_fwd_f16x3(ptr(x), H * H * Cin, H * Cin, Cin, ptr(img), bn, ptr(y),
+                                                    None if args.no_pre else ptr(sc), None if args.no_pre else ptr(sh),
+                                                    0 if args.no_pre else 1, ptr(ps), ptr(pq), B, H, H, Cin, Cout, k, stride, pad,
+                                                    None, None, None, 0, current_stream()))
+                return
             if use_wino:
                 check(lib().capnet_conv2d_fwd_wino(ptr(x), H * H * Cin, H * Cin, Cin, ptr(ww), ptr(y),
                                                    None if args.no_pre else ptr(sc), None if args.no_pre else ptr(sh),

@@ -5,7 +5,7 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import capnet
 from capnet._lib import check, current_stream, lib, ptr
-dev = torch.device("cuda:0"); L = lib()
+dev = torch.device("cuda:0"); L = lib(); B = 64
 KIND = os.environ.get("X6_KIND", "f16x3")      # bf16x6 | f16x3; B = 64
 X6 = {"s1c1": (56, 256, 64, 1, 0), "s1c3": (56, 64, 256, 1, 1), "s2c1": (28, 512, 128, 1, 0), "s2c3": (28, 128, 512, 1, 1),
       "s3c1": (14, 1024, 256, 1, 0), "s3c3": (14, 256, 1024, 1, 1), "s4c1": (7, 2048, 512, 1, 0), "s4c3": (7, 512, 2048, 1, 1)}
