@@ -351,17 +351,16 @@ def main():
             peak_equiv = algo / t_peak
             per_s = achieved / algo          # TFLOP/s per algorithmic flop of a pass
             roofline = {"bound": "mfma",
-                        "kernel": "the trunk's 155 conv launches: conv1x1_f16x3_kernel (the 104 1x1 convs: three "
-                                  "v_mfma_f32_32x32x16_f16 products of 2-way split, power-of-two scaled fp32 operands, "
-                                  "fp32-grade results), conv_wino_kernel (Winograd F(2x2,3x3), v_mfma_f32_16x16x4_f32) "
-                                  "for the 45 stride-1 3x3 convs, conv_f32_v2_kernel (implicit GEMM, "
-                                  "v_mfma_f32_32x32x2_f32) for the strided / 7x7-map 3x3 convs, conv_f32_kernel for the "
-                                  "7x7 stem; a launch includes its tail fix-up if any",
+                        "kernel": "the trunk's 155 conv launches: conv_f16x3_kernel (the 104 1x1 and the 50 3x3 convs: "
+                                  "three v_mfma_f32_32x32x16_f16 products of 2-way split fp32 operands per multiply, "
+                                  "fp32-grade results; the 3x3 ones as an implicit GEMM over (tap, channel)) and "
+                                  "conv_f32_kernel (v_mfma_f32_32x32x2_f32) for the 7x7 stem; CAPNET_H3_3X3=none puts "
+                                  "the stride-1 3x3 convs back on conv_wino_kernel (Winograd F(2x2,3x3), f32 MFMA)",
                         "flops": "ALGORITHMIC: 2*M*Cout*KH*KW*Cin of the direct sum (SURVEY 8d: 23.02 GFLOP per image)",
                         "peak_is": "algorithmic flops / (time the f32 matrix pipe needs for what is issued on it at "
                                    "157.3 TFLOP/s + time the 16-bit matrix pipe needs for its share at 2500 TFLOP/s): "
-                                   "Winograd issues 16/36 of its direct-sum flops on the f32 pipe, a split-f16 1x1 conv "
-                                   "3 f16 products per multiply, the rest f32 as counted (breakdown in `executed`)",
+                                   "a split-f16 conv issues 3 f16 products per multiply, Winograd (when selected) 16/36 of its "
+                                   "direct-sum flops on the f32 pipe, the rest f32 as counted (breakdown in `executed`)",
                         "how": "HIP events around every conv launch of the timed region, on its launch stream; "
                                "duration = time with at least one conv launch running (union of the "
                                "intervals: two trunk passes are in flight, their launches overlap)",

@@ -41,16 +41,19 @@ def main():
         for k, v in sorted(fetch.items(), key=lambda kv: -(2 * kv[1][1] + write.get(kv[0], [0, 0])[1]))[:14]:
             print("%s,%d,%.0f,%.0f" % (k.replace(",", ";"), v[0], v[1], write.get(k, [0, 0])[1]))
         return
-    conv = lambda n: "conv_f32" in n or "conv_wino" in n or "conv_tail_fixup" in n or "conv1x1_bf16x6_kernel" in n
-    launches = sum(v[0] for k, v in fetch.items()
-                   if "conv_f32" in k or "conv_wino" in k or "conv1x1_bf16x6_kernel" in k)   # fix-ups belong to a conv
+    convk = ("conv_f32", "conv_wino", "conv1x1_bf16x6", "conv_f16x3_kernel")
+    conv = lambda n: any(k in n for k in convk) or "conv_tail_fixup" in n
+    launches = sum(v[0] for k, v in fetch.items() if any(c in k for c in convk))   # fix-ups belong to a conv
     wino = lambda n: "conv_wino" in n
     wino_n = sum(v[0] for k, v in fetch.items() if wino(k))
     wino_bytes = (2.0 * sum(v[1] for k, v in fetch.items() if wino(k)) +
                   sum(v[1] for k, v in write.items() if wino(k))) * 1024.0
     fetch_kb = sum(v[1] for k, v in fetch.items() if conv(k))
     write_kb = sum(v[1] for k, v in write.items() if conv(k))
-    x6 = lambda n: "conv1x1_bf16x6_kernel" in n
+    x6 = lambda n: "conv1x1_bf16x6" in n
+    h3 = lambda n: "conv_f16x3_kernel" in n
+    h3_n = sum(v[0] for k, v in fetch.items() if h3(k))
+    h3_bytes = (2.0 * sum(v[1] for k, v in fetch.items() if h3(k)) + sum(v[1] for k, v in write.items() if h3(k))) * 1024.0
     x6_n = sum(v[0] for k, v in fetch.items() if x6(k))
     x6_bytes = (2.0 * sum(v[1] for k, v in fetch.items() if x6(k)) + sum(v[1] for k, v in write.items() if x6(k))) * 1024.0
     lp = lambda n: "lstm_persist_kernel" in n
@@ -70,6 +73,8 @@ def main():
         "algorithmic_bytes_per_launch": round((232e6 + 2 * 90e6 * 64) / 155),
         "winograd_launches": wino_n,
         "winograd_bytes_per_launch": round(wino_bytes / max(wino_n, 1)),
+        "f16x3_launches": h3_n,
+        "f16x3_bytes_per_launch": round(h3_bytes / max(h3_n, 1)),
         "bf16x6_launches": x6_n,
         "bf16x6_bytes_per_launch": round(x6_bytes / max(x6_n, 1)),
         "lstm_persist_launches": lp_n,
