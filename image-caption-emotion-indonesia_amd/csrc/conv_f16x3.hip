@@ -55,7 +55,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int HBM = 128, HBK = 32;
-constexpr int kSubA = HBM * 2 * 16;              // bytes of one (plane, k16 group) of the A image: 128 rows x 2 cells
+// bytes from one (plane, k16 group) of the A image (128 rows x 2 cells) to the next; + 16: lanes 2i / 2i + 1 stage the same row
+// of the two groups, 4 KB apart they hit the same banks (SQ_LDS_BANK_CONFLICT: 3 % of the kernel's cycles)
+constexpr int kSubA = HBM * 2 * 16 + 16;
 constexpr int kHdrWords = 4;                     // image header: [0] ew, [1] bits of max |w| (pack scratch)
 constexpr int kFoldMaxH = 512;                   // input channels whose BatchNorm scale / shift live in LDS
 

@@ -1,12 +1,13 @@
 """One trunk layer launched N times, for rocprofv3 --pmc passes (tools/pmc_sq2.sh).
     python tools/layer_one.py x6 s3c3 128 [iters]      bf16x6 1x1 conv
-    python tools/layer_one.py wino s3c2 0 [iters]      Winograd 3x3 conv"""
+    python tools/layer_one.py wino s3c2 0 [iters]      Winograd 3x3 conv
+    python tools/layer_one.py h33 s3c2 0 [iters]       3x3 conv on the split-f16 kernel"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import capnet
 from capnet import ops
 from capnet._lib import check, current_stream, lib, ptr
-dev = torch.device("cuda:0"); L = lib()
+dev = torch.device("cuda:0"); L = lib(); B = 64
 KIND = os.environ.get("X6_KIND", "f16x3")      # bf16x6 | f16x3; B = 64
 X6 = {"s1c1": (56, 256, 64, 1, 0), "s1c3": (56, 64, 256, 1, 1), "s2c1": (28, 512, 128, 1, 0), "s2c3": (28, 128, 512, 1, 1),
       "s3c1": (14, 1024, 256, 1, 0), "s3c3": (14, 256, 1024, 1, 1), "s4c1": (7, 2048, 512, 1, 0), "s4c3": (7, 512, 2048, 1, 1)}
@@ -24,6 +25,18 @@ if kind == "x6":
     check(getattr(L, 'capnet_conv1x1_%s_pack' % KIND)(ptr(w), ptr(img), Cout, Cin, bn, current_stream()))
     run = lambda: check(getattr(L, 'capnet_conv1x1_fwd_%s' % KIND)(ptr(x), H * H * Cin, H * Cin, Cin, ptr(img), bn, ptr(y), ptr(sc), ptr(sh), pre,
                                                      ptr(ps), ptr(pq), B, H, H, Cin, Cout, stride, None, None, None, 0, current_stream()))
+elif kind == "h33":
+    H, C = WI[name]
+    M = B * H * H
+    x = torch.randn(B, H, H, C, device=dev); w = torch.randn(C, C, 3, 3, device=dev) * 0.05
+    y = torch.empty(M, C, device=dev)
+    sc, sh = torch.rand(C, device=dev) + 0.5, torch.randn(C, device=dev)
+    bnw = 128 if C % 128 == 0 else 64
+    img = ops.pack_conv_weight_f16x3(w, bnw)
+    t = L.capnet_conv1x1_tiles_m(M)
+    ps, pq = torch.empty(t, C, device=dev), torch.empty(t, C, device=dev)
+    run = lambda: check(L.capnet_conv2d_fwd_f16x3(ptr(x), H * H * C, H * C, C, ptr(img), bnw, ptr(y), ptr(sc), ptr(sh), 1, ptr(ps), ptr(pq),
+                                                   B, H, H, C, C, 3, 1, 1, None, None, None, 0, current_stream()))
 else:
     H, C = WI[name]
     x = torch.randn(B, H, H, C, device=dev); w = torch.randn(C, C, 3, 3, device=dev) * 0.05
