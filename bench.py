@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--no-pipeline", action="store_true",
                     help="run trunk and decoder of a step back to back on one stream instead of "
                          "overlapping step i's decoder with step i+1's trunk (capnet.train.TrunkPipeline)")
+    ap.add_argument("--conv-event-every", type=int, default=1,
+                    help="bracket the conv launches of every N-th trunk pass only (N > 1: cheaper, but the passes in flight "
+                         "beside a timed one are then not in the union of intervals: per-launch times under contention)")
     ap.add_argument("--graph-trunk", action="store_true",
                     help="replay the trunk passes from hipGraphs (only without conv events)")
     ap.add_argument("--pipeline-depth", type=int, default=3,
@@ -304,7 +307,8 @@ def main():
     # the host with it and need not pay for 6 200 event calls per 20 steps)
     conv_events = not args.no_conv_events and rank == 0
     if conv_events:
-        runner.set_timing(plan, True)
+        # 310 event records per pass are bubbles in the pass's stream: they cost 2.5 % images/s (7 480 vs 7 680 without)
+        runner.set_timing(plan, args.conv_event_every)
     barrier()
     log("warm-up done, timing %d steps" % args.steps)
     t0 = time.perf_counter()
@@ -361,7 +365,8 @@ def main():
                                    "157.3 TFLOP/s + time the 16-bit matrix pipe needs for its share at 2500 TFLOP/s): "
                                    "a split-f16 conv issues 3 f16 products per multiply, Winograd (when selected) 16/36 of its "
                                    "direct-sum flops on the f32 pipe, the rest f32 as counted (breakdown in `executed`)",
-                        "how": "HIP events around every conv launch of the timed region, on its launch stream; "
+                        "how": "HIP events around every conv launch of every %d-th trunk pass of the timed region, on its "
+                               "launch stream; " % args.conv_event_every +
                                "duration = time with at least one conv launch running (union of the "
                                "intervals: two trunk passes are in flight, their launches overlap)",
                         "achieved": round(achieved, 2), "peak": round(peak_equiv, 2), "unit": "TFLOP/s",

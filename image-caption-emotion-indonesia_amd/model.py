@@ -294,7 +294,7 @@ class _TrunkRunner:
         """Per-conv hipEvent timing (bench.py roofline); event records cannot ride in a replayed
         graph, so timed passes are launched directly."""
         self.timing = bool(on)
-        check(_lib.lib().capnet_trunk_set_timing(plan["handle"], int(bool(on))), "capnet_trunk_set_timing")
+        check(_lib.lib().capnet_trunk_set_timing(plan["handle"], int(on)), "capnet_trunk_set_timing")
 
 
 class _BN1d(nn.Module):

@@ -115,7 +115,8 @@ int capnet_trunk_update_running(const capnet_trunk_t* t, const void* workspace,
                                 float momentum, capnet_stream_t stream);
 /* Per-convolution hipEvent timing for bench.py's roofline: while enabled, every conv kernel
  * launched by capnet_trunk_forward is bracketed by two events on the launch stream;
- * collect synchronises on them and returns the totals since the previous collect. */
+ * collect synchronises on them and returns the totals since the previous collect. enable = N > 1:
+ * only every N-th pass is bracketed (an event pair is a bubble in its stream). */
 int capnet_trunk_set_timing(capnet_trunk_t* t, int enable);
 int capnet_trunk_collect_timing(capnet_trunk_t* t, double* conv_ms, long* conv_launches,
                                 double* conv_flops);
