@@ -397,23 +397,28 @@ int bn1d_bwd(const float* dy, const float* x, int B, int C, const float* gamma,
 }
 
 // ---- attention loss: nll + alpha_c * ((1 - sum_t alphas[b][t][p])^2).mean() -------------------------
-// (stylenet/train_multitask_att.py:409-411). One workgroup: B*P sums over the steps (fixed order),
-// a block reduction, the scalar total. `colsum` [B*P] keeps sum_t alpha for the backward kernel.
-__global__ __launch_bounds__(256) void att_loss_fwd_kernel(const float* __restrict__ nll,
-                                                           const float* __restrict__ alphas, int B,
-                                                           int steps, int P, float alpha_c,
-                                                           float* __restrict__ colsum,
-                                                           float* __restrict__ out) {
-  __shared__ float red[256];
+// (stylenet/train_multitask_att.py:409-411). Two launches: B*P sums over the steps (fixed order, one thread each,
+// any number of workgroups; `colsum` [B*P] keeps sum_t alpha for the backward kernel), then one workgroup
+// reduces (1 - colsum)^2 in a fixed order and writes the scalar total. (One workgroup doing both took 390 us
+// at B = 64 on the critical path of every attention step.)
+__global__ __launch_bounds__(256) void att_loss_colsum_kernel(const float* __restrict__ alphas, int B, int steps,
+                                                              int P, float* __restrict__ colsum) {
   const int n = B * P;
-  float part = 0.f;
-  for (int i = threadIdx.x; i < n; i += 256) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
     const int b = i / P, p = i - b * P;
     const float* a = alphas + (long)b * steps * P + p;
     float s = 0.f;
     for (int t = 0; t < steps; ++t) s += a[(long)t * P];
     colsum[i] = s;
-    const float d = 1.f - s;
+  }
+}
+__global__ __launch_bounds__(256) void att_loss_fwd_kernel(const float* __restrict__ nll,
+                                                           const float* __restrict__ colsum, int n,
+                                                           float alpha_c, float* __restrict__ out) {
+  __shared__ float red[256];
+  float part = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float d = 1.f - colsum[i];
     part = fmaf(d, d, part);
   }
   red[threadIdx.x] = part;
@@ -443,8 +448,10 @@ __global__ __launch_bounds__(256) void att_loss_bwd_kernel(const float* __restri
 int att_loss_fwd(const float* nll, const float* alphas, int B, int steps, int P, float alpha_c,
                  float* colsum, float* out, hipStream_t stream) {
   CAPNET_REQUIRE(nll && alphas && colsum && out && B > 0 && steps > 0 && P > 0, "att_loss_fwd: bad argument");
-  hipLaunchKernelGGL(att_loss_fwd_kernel, dim3(1), dim3(256), 0, stream, nll, alphas, B, steps, P, alpha_c,
-                     colsum, out);
+  const int n = B * P;
+  hipLaunchKernelGGL(att_loss_colsum_kernel, dim3(cdiv(n, 256) > 512 ? 512 : cdiv(n, 256)), dim3(256), 0, stream, alphas, B,
+                     steps, P, colsum);
+  hipLaunchKernelGGL(att_loss_fwd_kernel, dim3(1), dim3(256), 0, stream, nll, colsum, n, alpha_c, out);
   CAPNET_LAUNCH_CHECK();
   return kOk;
 }
