@@ -340,13 +340,17 @@ def main():
             # 2.5 PFLOP/s dense). Everything else: f32 MFMA as counted. The peak the union of the conv launches is
             # priced against is the rate at which BOTH pipes, each at its own peak, would get through that work:
             # algorithmic flops / (f32-issued / 157.3 + 16-bit-issued / 2500).
-            algo = f32x = bf16x = f16x = 0.0
+            algo = f32x = bf16x = f16x = algo_f16 = 0.0
             for i in range(lib.capnet_trunk_num_convs(plan["handle"])):
                 fi = lib.capnet_trunk_conv_flops(plan["handle"], i)
                 kind = lib.capnet_trunk_conv_kmajor(plan["handle"], i)
                 algo += fi
                 if kind == 5:
                     f16x += 3.0 * fi
+                    algo_f16 += fi
+                elif kind == 6:      # the stem: K = 147 issued as 22 rows x 8 taps = 176
+                    f16x += 3.0 * fi * 176.0 / 147.0
+                    algo_f16 += fi
                 elif kind == 4:
                     bf16x += 6.0 * fi
                 else:
@@ -358,13 +362,15 @@ def main():
                         "kernel": "the trunk's 155 conv launches: conv_f16x3_kernel (the 104 1x1 and the 50 3x3 convs: "
                                   "three v_mfma_f32_32x32x16_f16 products of 2-way split fp32 operands per multiply, "
                                   "fp32-grade results; the 3x3 ones as an implicit GEMM over (tap, channel)) and "
-                                  "conv_f32_kernel (v_mfma_f32_32x32x2_f32) for the 7x7 stem; CAPNET_H3_3X3=none puts "
-                                  "the stride-1 3x3 convs back on conv_wino_kernel (Winograd F(2x2,3x3), f32 MFMA)",
+                                  "conv_stem_f16x3_kernel (the same arithmetic, K = 147 issued as 176) for the 7x7 stem; "
+                                  "CAPNET_H3_3X3=none puts the stride-1 3x3 convs back on conv_wino_kernel (Winograd "
+                                  "F(2x2,3x3), f32 MFMA), CAPNET_NO_STEM_H3=1 the stem on conv_f32_kernel",
                         "flops": "ALGORITHMIC: 2*M*Cout*KH*KW*Cin of the direct sum (SURVEY 8d: 23.02 GFLOP per image)",
                         "peak_is": "algorithmic flops / (time the f32 matrix pipe needs for what is issued on it at "
                                    "157.3 TFLOP/s + time the 16-bit matrix pipe needs for its share at 2500 TFLOP/s): "
-                                   "a split-f16 conv issues 3 f16 products per multiply, Winograd (when selected) 16/36 of its "
-                                   "direct-sum flops on the f32 pipe, the rest f32 as counted (breakdown in `executed`)",
+                                   "a split-f16 conv issues 3 f16 products per multiply (the stem x 176/147 for its padded K), "
+                                   "Winograd (when selected) 16/36 of its direct-sum flops on the f32 pipe, the rest f32 as "
+                                   "counted (breakdown in `executed`)",
                         "how": "HIP events around every conv launch of every %d-th trunk pass of the timed region, on its "
                                "launch stream; " % args.conv_event_every +
                                "duration = time with at least one conv launch running (union of the "
@@ -377,9 +383,9 @@ def main():
                         "vs_f32_matrix_peak": round(achieved / MFMA_F32_PEAK_TFLOPS, 4)}
             roofline["executed"] = {
                 "f32_mfma": {"achieved": round(f32x * per_s, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                             "share_of_algorithmic_flops": round((algo - bf16x / 6.0 - f16x / 3.0) / algo, 4)},
+                             "share_of_algorithmic_flops": round((algo - bf16x / 6.0 - algo_f16) / algo, 4)},
                 "f16_mfma": {"achieved": round(f16x * per_s, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                             "share_of_algorithmic_flops": round(f16x / 3.0 / algo, 4)},
+                             "share_of_algorithmic_flops": round(algo_f16 / algo, 4)},
                 "bf16_mfma": {"achieved": round(bf16x * per_s, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "share_of_algorithmic_flops": round(bf16x / 6.0 / algo, 4)},
                 "frac": round(f32x * per_s / MFMA_F32_PEAK_TFLOPS + (bf16x + f16x) * per_s / MFMA_BF16_PEAK_TFLOPS, 4),

@@ -94,6 +94,16 @@ int capnet_conv2d_fwd_f16x3(const float* x, long sxb, long sxh, long sxw, const 
                         Cin, Cout, k, stride, pad, S(stream), out_scale, out_shift, res, relu_out);
 }
 
+size_t capnet_conv_stem_f16x3_weight_words(void) { return conv_stem_f16x3_weight_words(); }
+int capnet_conv_stem_f16x3_part_rows(int B, int H, int W) { return conv_stem_f16x3_part_rows(B, H, W); }
+int capnet_conv_stem_f16x3_pack(const float* w_oihw, unsigned* image, capnet_stream_t stream) {
+  return conv_stem_f16x3_pack(w_oihw, image, S(stream));
+}
+int capnet_conv_stem_fwd_f16x3(const float* x, long sxb, long sxc, long sxh, const unsigned* image, float* y,
+                               float* part_sum, float* part_sq, int B, int H, int W, capnet_stream_t stream) {
+  return conv_stem_fwd_f16x3(x, sxb, sxc, sxh, image, y, part_sum, part_sq, B, H, W, S(stream));
+}
+
 int capnet_sgemm_splitk(int transA, int transB, int M, int N, int K, const float* A, long lda,
                         const float* B, long ldb, float* C, long ldc, const float* bias,
                         int accumulate, float* workspace, size_t workspace_floats,

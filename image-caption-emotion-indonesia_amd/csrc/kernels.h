@@ -91,6 +91,15 @@ int conv_fwd_f16x3(const float* x, long sxb, long sxh, long sxw, const unsigned*
                    int H, int W, int Cin, int Cout, int k, int stride, int pad, hipStream_t stream,
                    const float* out_scale = nullptr, const float* out_shift = nullptr, const float* res = nullptr,
                    int relu_out = 0);
+// The stem (7x7 stride 2 pad 3, 3 -> 64 channels, NCHW image in, NHWC out) on the same split-f16 arithmetic
+// (conv_stem.hip); statistics partials: one row per workgroup
+bool conv_stem_f16x3_eligible(const float* x, long sxb, long sxc, long sxh, long sxw, int Bn, int H, int W, int Cin,
+                              int Cout, int k, int stride, int pad);
+size_t conv_stem_f16x3_weight_words();
+int conv_stem_f16x3_part_rows(int Bn, int H, int W);
+int conv_stem_f16x3_pack(const float* w_oihw, unsigned* img, hipStream_t stream);
+int conv_stem_fwd_f16x3(const float* x, long sxb, long sxc, long sxh, const unsigned* wimg, float* y, float* part_sum,
+                        float* part_sq, int Bn, int H, int W, hipStream_t stream);
 size_t conv1x1_f16x3_weight_words(int Cin, int Cout);
 int conv1x1_f16x3_pack(const float* w, unsigned* img, int Cout, int Cin, int bn, hipStream_t stream);
 int conv1x1_fwd_f16x3(const float* x, long sxb, long sxh, long sxw, const unsigned* wimg, int bn, float* y,

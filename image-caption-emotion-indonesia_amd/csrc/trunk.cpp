@@ -35,6 +35,7 @@ struct TrunkConv {
   bool x6;     // 1x1: six bf16 MFMA products of 3-way split fp32 operands (conv_bf16x6.hip), its own weight image
   int x6_bn;   // tile width that image was laid out for
   bool h3;     // Cin % 64 == 0, 1x1 or 3x3: three f16 MFMA products of 2-way split operands (conv_f16x3.hip); wins over x6 / Winograd
+  bool stem_h3 = false;   // the 7x7 / 2 stem on the same arithmetic, NCHW image in (conv_stem.hip)
 };
 
 struct Trunk {
@@ -121,6 +122,11 @@ int trunk_create(int B, int H, int W, Trunk** out) {
     return c;
   };
   TrunkConv stem = add(3, 64, 7, 2, 3, H, W);
+  {
+    // CAPNET_NO_STEM_H3=1 keeps the stem on the generic f32 gather kernel (A/B runs)
+    const char* e = getenv("CAPNET_NO_STEM_H3");
+    t->convs[0].stem_h3 = use_h3 && !(e && e[0] == '1') && W % 4 == 0;
+  }
   int h = (stem.OH + 2 - 3) / 2 + 1, w = (stem.OW + 2 - 3) / 2 + 1;  // maxpool
   int inplanes = 64;
   const int blocks[4] = {3, 8, 36, 3};
@@ -164,6 +170,7 @@ int trunk_create(int B, int H, int W, Trunk** out) {
     max_part = std::max(max_part, (size_t)conv_tiles_m((int)M, tile) * c.Cout);
     if (c.wino) max_part = std::max(max_part, (size_t)conv_wino_tiles_m(B, c.H, c.W) * c.Cout);
     if (c.dma1x1 || c.x6 || c.h3) max_part = std::max(max_part, (size_t)conv1x1_tiles_m(M) * c.Cout);
+    if (c.stem_h3) max_part = std::max(max_part, (size_t)conv_stem_f16x3_part_rows(B, c.H, c.W) * c.Cout);
   }
   t->off_part = take(2 * max_part);
   size_t max_slab = 0;
@@ -247,7 +254,7 @@ int trunk_conv_shape(const Trunk* t, int i, int* cout, int* cin, int* k, int* st
 
 int trunk_conv_kmajor(const Trunk* t, int i) {
   if (i < 0 || i >= (int)t->convs.size()) return 0;
-  return t->convs[i].h3 ? 5 : t->convs[i].x6 ? 4 : t->convs[i].dma1x1 ? 3 : t->convs[i].wino ? 2 : (t->convs[i].kmajor ? 1 : 0);
+  return t->convs[i].stem_h3 ? 6 : t->convs[i].h3 ? 5 : t->convs[i].x6 ? 4 : t->convs[i].dma1x1 ? 3 : t->convs[i].wino ? 2 : (t->convs[i].kmajor ? 1 : 0);
 }
 
 int trunk_conv_x6_bn(const Trunk* t, int i) {
@@ -298,7 +305,7 @@ int conv_bn(const Ctx& c, int i, const float* x, long sxb, long sxh, long sxw, l
   int tile = d.kmajor ? conv_v2_auto_tile((int)M, d.Cout, d.Kw) : conv_auto_tile((int)M, d.Cout);
   if (d.kmajor && !c.t->tail_balance && M >= 5000) tile = 12864;
   // rows of the statistics partials this conv writes
-  const int prows = (d.dma1x1 || d.x6 || d.h3) ? conv1x1_tiles_m(M) : d.wino ? conv_wino_tiles_m(c.t->B, d.H, d.W) : conv_tiles_m((int)M, tile);
+  const int prows = d.stem_h3 ? conv_stem_f16x3_part_rows(c.t->B, d.H, d.W) : (d.dma1x1 || d.x6 || d.h3) ? conv1x1_tiles_m(M) : d.wino ? conv_wino_tiles_m(c.t->B, d.H, d.W) : conv_tiles_m((int)M, tile);
   float* psum = c.ws + c.t->off_part;
   float* psq = psum + (size_t)prows * d.Cout;
   hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -308,7 +315,12 @@ int conv_bn(const Ctx& c, int i, const float* x, long sxb, long sxh, long sxw, l
     CAPNET_HIP_CHECK(hipEventRecord(e0, c.s));
   }
   int rc;
-  if (d.h3) {
+  if (d.stem_h3) {
+    CAPNET_REQUIRE(!in_scale && conv_stem_f16x3_eligible(x, sxb, sxc, sxh, sxw, c.t->B, d.H, d.W, d.Cin, d.Cout, d.k, d.stride, d.pad),
+                   "trunk: the stem is planned for the split-f16 kernel but its operands are not eligible");
+    rc = conv_stem_fwd_f16x3(x, sxb, sxc, sxh, reinterpret_cast<const unsigned*>(c.w[i]), y, c.train ? psum : nullptr,
+                             c.train ? psq : nullptr, c.t->B, d.H, d.W, c.s);
+  } else if (d.h3) {
     CAPNET_REQUIRE(conv_f16x3_eligible(x, sxb, sxh, sxw, sxc, c.t->B, d.H, d.W, d.Cin, d.Cout, d.k, d.stride, d.pad, in_scale, in_shift),
                    "trunk: conv %d planned for the split-f16 kernel but its operands are not eligible", i);
     rc = conv_fwd_f16x3(x, sxb, sxh, sxw, reinterpret_cast<const unsigned*>(c.w[i]), d.x6_bn, y, in_scale,
@@ -433,9 +445,13 @@ int trunk_forward_eval(const Ctx& c, const float* images_nchw, float* out_pooled
     // stem: the gather-loader kernel writes the raw conv, BN + ReLU ride on the max-pool
     const TrunkConv& d = t->convs[0];
     const long M = (long)B * d.OH * d.OW;
-    rc = conv2d_fwd(images_nchw, (long)3 * d.H * d.W, d.W, 1, (long)d.H * d.W, c.w[0], d.Kw, Y3, nullptr,
-                    nullptr, 0, nullptr, nullptr, B, d.H, d.W, d.Cin, d.Cout, d.k, d.k, d.stride, d.pad,
-                    conv_auto_tile((int)M, d.Cout), c.s);
+    if (d.stem_h3)
+      rc = conv_stem_fwd_f16x3(images_nchw, (long)3 * d.H * d.W, (long)d.H * d.W, d.W, reinterpret_cast<const unsigned*>(c.w[0]),
+                               Y3, nullptr, nullptr, B, d.H, d.W, c.s);
+    else
+      rc = conv2d_fwd(images_nchw, (long)3 * d.H * d.W, d.W, 1, (long)d.H * d.W, c.w[0], d.Kw, Y3, nullptr,
+                      nullptr, 0, nullptr, nullptr, B, d.H, d.W, d.Cin, d.Cout, d.k, d.k, d.stride, d.pad,
+                      conv_auto_tile((int)M, d.Cout), c.s);
     if (rc) return rc;
     rc = bn_relu_maxpool(Y3, c.scale(0), c.shift(0), X[0], B, d.OH, d.OW, 64, c.s);
     if (rc) return rc;

@@ -178,9 +178,11 @@ class _TrunkRunner:
                 if tuple(c.weight.shape) != (cout, cin, k, k) or c.stride != stride:
                     raise CapnetError("conv %d: module shape %s does not match the plan" %
                                       (i, tuple(c.weight.shape)))
-                # 0 rows, 1 K-major, 2 Winograd, 3 as stored (a 1x1 OIHW weight IS [Cout][Cin]), 4 split bf16, 5 split f16
+                # 0 rows, 1 K-major, 2 Winograd, 3 as stored (a 1x1 OIHW weight IS [Cout][Cin]), 4 split bf16, 5 split f16, 6 the stem's split f16
                 kind = L.capnet_trunk_conv_kmajor(plan["handle"], i)
-                if kind == 5:
+                if kind == 6:
+                    packed.append(ops.pack_conv_weight_stem_f16x3(c.weight.detach()))
+                elif kind == 5:
                     packed.append(ops.pack_conv_weight_f16x3(c.weight.detach(), L.capnet_trunk_conv_x6_bn(plan["handle"], i)))
                 elif kind == 4:
                     packed.append(ops.pack_conv_weight_bf16x6(c.weight.detach(), L.capnet_trunk_conv_x6_bn(plan["handle"], i)))

@@ -283,6 +283,17 @@ def pack_conv_weight_f16x3(w_oihw, bn):
     return out
 
 
+def pack_conv_weight_stem_f16x3(w_oihw):
+    """The stem's OIHW weights [64][3][7][7] -> header + the split-f16 image of capnet_conv_stem_fwd_f16x3."""
+    _need_cuda(w_oihw)
+    w = _c(w_oihw)
+    if tuple(w.shape) != (64, 3, 7, 7):
+        raise CapnetError("pack_conv_weight_stem_f16x3: weights must be [64][3][7][7]")
+    out = torch.empty(_lib.lib().capnet_conv_stem_f16x3_weight_words(), dtype=torch.int32, device=w.device)
+    check(_lib.lib().capnet_conv_stem_f16x3_pack(ptr(w), ptr(out), current_stream()), "capnet_conv_stem_f16x3_pack")
+    return out
+
+
 def clamp_adam(params, grads, exp_avg, exp_avg_sq, steps, lr, beta1, beta2, eps, clip,
                write_grad=True):
     """Fused element-wise clamp + Adam over a list of tensors (in place)."""

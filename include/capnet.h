@@ -129,7 +129,9 @@ int capnet_trunk_collect_timing(capnet_trunk_t* t, double* conv_ms, long* conv_l
  * 4 = the split-bf16 image of a 1x1 convolution (capnet_conv1x1_bf16x6_pack with tile width
  * capnet_trunk_conv_x6_bn(t, i); 1x1 convolutions image 5 does not take, unless CAPNET_NO_X6=1),
  * 5 = the split-f16 image of a 1x1 convolution (capnet_conv1x1_f16x3_pack with tile width
- * capnet_trunk_conv_x6_bn(t, i); every 1x1 convolution with Cin % 64 == 0 unless CAPNET_NO_H3=1). */
+ * capnet_trunk_conv_x6_bn(t, i); every 1x1 convolution with Cin % 64 == 0 unless CAPNET_NO_H3=1; the 3x3 ones through
+ * capnet_conv_f16x3_pack),
+ * 6 = the split-f16 image of the stem (capnet_conv_stem_f16x3_pack; unless CAPNET_NO_H3=1 or CAPNET_NO_STEM_H3=1). */
 int capnet_trunk_conv_kmajor(const capnet_trunk_t* t, int i);
 int capnet_trunk_conv_x6_bn(const capnet_trunk_t* t, int i);
 int capnet_pack_conv_weight_kmajor(const float* w_oihw, float* out, int Cout, int Cin, int KH,
@@ -210,6 +212,17 @@ int capnet_conv2d_fwd_f16x3(const float* x, long sxb, long sxh, long sxw, const 
                             float* part_sq, int B, int H, int W, int Cin, int Cout, int k, int stride, int pad,
                             const float* out_scale, const float* out_shift, const float* res, int relu_out,
                             capnet_stream_t stream);
+
+/* The stem on the same arithmetic (csrc/conv_stem.hip): 7x7, stride 2, pad 3, 3 -> 64 channels; x is the NCHW image
+ * (strides in floats, unit stride along W, W % 4 == 0, 16-B aligned rows), y is NHWC [B][OH][OW][64]. Replaces
+ * torchvision resnet152.conv1 as run by /root/reference/stylenet/model.py:14-24,33. Weights: capnet_conv_stem_f16x3_pack
+ * of the OIHW tensor [64][3][7][7] into capnet_conv_stem_f16x3_weight_words() words. part_sum / part_sq (or both
+ * null): [capnet_conv_stem_f16x3_part_rows(B, H, W)][64], one row per workgroup, for capnet_bn_finalize. */
+size_t capnet_conv_stem_f16x3_weight_words(void);
+int capnet_conv_stem_f16x3_part_rows(int B, int H, int W);
+int capnet_conv_stem_f16x3_pack(const float* w_oihw, unsigned* image, capnet_stream_t stream);
+int capnet_conv_stem_fwd_f16x3(const float* x, long sxb, long sxc, long sxh, const unsigned* image, float* y,
+                               float* part_sum, float* part_sq, int B, int H, int W, capnet_stream_t stream);
 
 /* the low-VALU kernel used for every trunk convolution with Cin % 16 == 0 and Cout % 64 == 0:
  * NHWC channel-contiguous input, K-major weights, k_rows == KH*KW*Cin */

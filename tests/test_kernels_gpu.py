@@ -724,3 +724,37 @@ def test_conv3x3_f16x3_matches_fp64(dev, bn, B, H, W, Cin, Cout, stride, pre, ep
     assert rms < 6e-7
     assert rel_err(psum.sum(0), ref.sum(0)) < 1e-5
     assert rel_err(psq.sum(0), (ref ** 2).sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 224, 224), (3, 64, 96), (1, 40, 264), (2, 32, 520), (5, 7, 8)])
+def test_conv_stem_f16x3_matches_fp64(dev, B, H, W):
+    """The 7x7 / 2 stem on the split-f16 kernel (NCHW image in, NHWC out): fp32-grade against fp64, odd and
+    rectangular maps, output rows of one, two and three 128-wide segments, a strided (non-contiguous) batch."""
+    g = torch.Generator().manual_seed(11 * B + H + W)
+    big = torch.randn(B, 2, 3, H, W, generator=g) * torch.exp(0.5 * torch.randn(B, 2, 3, H, W, generator=g))
+    x = big[:, 1]                                   # batch stride 2 * 3 * H * W
+    w = torch.randn(64, 3, 7, 7, generator=g) * 0.05 * torch.exp(0.5 * torch.randn(64, 3, 7, 7, generator=g))
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), stride=2, padding=3)
+    OH, OW = ref.shape[2], ref.shape[3]
+    ref = ref.permute(0, 2, 3, 1).reshape(B * OH * OW, 64)
+    L = lib()
+    bigd = big.to(dev)
+    xd = bigd[:, 1]
+    img = ops.pack_conv_weight_stem_f16x3(w.to(dev))
+    y = torch.full((B * OH * OW, 64), float("nan"), device=dev)
+    rows = L.capnet_conv_stem_f16x3_part_rows(B, H, W)
+    psum = torch.full((rows, 64), float("nan"), device=dev)
+    psq = torch.full((rows, 64), float("nan"), device=dev)
+    check(L.capnet_conv_stem_fwd_f16x3(ptr(xd), xd.stride(0), xd.stride(1), xd.stride(2), ptr(img), ptr(y), ptr(psum),
+                                       ptr(psq), B, H, W, current_stream()))
+    assert rel_err(y, ref) < 3e-6
+    rms = (((y.double().cpu() - ref) ** 2).mean().sqrt() / (ref ** 2).mean().sqrt()).item()
+    print("stem split-f16 rms vs fp64: %.2e" % rms)
+    assert rms < 6e-7
+    assert rel_err(psum.sum(0), ref.sum(0)) < 1e-5
+    assert rel_err(psq.sum(0), (ref ** 2).sum(0)) < 1e-5
+    # no statistics asked for: same output
+    y2 = torch.full_like(y, float("nan"))
+    check(L.capnet_conv_stem_fwd_f16x3(ptr(xd), xd.stride(0), xd.stride(1), xd.stride(2), ptr(img), ptr(y2), None,
+                                       None, B, H, W, current_stream()))
+    assert torch.equal(y, y2)
