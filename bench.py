@@ -359,10 +359,12 @@ def main():
             peak_equiv = algo / t_peak
             per_s = achieved / algo          # TFLOP/s per algorithmic flop of a pass
             roofline = {"bound": "mfma",
-                        "kernel": "the trunk's 155 conv launches: conv_f16x3_kernel (the 104 1x1 and the 50 3x3 convs: "
-                                  "three v_mfma_f32_32x32x16_f16 products of 2-way split fp32 operands per multiply, "
-                                  "fp32-grade results; the 3x3 ones as an implicit GEMM over (tap, channel)) and "
-                                  "conv_stem_f16x3_kernel (the same arithmetic, K = 147 issued as 176) for the 7x7 stem; "
+                        "kernel": "the trunk's 155 conv launches, all on three v_mfma_f32_32x32x16_f16 products of 2-way "
+                                  "split fp32 operands per multiply (fp32-grade results): conv_f16x3_kernel (the 104 1x1 "
+                                  "convs and the 3 strided 3x3 ones, implicit GEMM over (tap, channel)), "
+                                  "conv3x3_patch_kernel (the 47 stride-1 3x3 convs, input patch resident in LDS; "
+                                  "CAPNET_NO_P3=1 puts them back on conv_f16x3_kernel) and "
+                                  "conv_stem_f16x3_kernel (K = 147 issued as 176) for the 7x7 stem; "
                                   "CAPNET_H3_3X3=none puts the stride-1 3x3 convs back on conv_wino_kernel (Winograd "
                                   "F(2x2,3x3), f32 MFMA), CAPNET_NO_STEM_H3=1 the stem on conv_f32_kernel",
                         "flops": "ALGORITHMIC: 2*M*Cout*KH*KW*Cin of the direct sum (SURVEY 8d: 23.02 GFLOP per image)",

@@ -1,0 +1,320 @@
+// 3x3 / stride 1 / pad 1 convolutions of the trunk on the split-f16 arithmetic of conv_f16x3.hip, with the INPUT PATCH
+// of a tile resident in LDS: the implicit GEMM over (tap, channel) of conv_f16x3.hip fetches, folds (BatchNorm + ReLU of
+// the producing layer) and splits every input element once per tap -- nine times. Here a workgroup stages, per 32-channel
+// chunk, the 128 + 2 W + 2 input pixels its 128 output pixels touch (stride 1: output pixel m sits on input pixel m, tap
+// (kh, kw) on pixel m + (kh - 1) W + (kw - 1)) ONCE as split f16 planes, and the nine taps read their A fragments from
+// that patch at nine offsets; positions in the zero padding are masked per lane and tap. Per k-step only the packed
+// weights (the same image as conv_f16x3.hip's, 16 KB, copied verbatim) still go through registers.
+// Eight waves per workgroup, in two arrangements:
+//  * KSPLIT (launches of at most one tile per CU: the 14 x 14 and 7 x 7 maps): such a layer runs ONE workgroup per CU, and
+//    with four waves every SIMD sits idle through each LDS round trip and barrier of its only wave. The eight waves are
+//    four PAIRS on the 2 x 2 grid of 64 x (BN / 2) blocks; the two waves of a pair split K -- each takes one of the
+//    step's two k16 groups -- so the workgroup reads no more LDS than four waves would (the LDS port is as busy as the
+//    matrix pipe here). The halves meet once per tile, through LDS, each wave finishing one of the pair's 32-row blocks.
+//  * otherwise (56 x 56, 28 x 28: several tiles per CU): 4 x 2 waves of 32 rows x BN / 2 columns at <= 128 VGPRs, so that
+//    two workgroups share a CU.
+#include <cstdlib>
+
+#include "common.h"
+#include "mfma_core.h"
+#include "kernels.h"
+
+namespace capnet {
+namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+
+constexpr int PBM = 128;                 // output pixels of a tile
+constexpr int kPmax = 248;               // patch pixels: >= 128 + 2 * 56 + 2, = 8 mod 16 (the four channel groups 32 banks apart)
+constexpr int kPatchSub = kPmax * 16;    // bytes of one (plane, 8-channel group) array: [pixel][8 halfs]
+constexpr int kPatch = 8 * kPatchSub;    // 2 planes x 4 groups
+constexpr int kThreads = 512;
+constexpr int kPL = (kPmax * 8 + kThreads - 1) / kThreads;   // 16-B loads per thread and chunk (4)
+constexpr int kHdrWords = 4;             // as conv_f16x3.hip: [0] ew
+static_assert(kPmax % 16 == 8 && kPmax >= PBM + 2 * 56 + 2, "patch size");
+
+struct PArgs {
+  const float* x;
+  const unsigned* wimg;
+  float* y;
+  const float* in_scale;
+  const float* in_shift;
+  float* part_sum;
+  float* part_sq;
+  int M, Cin, Cout, relu_in, H, W;
+  int tiles_m, tiles_n;
+  unsigned tn_mul, tn_sh, hw_mul, hw_sh, w_mul, w_sh;
+};
+
+__device__ __forceinline__ void p_split4(const f32x4 v, h4& h, h4& l) {
+  const f2 a = {v[0], v[1]}, b = {v[2], v[3]};
+  const h2 ha = __builtin_convertvector(a, h2), hb = __builtin_convertvector(b, h2);      // v_cvt_pk_f16_f32
+  const f2 ra = a - __builtin_convertvector(ha, f2), rb = b - __builtin_convertvector(hb, f2);   // exact
+  const h2 la = __builtin_convertvector(ra, h2), lb = __builtin_convertvector(rb, h2);
+  h = h4{ha[0], ha[1], hb[0], hb[1]};
+  l = h4{la[0], la[1], lb[0], lb[1]};
+}
+// byte offset of weight cell (row n, 8-channel half c) inside one (plane, k16 group) sub-image -- conv_f16x3.hip's h_cell
+__device__ __forceinline__ unsigned p_cell(int row, int c) {
+  const int r = row & 15;
+  return (unsigned)((row * 2 + (c ^ ((r >> 3) & 1))) * 16);
+}
+
+template <int BN, bool KSPLIT>
+__global__ __launch_bounds__(kThreads, KSPLIT ? 2 : 4) void conv3x3_patch_kernel(const PArgs g) {
+  constexpr int NT = BN / 64;
+  constexpr int MT = KSPLIT ? 2 : 1;                  // 32-row blocks of a wave
+  constexpr int kSubB = BN * 2 * 16, kImgB = 4 * kSubB;
+  constexpr int NBR = kImgB / 16 / kThreads;          // 16-B weight cells per thread and step (2 / 1)
+  constexpr int kXch = KSPLIT ? 8 * NT * 16 * 64 * 4 : 0;       // the pairs' exchange at the end of a tile reuses the buffers
+  constexpr int kLds = kPatch + 2 * kImgB > kXch ? kPatch + 2 * kImgB : kXch;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[kLds];
+  __shared__ float scratch[2][4][BN];
+  unsigned char* const patch = lds;
+  unsigned char* const bbuf = lds + kPatch;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // KSPLIT: wave = (pair on the 2 x 2 grid of 64-row blocks, k16 group kq2); else 4 x 2 waves of 32 rows, both groups
+  const int kq2 = KSPLIT ? (wave & 1) : 0;
+  const int wm = KSPLIT ? (wave >> 2) : (wave >> 1), wn = KSPLIT ? ((wave >> 1) & 1) : (wave & 1);
+  const int rows0 = wm * (32 * MT);                   // this wave's first row of the tile
+  const int li = lane & 31, lh = lane >> 5;
+  const int W = g.W, Cin = g.Cin;
+  const int nkc = Cin / 32, nk = 9 * nkc;
+  const int total = g.tiles_m * g.tiles_n, G = (int)gridDim.x;
+  const float oscale = ldexpf(1.f, -(int)g.wimg[0]);
+  const int pq = tid & 7;                             // this thread's 4 channels of a chunk: 4 pq .. 4 pq + 3
+  const unsigned char* const a_rd = patch + (kq2 * 2 + lh) * kPatchSub + (rows0 + li) * 16;      // + plane, k16, mt, tap offsets
+  const unsigned char* const b_rd = bbuf + p_cell(wn * (BN / 2) + li, lh);
+
+  for (int wk = (int)blockIdx.x; wk < total; wk += G) {
+    const int id = xcd_remap(wk, total);
+    const int tm = (int)fast_div((unsigned)id, g.tn_mul, g.tn_sh), tn = id - tm * g.tiles_n;
+    const int m0 = tm * PBM, n0 = tn * BN;
+    const int pb = m0 - W - 1;                         // input pixel of patch position 0
+    const int P = PBM + 2 * W + 2;                     // patch pixels
+    // which taps of this lane's two rows fall inside the map
+    unsigned vmask[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = m0 + rows0 + mt * 32 + li;
+      const int mc = m < g.M ? m : g.M - 1;
+      const int b = (int)fast_div((unsigned)mc, g.hw_mul, g.hw_sh), rem = mc - b * g.H * W;
+      const int oh = (int)fast_div((unsigned)rem, g.w_mul, g.w_sh), ow = rem - oh * W;
+      unsigned vm = 0;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int ih = oh + t / 3 - 1, iw = ow + t % 3 - 1;
+        if ((unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)W) vm |= 1u << t;
+      }
+      vmask[mt] = vm;
+    }
+    const float* wsrc = reinterpret_cast<const float*>(g.wimg + kHdrWords) + (long)tn * nk * (kImgB / 4);
+
+    f32x4 pre[kPL], fs, ft;
+    u4 bre[NBR];
+    auto fetch_patch = [&](int c) {
+#pragma unroll
+      for (int u = 0; u < kPL; ++u) {
+        const int px = (tid >> 3) + (kThreads / 8) * u;
+        const long p = (long)pb + px;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (px < P && p >= 0 && p < g.M) v = *reinterpret_cast<const f32x4*>(g.x + p * Cin + c * 32 + 4 * pq);
+        pre[u] = v;
+      }
+      if (g.in_scale) {
+        fs = *reinterpret_cast<const f32x4*>(g.in_scale + c * 32 + 4 * pq);
+        ft = *reinterpret_cast<const f32x4*>(g.in_shift + c * 32 + 4 * pq);
+      }
+    };
+    auto stage_patch = [&]() {
+      unsigned char* d = patch + (pq >> 1) * kPatchSub + (pq & 1) * 8;
+#pragma unroll
+      for (int u = 0; u < kPL; ++u) {
+        const int px = (tid >> 3) + (kThreads / 8) * u;
+        if (px < P) {
+          f32x4 v = pre[u];
+          if (g.in_scale) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], fs[e], ft[e]);
+          }
+          if (g.relu_in) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+          }
+          h4 h, l;
+          p_split4(v, h, l);
+          *reinterpret_cast<h4*>(d + px * 16) = h;
+          *reinterpret_cast<h4*>(d + 4 * kPatchSub + px * 16) = l;
+        }
+      }
+    };
+    auto fetch_b = [&](int kt) {
+      const u4* src = reinterpret_cast<const u4*>(wsrc + (long)kt * (kImgB / 4));
+#pragma unroll
+      for (int q = 0; q < NBR; ++q) bre[q] = src[tid + kThreads * q];
+    };
+    auto stage_b = [&](int buf) {
+#pragma unroll
+      for (int q = 0; q < NBR; ++q) *reinterpret_cast<u4*>(bbuf + buf * kImgB + (tid + kThreads * q) * 16) = bre[q];
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+    fetch_patch(0);
+    fetch_b(0);                                        // kt = tap * nkc + chunk: (tap 0, chunk 0)
+    int step = 0;
+    for (int c = 0; c < nkc; ++c) {
+      __syncthreads();                                 // every wave is through with the previous chunk's patch (and tile's exchange)
+      stage_patch();
+      if (c + 1 < nkc) fetch_patch(c + 1);
+#pragma unroll
+      for (int t = 0; t < 9; ++t, ++step) {
+        const int buf = step & 1;
+        stage_b(buf);
+        __syncthreads();
+        if (t < 8) fetch_b((t + 1) * nkc + c);
+        else if (c + 1 < nkc) fetch_b(c + 1);
+        const int toff = ((t / 3) * W + t % 3) * 16;                 // patch position of row 0 under this tap
+#pragma unroll
+        for (int gi = 0; gi < (KSPLIT ? 1 : 2); ++gi) {              // k16 groups of this wave: its own one / both
+          const int gsel = KSPLIT ? kq2 : gi;                        // (a_rd already points at group kq2)
+          h8 af[MT][2], bf[NT][2];
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            const bool ok = (vmask[mt] >> t) & 1u;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+              const h8 v = *reinterpret_cast<const h8*>(a_rd + (p * 4 + gi * 2) * kPatchSub + mt * 512 + toff);
+              const h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+              af[mt][p] = ok ? v : z;
+            }
+          }
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+              bf[nt][p] = *reinterpret_cast<const h8*>(b_rd + buf * kImgB + (p * 2 + gsel) * kSubB + nt * 1024);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mt][1], bf[nt][0], acc[mt][nt], 0, 0, 0);    // l h'
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mt][0], bf[nt][1], acc[mt][nt], 0, 0, 0);    // h l'
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mt][0], bf[nt][0], acc[mt][nt], 0, 0, 0);    // h h'
+            }
+        }
+      }
+    }
+    // ---- KSPLIT: the pair's two K halves meet -- wave kq2 finishes row block mt = kq2 and hands the other one over through LDS
+    if (KSPLIT) {
+      __syncthreads();                                 // patch and weight buffers are free
+      float* xch = reinterpret_cast<float*>(lds) + (long)wave * (NT * 16 * 64);       // this wave's outgoing block
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xch[(nt * 16 + r) * 64 + lane] = kq2 ? acc[0][nt][r] : acc[MT - 1][nt][r];
+      __syncthreads();
+    }
+    float cs[NT], cq[NT];
+    {
+      const float* xin = reinterpret_cast<const float*>(lds) + (long)(wave ^ 1) * (NT * 16 * 64);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        cs[nt] = 0.f;
+        cq[nt] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + rows0 + kq2 * 32 + 4 * lh + (r & 3) + 8 * (r >> 2);
+          float v = kq2 ? acc[MT - 1][nt][r] : acc[0][nt][r];
+          if (KSPLIT) v += xin[(nt * 16 + r) * 64 + lane];
+          v *= oscale;
+          if (row < g.M) {
+            g.y[(long)row * g.Cout + n0 + wn * (BN / 2) + nt * 32 + li] = v;
+            cs[nt] += v;
+            cq[nt] = fmaf(v, v, cq[nt]);
+          }
+        }
+      }
+    }
+    if (g.part_sum) {
+      const int rb = KSPLIT ? wm * 2 + kq2 : wm;       // the tile's four 32-row blocks
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        cs[nt] += __shfl_xor(cs[nt], 32);
+        cq[nt] += __shfl_xor(cq[nt], 32);
+        if (lh == 0) {
+          scratch[0][rb][wn * (BN / 2) + nt * 32 + li] = cs[nt];
+          scratch[1][rb][wn * (BN / 2) + nt * 32 + li] = cq[nt];
+        }
+      }
+      __syncthreads();
+      if (tid < BN) {
+        g.part_sum[(long)tm * g.Cout + n0 + tid] = (scratch[0][0][tid] + scratch[0][1][tid]) + (scratch[0][2][tid] + scratch[0][3][tid]);
+        g.part_sq[(long)tm * g.Cout + n0 + tid] = (scratch[1][0][tid] + scratch[1][1][tid]) + (scratch[1][2][tid] + scratch[1][3][tid]);
+      }
+    }
+  }
+}
+
+}  // namespace
+
+bool conv3x3_patch_eligible(const float* x, long sxb, long sxh, long sxw, long sxc, int Bn, int H, int W, int Cin,
+                            int Cout, int k, int stride, int pad, const float* in_scale, const float* in_shift) {
+  if (!(k == 3 && stride == 1 && pad == 1)) return false;
+  return sxc == 1 && sxw == Cin && sxh == (long)W * Cin && sxb == (long)H * W * Cin && Cin % 32 == 0 && Cout % 64 == 0 &&
+         W >= 3 && H >= 3 && PBM + 2 * W + 2 <= kPmax && aligned16(x) && (long)Bn * H * W < (1l << 24) &&
+         (long)Bn * H * W * (Cin > Cout ? Cin : Cout) < (1l << 31) &&
+         (!in_scale || (aligned16(in_scale) && aligned16(in_shift)));
+}
+
+// same weight image and tile width as conv_fwd_f16x3 (conv_f16x3_pack, conv1x1_f16x3_bn); statistics rows conv1x1_tiles_m(M).
+// shared_chip: other kernels run beside this one (several trunk passes in flight)
+int conv3x3_fwd_patch(const float* x, const unsigned* wimg, int bn, float* y, const float* in_scale, const float* in_shift,
+                      int relu_in, float* part_sum, float* part_sq, int Bn, int H, int W, int Cin, int Cout,
+                      hipStream_t stream, bool shared_chip) {
+  CAPNET_REQUIRE(x && wimg && y && aligned16(wimg) && (bn == 64 || bn == 128) && Cout % bn == 0, "conv3x3_fwd_patch: bad argument");
+  CAPNET_REQUIRE(conv3x3_patch_eligible(x, (long)H * W * Cin, (long)W * Cin, Cin, 1, Bn, H, W, Cin, Cout, 3, 1, 1, in_scale, in_shift),
+                 "conv3x3_fwd_patch: operands not eligible");
+  CAPNET_REQUIRE((in_scale == nullptr) == (in_shift == nullptr) && (part_sum == nullptr) == (part_sq == nullptr),
+                 "conv3x3_fwd_patch: scale / shift and statistics come in pairs");
+  PArgs a{};
+  a.x = x; a.wimg = wimg; a.y = y; a.in_scale = in_scale; a.in_shift = in_shift; a.part_sum = part_sum; a.part_sq = part_sq;
+  a.M = Bn * H * W; a.Cin = Cin; a.Cout = Cout; a.relu_in = relu_in; a.H = H; a.W = W;
+  a.tiles_m = cdiv(a.M, PBM); a.tiles_n = Cout / bn;
+  magic_div((unsigned)a.tiles_n, &a.tn_mul, &a.tn_sh);
+  magic_div((unsigned)(H * W), &a.hw_mul, &a.hw_sh);
+  magic_div((unsigned)W, &a.w_mul, &a.w_sh);
+  const char* ge = getenv("CAPNET_P3_WGS");
+  const int cap = ge ? atoi(ge) : 512;
+  const int total = a.tiles_m * a.tiles_n;
+  const dim3 grid(total <= cap ? total : cap), block(kThreads);
+  // at most one tile per CU and nothing else on the chip: a workgroup is alone on its CU, the pairs split K (see the
+  // top of the file). Beside other passes' kernels (shared_chip) the <= 128-VGPR arrangement wins although it is the
+  // slower one alone: a 185-VGPR workgroup of 8 waves keeps every other conv workgroup off its CU. Measured in the
+  // pipelined step: 8 319 images/s without K split, 8 227 with it on the 7 x 7 maps only, 7 981 on 14 x 14 and 7 x 7,
+  // 8 097 on the implicit-GEMM kernel (CAPNET_P3_KSPLIT_MAX overrides the bound on the tile count).
+  static const int ks_env = [] { const char* e = getenv("CAPNET_P3_KSPLIT_MAX"); return e ? atoi(e) : -1; }();
+  const int ks_max = ks_env >= 0 ? ks_env : (shared_chip ? 0 : 256);
+  const bool ksplit = total <= ks_max;
+  if (bn == 128) {
+    if (ksplit) hipLaunchKernelGGL((conv3x3_patch_kernel<128, true>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((conv3x3_patch_kernel<128, false>), grid, block, 0, stream, a);
+  } else {
+    if (ksplit) hipLaunchKernelGGL((conv3x3_patch_kernel<64, true>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((conv3x3_patch_kernel<64, false>), grid, block, 0, stream, a);
+  }
+  CAPNET_LAUNCH_CHECK();
+  return kOk;
+}
+
+}  // namespace capnet

@@ -100,6 +100,13 @@ int conv_stem_f16x3_part_rows(int Bn, int H, int W);
 int conv_stem_f16x3_pack(const float* w_oihw, unsigned* img, hipStream_t stream);
 int conv_stem_fwd_f16x3(const float* x, long sxb, long sxc, long sxh, const unsigned* wimg, float* y, float* part_sum,
                         float* part_sq, int Bn, int H, int W, hipStream_t stream);
+// ... and the stride-1 3x3 ones with the tile's input patch resident in LDS (conv3x3_patch.hip): same weight image,
+// tile width and statistics rows as conv_fwd_f16x3; dense NHWC input
+bool conv3x3_patch_eligible(const float* x, long sxb, long sxh, long sxw, long sxc, int Bn, int H, int W, int Cin,
+                            int Cout, int k, int stride, int pad, const float* in_scale, const float* in_shift);
+int conv3x3_fwd_patch(const float* x, const unsigned* wimg, int bn, float* y, const float* in_scale, const float* in_shift,
+                      int relu_in, float* part_sum, float* part_sq, int Bn, int H, int W, int Cin, int Cout,
+                      hipStream_t stream, bool shared_chip = false);
 size_t conv1x1_f16x3_weight_words(int Cin, int Cout);
 int conv1x1_f16x3_pack(const float* w, unsigned* img, int Cout, int Cin, int bn, hipStream_t stream);
 int conv1x1_fwd_f16x3(const float* x, long sxb, long sxh, long sxw, const unsigned* wimg, int bn, float* y,

@@ -293,6 +293,12 @@ struct Ctx {
   float* bvar(int i) const { return ws + t->bs_off[i] + t->convs[i].Cout; }
 };
 
+// CAPNET_NO_P3=1: the stride-1 3x3 convolutions stay on the implicit-GEMM kernel (A/B runs)
+static bool use_patch_kernel() {
+  static const bool on = [] { const char* e = getenv("CAPNET_NO_P3"); return !(e && e[0] == '1'); }();
+  return on;
+}
+
 // conv i + the (scale, shift) of the BatchNorm that follows it
 int conv_bn(const Ctx& c, int i, const float* x, long sxb, long sxh, long sxw, long sxc,
             const float* in_scale, const float* in_shift, int relu_in, float* y) {
@@ -320,6 +326,12 @@ int conv_bn(const Ctx& c, int i, const float* x, long sxb, long sxh, long sxw, l
                    "trunk: the stem is planned for the split-f16 kernel but its operands are not eligible");
     rc = conv_stem_fwd_f16x3(x, sxb, sxc, sxh, reinterpret_cast<const unsigned*>(c.w[i]), y, c.train ? psum : nullptr,
                              c.train ? psq : nullptr, c.t->B, d.H, d.W, c.s);
+  } else if (d.h3 && d.k == 3 && use_patch_kernel() &&
+             conv3x3_patch_eligible(x, sxb, sxh, sxw, sxc, c.t->B, d.H, d.W, d.Cin, d.Cout, d.k, d.stride, d.pad, in_scale, in_shift)) {
+    // stride-1 3x3: the tile's input patch staged once instead of once per tap (conv3x3_patch.hip), same weight image
+    rc = conv3x3_fwd_patch(x, reinterpret_cast<const unsigned*>(c.w[i]), d.x6_bn, y, in_scale, in_shift, relu_in,
+                           c.train ? psum : nullptr, c.train ? psq : nullptr, c.t->B, d.H, d.W, d.Cin, d.Cout, c.s,
+                           !c.t->tail_balance);
   } else if (d.h3) {
     CAPNET_REQUIRE(conv_f16x3_eligible(x, sxb, sxh, sxw, sxc, c.t->B, d.H, d.W, d.Cin, d.Cout, d.k, d.stride, d.pad, in_scale, in_shift),
                    "trunk: conv %d planned for the split-f16 kernel but its operands are not eligible", i);

@@ -213,6 +213,14 @@ int capnet_conv2d_fwd_f16x3(const float* x, long sxb, long sxh, long sxw, const 
                             const float* out_scale, const float* out_shift, const float* res, int relu_out,
                             capnet_stream_t stream);
 
+/* The stride-1 3x3 convolutions with the tile's input patch staged once in LDS instead of once per tap
+ * (csrc/conv3x3_patch.hip; torchvision Bottleneck.conv2, /root/reference/stylenet/model.py:14-33): dense NHWC x
+ * [B][H][W][Cin], Cin % 32 == 0, Cout % bn == 0, W <= 56; weight image, bn and statistics rows exactly as
+ * capnet_conv2d_fwd_f16x3 with k = 3. */
+int capnet_conv3x3_fwd_patch(const float* x, const unsigned* image, int bn, float* y, const float* in_scale,
+                             const float* in_shift, int relu_in, float* part_sum, float* part_sq, int B, int H, int W,
+                             int Cin, int Cout, capnet_stream_t stream);
+
 /* The stem on the same arithmetic (csrc/conv_stem.hip): 7x7, stride 2, pad 3, 3 -> 64 channels; x is the NCHW image
  * (strides in floats, unit stride along W, W % 4 == 0, 16-B aligned rows), y is NHWC [B][OH][OW][64]. Replaces
  * torchvision resnet152.conv1 as run by /root/reference/stylenet/model.py:14-24,33. Weights: capnet_conv_stem_f16x3_pack

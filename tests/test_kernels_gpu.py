@@ -758,3 +758,42 @@ def test_conv_stem_f16x3_matches_fp64(dev, B, H, W):
     check(L.capnet_conv_stem_fwd_f16x3(ptr(xd), xd.stride(0), xd.stride(1), xd.stride(2), ptr(img), ptr(y2), None,
                                        None, B, H, W, current_stream()))
     assert torch.equal(y, y2)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,bn,pre", [
+    (2, 14, 14, 256, 256, 128, True), (3, 7, 7, 512, 512, 128, True), (1, 56, 56, 64, 64, 64, True),
+    (2, 28, 28, 128, 128, 128, False), (2, 9, 11, 64, 128, 64, True), (5, 3, 3, 32, 64, 64, False)])
+def test_conv3x3_patch_matches_fp64(dev, B, H, W, Cin, Cout, bn, pre):
+    """Stride-1 3x3 convolution with the tile's input patch resident in LDS: fp32-grade against fp64 on the trunk's
+    four map sizes, odd maps, tiles that span several images and ragged last tiles; same weight image as the
+    implicit-GEMM kernel, whose output it must reproduce to rounding."""
+    g = torch.Generator().manual_seed(13 * B + H + W + Cin + Cout)
+    x = torch.randn(B, Cin, H, W, generator=g) * torch.exp(0.5 * torch.randn(B, Cin, H, W, generator=g))
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05 * torch.exp(0.5 * torch.randn(Cout, Cin, 3, 3, generator=g))
+    scale = torch.rand(Cin, generator=g) - 0.3 if pre else None
+    shift = torch.randn(Cin, generator=g) if pre else None
+    xin = torch.relu(x * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)).double() if pre else x.double()
+    ref = torch.nn.functional.conv2d(xin, w.double(), stride=1, padding=1)
+    M = B * H * W
+    ref = ref.permute(0, 2, 3, 1).reshape(M, Cout)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    L = lib()
+    img = ops.pack_conv_weight_f16x3(w.to(dev), bn)
+    y = torch.full((M, Cout), float("nan"), device=dev)
+    tiles = L.capnet_conv1x1_tiles_m(M)
+    psum = torch.full((tiles, Cout), float("nan"), device=dev)
+    psq = torch.full((tiles, Cout), float("nan"), device=dev)
+    sd, hd = (scale.to(dev), shift.to(dev)) if pre else (None, None)
+    check(L.capnet_conv3x3_fwd_patch(ptr(xd), ptr(img), bn, ptr(y), ptr(sd), ptr(hd), int(pre), ptr(psum), ptr(psq),
+                                     B, H, W, Cin, Cout, current_stream()))
+    assert rel_err(y, ref) < 3e-6
+    rms = (((y.double().cpu() - ref) ** 2).mean().sqrt() / (ref ** 2).mean().sqrt()).item()
+    print("3x3 patch kernel rms vs fp64: %.2e" % rms)
+    assert rms < 8e-7          # K = 9 * 512 = 4 608 fp32 accumulations at the deep end
+    assert rel_err(psum.sum(0), ref.sum(0)) < 1e-5
+    assert rel_err(psq.sum(0), (ref ** 2).sum(0)) < 1e-5
+    if Cin % 64 == 0:
+        y2 = torch.full_like(y, float("nan"))
+        check(L.capnet_conv2d_fwd_f16x3(ptr(xd), H * W * Cin, W * Cin, Cin, ptr(img), bn, ptr(y2), ptr(sd), ptr(hd), int(pre),
+                                        None, None, B, H, W, Cin, Cout, 3, 1, 1, None, None, None, 0, current_stream()))
+        assert rel_err(y, y2) < 4e-6          # another order of the same fp32 accumulation
