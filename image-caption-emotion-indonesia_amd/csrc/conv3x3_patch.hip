@@ -170,20 +170,26 @@ __global__ __launch_bounds__(kThreads, KSPLIT ? 2 : 4) void conv3x3_patch_kernel
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
+    // k-step s = 9 c + t uses weight buffer s & 1. The weights of step s + 1 are written to the other buffer right BEHIND
+    // the barrier that opens step s (every wave is then through with step s - 1, which read it), from registers loaded a
+    // whole step earlier, and the loads of step s + 2 follow: a barrier never waits for an LDS write issued just before it.
+    auto kt_of = [&](int s2) { const int c2 = s2 / 9; return (s2 - 9 * c2) * nkc + c2; };       // kt = tap * nkc + chunk
     fetch_patch(0);
-    fetch_b(0);                                        // kt = tap * nkc + chunk: (tap 0, chunk 0)
+    fetch_b(0);
+    __syncthreads();                                   // every wave is through with the previous tile's buffers
+    stage_b(0);
+    if (nk > 1) fetch_b(kt_of(1));
     int step = 0;
     for (int c = 0; c < nkc; ++c) {
-      __syncthreads();                                 // every wave is through with the previous chunk's patch (and tile's exchange)
+      if (c > 0) __syncthreads();                      // every wave is through with the previous chunk's patch
       stage_patch();
       if (c + 1 < nkc) fetch_patch(c + 1);
 #pragma unroll
       for (int t = 0; t < 9; ++t, ++step) {
         const int buf = step & 1;
-        stage_b(buf);
         __syncthreads();
-        if (t < 8) fetch_b((t + 1) * nkc + c);
-        else if (c + 1 < nkc) fetch_b(c + 1);
+        if (step + 1 < nk) stage_b(buf ^ 1);
+        if (step + 2 < nk) fetch_b((t + 2 < 9) ? (t + 2) * nkc + c : (t + 2 - 9) * nkc + c + 1);
         const int toff = ((t / 3) * W + t % 3) * 16;                 // patch position of row 0 under this tap
 #pragma unroll
         for (int gi = 0; gi < (KSPLIT ? 1 : 2); ++gi) {              // k16 groups of this wave: its own one / both

@@ -1,7 +1,8 @@
 """One trunk layer launched N times, for rocprofv3 --pmc passes (tools/pmc_sq2.sh).
     python tools/layer_one.py x6 s3c3 128 [iters]      bf16x6 1x1 conv
     python tools/layer_one.py wino s3c2 0 [iters]      Winograd 3x3 conv
-    python tools/layer_one.py h33 s3c2 0 [iters]       3x3 conv on the split-f16 kernel"""
+    python tools/layer_one.py h33 s3c2 0 [iters]       3x3 conv on the split-f16 kernel
+    python tools/layer_one.py p33 s3c2 0 [iters]       ... with the input patch in LDS (P3_ALONE=1: the K-split arrangement)"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import capnet
@@ -37,6 +38,17 @@ elif kind == "h33":
     ps, pq = torch.empty(t, C, device=dev), torch.empty(t, C, device=dev)
     run = lambda: check(L.capnet_conv2d_fwd_f16x3(ptr(x), H * H * C, H * C, C, ptr(img), bnw, ptr(y), ptr(sc), ptr(sh), 1, ptr(ps), ptr(pq),
                                                    B, H, H, C, C, 3, 1, 1, None, None, None, 0, current_stream()))
+elif kind == "p33":
+    H, C = WI[name]
+    M = B * H * H
+    x = torch.randn(B, H, H, C, device=dev); w = torch.randn(C, C, 3, 3, device=dev) * 0.05
+    y = torch.empty(M, C, device=dev)
+    sc, sh = torch.rand(C, device=dev) + 0.5, torch.randn(C, device=dev)
+    bnw = 128 if C % 128 == 0 else 64
+    img = ops.pack_conv_weight_f16x3(w, bnw)
+    t = L.capnet_conv1x1_tiles_m(M)
+    ps, pq = torch.empty(t, C, device=dev), torch.empty(t, C, device=dev)
+    run = lambda: check(L.capnet_conv3x3_fwd_patch(ptr(x), ptr(img), bnw, ptr(y), ptr(sc), ptr(sh), 1, ptr(ps), ptr(pq), B, H, H, C, C, current_stream()))
 else:
     H, C = WI[name]
     x = torch.randn(B, H, H, C, device=dev); w = torch.randn(C, C, 3, 3, device=dev) * 0.05

@@ -41,7 +41,7 @@ def main():
         for k, v in sorted(fetch.items(), key=lambda kv: -(2 * kv[1][1] + write.get(kv[0], [0, 0])[1]))[:14]:
             print("%s,%d,%.0f,%.0f" % (k.replace(",", ";"), v[0], v[1], write.get(k, [0, 0])[1]))
         return
-    convk = ("conv_f32", "conv_wino", "conv1x1_bf16x6", "conv_f16x3_kernel")
+    convk = ("conv_f32", "conv_wino", "conv1x1_bf16x6", "conv_f16x3_kernel", "conv3x3_patch_kernel", "conv_stem_f16x3_kernel")
     conv = lambda n: any(k in n for k in convk) or "conv_tail_fixup" in n
     launches = sum(v[0] for k, v in fetch.items() if any(c in k for c in convk))   # fix-ups belong to a conv
     wino = lambda n: "conv_wino" in n
@@ -54,6 +54,12 @@ def main():
     h3 = lambda n: "conv_f16x3_kernel" in n
     h3_n = sum(v[0] for k, v in fetch.items() if h3(k))
     h3_bytes = (2.0 * sum(v[1] for k, v in fetch.items() if h3(k)) + sum(v[1] for k, v in write.items() if h3(k))) * 1024.0
+    p3 = lambda n: "conv3x3_patch_kernel" in n
+    p3_n = sum(v[0] for k, v in fetch.items() if p3(k))
+    p3_bytes = (2.0 * sum(v[1] for k, v in fetch.items() if p3(k)) + sum(v[1] for k, v in write.items() if p3(k))) * 1024.0
+    st = lambda n: "conv_stem_f16x3_kernel" in n
+    st_n = sum(v[0] for k, v in fetch.items() if st(k))
+    st_bytes = (2.0 * sum(v[1] for k, v in fetch.items() if st(k)) + sum(v[1] for k, v in write.items() if st(k))) * 1024.0
     x6_n = sum(v[0] for k, v in fetch.items() if x6(k))
     x6_bytes = (2.0 * sum(v[1] for k, v in fetch.items() if x6(k)) + sum(v[1] for k, v in write.items() if x6(k))) * 1024.0
     lp = lambda n: "lstm_persist_kernel" in n
@@ -75,6 +81,10 @@ def main():
         "winograd_bytes_per_launch": round(wino_bytes / max(wino_n, 1)),
         "f16x3_launches": h3_n,
         "f16x3_bytes_per_launch": round(h3_bytes / max(h3_n, 1)),
+        "patch3x3_launches": p3_n,
+        "patch3x3_bytes_per_launch": round(p3_bytes / max(p3_n, 1)),
+        "stem_launches": st_n,
+        "stem_bytes_per_launch": round(st_bytes / max(st_n, 1)),
         "bf16x6_launches": x6_n,
         "bf16x6_bytes_per_launch": round(x6_bytes / max(x6_n, 1)),
         "lstm_persist_launches": lp_n,
