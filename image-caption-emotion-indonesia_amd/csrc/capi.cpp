@@ -96,8 +96,9 @@ int capnet_conv2d_fwd_f16x3(const float* x, long sxb, long sxh, long sxw, const 
 
 int capnet_conv3x3_fwd_patch(const float* x, const unsigned* image, int bn, float* y, const float* in_scale,
                              const float* in_shift, int relu_in, float* part_sum, float* part_sq, int B, int H, int W,
-                             int Cin, int Cout, capnet_stream_t stream) {
-  return conv3x3_fwd_patch(x, image, bn, y, in_scale, in_shift, relu_in, part_sum, part_sq, B, H, W, Cin, Cout, S(stream));
+                             int Cin, int Cout, int shared_chip, capnet_stream_t stream) {
+  return conv3x3_fwd_patch(x, image, bn, y, in_scale, in_shift, relu_in, part_sum, part_sq, B, H, W, Cin, Cout, S(stream),
+                           shared_chip != 0);
 }
 size_t capnet_conv_stem_f16x3_weight_words(void) { return conv_stem_f16x3_weight_words(); }
 int capnet_conv_stem_f16x3_part_rows(int B, int H, int W) { return conv_stem_f16x3_part_rows(B, H, W); }

@@ -216,10 +216,12 @@ int capnet_conv2d_fwd_f16x3(const float* x, long sxb, long sxh, long sxw, const 
 /* The stride-1 3x3 convolutions with the tile's input patch staged once in LDS instead of once per tap
  * (csrc/conv3x3_patch.hip; torchvision Bottleneck.conv2, /root/reference/stylenet/model.py:14-33): dense NHWC x
  * [B][H][W][Cin], Cin % 32 == 0, Cout % bn == 0, W <= 56; weight image, bn and statistics rows exactly as
- * capnet_conv2d_fwd_f16x3 with k = 3. */
+ * capnet_conv2d_fwd_f16x3 with k = 3. shared_chip != 0: other kernels run beside this one (several trunk passes in
+ * flight) -- the <= 128-VGPR wave arrangement is used whatever the tile count; 0: launches of at most one tile per CU
+ * split K between wave pairs (faster alone). Results differ between the two at rounding level only. */
 int capnet_conv3x3_fwd_patch(const float* x, const unsigned* image, int bn, float* y, const float* in_scale,
                              const float* in_shift, int relu_in, float* part_sum, float* part_sq, int B, int H, int W,
-                             int Cin, int Cout, capnet_stream_t stream);
+                             int Cin, int Cout, int shared_chip, capnet_stream_t stream);
 
 /* The stem on the same arithmetic (csrc/conv_stem.hip): 7x7, stride 2, pad 3, 3 -> 64 channels; x is the NCHW image
  * (strides in floats, unit stride along W, W % 4 == 0, 16-B aligned rows), y is NHWC [B][OH][OW][64]. Replaces

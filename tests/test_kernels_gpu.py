@@ -760,13 +760,15 @@ def test_conv_stem_f16x3_matches_fp64(dev, B, H, W):
     assert torch.equal(y, y2)
 
 
+@pytest.mark.parametrize("shared", [0, 1])
 @pytest.mark.parametrize("B,H,W,Cin,Cout,bn,pre", [
     (2, 14, 14, 256, 256, 128, True), (3, 7, 7, 512, 512, 128, True), (1, 56, 56, 64, 64, 64, True),
     (2, 28, 28, 128, 128, 128, False), (2, 9, 11, 64, 128, 64, True), (5, 3, 3, 32, 64, 64, False)])
-def test_conv3x3_patch_matches_fp64(dev, B, H, W, Cin, Cout, bn, pre):
+def test_conv3x3_patch_matches_fp64(dev, B, H, W, Cin, Cout, bn, pre, shared):
     """Stride-1 3x3 convolution with the tile's input patch resident in LDS: fp32-grade against fp64 on the trunk's
     four map sizes, odd maps, tiles that span several images and ragged last tiles; same weight image as the
-    implicit-GEMM kernel, whose output it must reproduce to rounding."""
+    implicit-GEMM kernel, whose output it must reproduce to rounding. shared = 0: wave pairs split K (these launches
+    have at most one tile per CU); 1: the <= 128-VGPR arrangement used beside other kernels."""
     g = torch.Generator().manual_seed(13 * B + H + W + Cin + Cout)
     x = torch.randn(B, Cin, H, W, generator=g) * torch.exp(0.5 * torch.randn(B, Cin, H, W, generator=g))
     w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05 * torch.exp(0.5 * torch.randn(Cout, Cin, 3, 3, generator=g))
@@ -785,7 +787,7 @@ def test_conv3x3_patch_matches_fp64(dev, B, H, W, Cin, Cout, bn, pre):
     psq = torch.full((tiles, Cout), float("nan"), device=dev)
     sd, hd = (scale.to(dev), shift.to(dev)) if pre else (None, None)
     check(L.capnet_conv3x3_fwd_patch(ptr(xd), ptr(img), bn, ptr(y), ptr(sd), ptr(hd), int(pre), ptr(psum), ptr(psq),
-                                     B, H, W, Cin, Cout, current_stream()))
+                                     B, H, W, Cin, Cout, shared, current_stream()))
     assert rel_err(y, ref) < 3e-6
     rms = (((y.double().cpu() - ref) ** 2).mean().sqrt() / (ref ** 2).mean().sqrt()).item()
     print("3x3 patch kernel rms vs fp64: %.2e" % rms)

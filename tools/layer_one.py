@@ -48,7 +48,7 @@ elif kind == "p33":
     img = ops.pack_conv_weight_f16x3(w, bnw)
     t = L.capnet_conv1x1_tiles_m(M)
     ps, pq = torch.empty(t, C, device=dev), torch.empty(t, C, device=dev)
-    run = lambda: check(L.capnet_conv3x3_fwd_patch(ptr(x), ptr(img), bnw, ptr(y), ptr(sc), ptr(sh), 1, ptr(ps), ptr(pq), B, H, H, C, C, current_stream()))
+    run = lambda: check(L.capnet_conv3x3_fwd_patch(ptr(x), ptr(img), bnw, ptr(y), ptr(sc), ptr(sh), 1, ptr(ps), ptr(pq), B, H, H, C, C, int(os.environ.get("P3_SHARED", "0")), current_stream()))
 else:
     H, C = WI[name]
     x = torch.randn(B, H, H, C, device=dev); w = torch.randn(C, C, 3, 3, device=dev) * 0.05

@@ -17,7 +17,7 @@ for side, ch in ((56, 64), (28, 128), (14, 256), (7, 512)):
     ps, pq = torch.empty(tiles, ch, device=dev), torch.empty(tiles, ch, device=dev)
     y1, y2 = torch.empty(M, ch, device=dev), torch.empty(M, ch, device=dev)
     def patch():
-        check(L.capnet_conv3x3_fwd_patch(ptr(x), ptr(img), bn, ptr(y1), ptr(sc), ptr(sh), 1, ptr(ps), ptr(pq), B, side, side, ch, ch, current_stream()))
+        check(L.capnet_conv3x3_fwd_patch(ptr(x), ptr(img), bn, ptr(y1), ptr(sc), ptr(sh), 1, ptr(ps), ptr(pq), B, side, side, ch, ch, int(os.environ.get("P3_SHARED", "0")), current_stream()))
     def gemm():
         check(L.capnet_conv2d_fwd_f16x3(ptr(x), side * side * ch, side * ch, ch, ptr(img), bn, ptr(y2), ptr(sc), ptr(sh), 1, ptr(ps), ptr(pq),
                                         B, side, side, ch, ch, 3, 1, 1, None, None, None, 0, current_stream()))
