@@ -74,6 +74,7 @@ SIGNATURES = {
     "capnet_conv1x1_fwd_f16x3": (_i, [_vp, _l, _l, _l, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i,
                                       _i, _vp, _vp, _vp, _i, _vp]),
     "capnet_conv3x3_fwd_patch": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "capnet_conv1x1_fwd_tail": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _l, _i, _i, _vp]),
     "capnet_conv_stem_f16x3_weight_words": (_sz, []),
     "capnet_conv_stem_f16x3_part_rows": (_i, [_i, _i, _i]),
     "capnet_conv_stem_f16x3_pack": (_i, [_vp, _vp, _vp]),

@@ -100,6 +100,11 @@ int capnet_conv3x3_fwd_patch(const float* x, const unsigned* image, int bn, floa
   return conv3x3_fwd_patch(x, image, bn, y, in_scale, in_shift, relu_in, part_sum, part_sq, B, H, W, Cin, Cout, S(stream),
                            shared_chip != 0);
 }
+int capnet_conv1x1_fwd_tail(const float* y3, const float* s1, const float* t1, const float* res, const float* s2,
+                            const float* t2, float* tail_out, const unsigned* image, int bn, float* y, float* part_sum,
+                            float* part_sq, long M, int Cin, int Cout, capnet_stream_t stream) {
+  return conv1x1_fwd_tail(y3, s1, t1, res, s2, t2, tail_out, image, bn, y, part_sum, part_sq, M, Cin, Cout, S(stream));
+}
 size_t capnet_conv_stem_f16x3_weight_words(void) { return conv_stem_f16x3_weight_words(); }
 int capnet_conv_stem_f16x3_part_rows(int B, int H, int W) { return conv_stem_f16x3_part_rows(B, H, W); }
 int capnet_conv_stem_f16x3_pack(const float* w_oihw, unsigned* image, capnet_stream_t stream) {

@@ -48,6 +48,12 @@ struct PArgs {
   int M, Cin, Cout, relu_in, H, W;
   int tiles_m, tiles_n;
   unsigned tn_mul, tn_sh, hw_mul, hw_sh, w_mul, w_sh;
+  // conv1x1_tail_kernel: the block tail it absorbs -- input = relu(x * in_scale + in_shift + res (* res_scale + res_shift)),
+  // also written to tail_out
+  const float* res;
+  const float* res_scale;
+  const float* res_shift;
+  float* tail_out;
 };
 
 __device__ __forceinline__ void p_split4(const f32x4 v, h4& h, h4& l) {
@@ -272,6 +278,166 @@ __global__ __launch_bounds__(kThreads, KSPLIT ? 2 : 4) void conv3x3_patch_kernel
   }
 }
 
+// A bottleneck block's tail fused into the next block's first convolution. The tail -- out = relu(bn3(y3) + identity),
+// three passes over the block's widest tensor (bn_add_relu, 40 % of the trunk's memory traffic) -- has one consumer that
+// needs every element anyway: the stride-1 1x1 conv1 that follows. This kernel is that conv1 with the tail as its staging
+// step: per 32-channel chunk a thread reads its 2 x 4 values of y3 and of the identity (and the two BatchNorms' scale /
+// shift), forms out, WRITES it (workgroups of column tile 0 only: the next tail needs it as its identity) and splits it
+// into the f16 planes of the A operand. Eight waves at <= 128 VGPRs, both operands double-buffered in LDS, the (tile,
+// chunk) steps of a workgroup one stream: operands of step s + 1 are written behind the barrier that opens step s,
+// those of step s + 2 fetched then -- also across the end of a tile.
+template <int BN>
+__global__ __launch_bounds__(kThreads, 4) void conv1x1_tail_kernel(const PArgs g) {
+  constexpr int NT = BN / 64;
+  constexpr int kSubB = BN * 2 * 16, kImgB = 4 * kSubB;
+  constexpr int NBR = kImgB / 16 / kThreads;
+  constexpr int kSubA = PBM * 16, kImgA = 8 * kSubA;            // [plane 2][group 4][pixel 128][8 halfs]
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kImgA + 2 * kImgB];
+  __shared__ float scratch[2][4][BN];
+  unsigned char* const abuf = lds;
+  unsigned char* const bbuf = lds + 2 * kImgA;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+  const int Cin = g.Cin, nkc = Cin / 32, kc_sh = g.H;           // nkc = 1 << kc_sh
+  const int total = g.tiles_m * g.tiles_n, G = (int)gridDim.x;
+  const int my_tiles = (total - 1 - (int)blockIdx.x) / G + 1;
+  const int n_steps = my_tiles * nkc;
+  const float oscale = ldexpf(1.f, -(int)g.wimg[0]);
+  const int pq = tid & 7, ppx = tid >> 3;              // this thread's 4 channels of a chunk and its pixel (and pixel + 64)
+  const unsigned char* const a_rd = abuf + lh * kSubA + (wm * 32 + li) * 16;
+  const unsigned char* const b_rd = bbuf + p_cell(wn * (BN / 2) + li, lh);
+
+  f32x4 pre[2], rsd[2], fs, ft, gs, gt;
+  u4 bre[NBR];
+  auto tile_of = [&](int s, int& tm, int& tn) {
+    const int id = xcd_remap((int)blockIdx.x + (s >> kc_sh) * G, total);
+    tm = (int)fast_div((unsigned)id, g.tn_mul, g.tn_sh);
+    tn = id - tm * g.tiles_n;
+  };
+  auto fetch = [&](int s) {
+    int tm, tn;
+    tile_of(s, tm, tn);
+    const int c = s & (nkc - 1);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int m = tm * PBM + ppx + 64 * u;
+      const long e = (long)(m < g.M ? m : g.M - 1) * Cin + c * 32 + 4 * pq;        // rows past M: a valid row, never stored
+      pre[u] = *reinterpret_cast<const f32x4*>(g.x + e);
+      rsd[u] = *reinterpret_cast<const f32x4*>(g.res + e);
+    }
+    fs = *reinterpret_cast<const f32x4*>(g.in_scale + c * 32 + 4 * pq);
+    ft = *reinterpret_cast<const f32x4*>(g.in_shift + c * 32 + 4 * pq);
+    if (g.res_scale) {
+      gs = *reinterpret_cast<const f32x4*>(g.res_scale + c * 32 + 4 * pq);
+      gt = *reinterpret_cast<const f32x4*>(g.res_shift + c * 32 + 4 * pq);
+    }
+    const u4* src = reinterpret_cast<const u4*>(reinterpret_cast<const float*>(g.wimg + kHdrWords) + ((long)tn * nkc + c) * (kImgB / 4));
+#pragma unroll
+    for (int q = 0; q < NBR; ++q) bre[q] = src[tid + kThreads * q];
+  };
+  // (the registers hold step s)
+  auto stage = [&](int s) {
+    const int buf = s & 1;
+    int tm, tn;
+    tile_of(s, tm, tn);
+    const int c = s & (nkc - 1);
+    unsigned char* d = abuf + buf * kImgA + (pq >> 1) * kSubA + (pq & 1) * 8;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      // exactly bn_add_relu_kernel's arithmetic (bn_pool.hip): fma, (fma,) add, max
+      f32x4 v, rr = rsd[u];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = fmaf(pre[u][e], fs[e], ft[e]);
+      if (g.res_scale) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rr[e] = fmaf(rr[e], gs[e], gt[e]);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e] + rr[e], 0.f);
+      const int m = tm * PBM + ppx + 64 * u;
+      if (tn == 0 && m < g.M) *reinterpret_cast<f32x4*>(g.tail_out + (long)m * Cin + c * 32 + 4 * pq) = v;
+      h4 h, l;
+      p_split4(v, h, l);
+      *reinterpret_cast<h4*>(d + (ppx + 64 * u) * 16) = h;
+      *reinterpret_cast<h4*>(d + 4 * kSubA + (ppx + 64 * u) * 16) = l;
+    }
+#pragma unroll
+    for (int q = 0; q < NBR; ++q) *reinterpret_cast<u4*>(bbuf + buf * kImgB + (tid + kThreads * q) * 16) = bre[q];
+  };
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+  fetch(0);
+  stage(0);
+  if (n_steps > 1) fetch(1);
+  for (int s = 0; s < n_steps; ++s) {
+    const int buf = s & 1;
+    __syncthreads();                                   // step s is in LDS; every wave is through with step s - 1
+    if (s + 1 < n_steps) stage(s + 1);
+    if (s + 2 < n_steps) fetch(s + 2);
+#pragma unroll
+    for (int gq = 0; gq < 2; ++gq) {
+      h8 af[2], bf[NT][2];
+#pragma unroll
+      for (int p = 0; p < 2; ++p) af[p] = *reinterpret_cast<const h8*>(a_rd + buf * kImgA + (p * 4 + gq * 2) * kSubA);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+          bf[nt][p] = *reinterpret_cast<const h8*>(b_rd + buf * kImgB + (p * 2 + gq) * kSubB + nt * 1024);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1], bf[nt][0], acc[nt], 0, 0, 0);    // l h'
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0], bf[nt][1], acc[nt], 0, 0, 0);    // h l'
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0], bf[nt][0], acc[nt], 0, 0, 0);    // h h'
+      }
+    }
+    if ((s & (nkc - 1)) == nkc - 1) {
+      // ---- end of a tile: 2^-ew, store, column statistics of the rows below M
+      int tm, tn;
+      tile_of(s, tm, tn);
+      const int m0 = tm * PBM, n0 = tn * BN;
+      float cs[NT], cq[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        cs[nt] = 0.f;
+        cq[nt] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wm * 32 + 4 * lh + (r & 3) + 8 * (r >> 2);
+          const float v = acc[nt][r] * oscale;
+          acc[nt][r] = 0.f;
+          if (row < g.M) {
+            g.y[(long)row * g.Cout + n0 + wn * (BN / 2) + nt * 32 + li] = v;
+            cs[nt] += v;
+            cq[nt] = fmaf(v, v, cq[nt]);
+          }
+        }
+      }
+      if (g.part_sum) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          cs[nt] += __shfl_xor(cs[nt], 32);
+          cq[nt] += __shfl_xor(cq[nt], 32);
+          if (lh == 0) {
+            scratch[0][wm][wn * (BN / 2) + nt * 32 + li] = cs[nt];
+            scratch[1][wm][wn * (BN / 2) + nt * 32 + li] = cq[nt];
+          }
+        }
+        __syncthreads();
+        if (tid < BN) {
+          g.part_sum[(long)tm * g.Cout + n0 + tid] = (scratch[0][0][tid] + scratch[0][1][tid]) + (scratch[0][2][tid] + scratch[0][3][tid]);
+          g.part_sq[(long)tm * g.Cout + n0 + tid] = (scratch[1][0][tid] + scratch[1][1][tid]) + (scratch[1][2][tid] + scratch[1][3][tid]);
+        }
+      }
+    }
+  }
+}
+
 }  // namespace
 
 bool conv3x3_patch_eligible(const float* x, long sxb, long sxh, long sxw, long sxc, int Bn, int H, int W, int Cin,
@@ -319,6 +485,42 @@ int conv3x3_fwd_patch(const float* x, const unsigned* wimg, int bn, float* y, co
     if (ksplit) hipLaunchKernelGGL((conv3x3_patch_kernel<64, true>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((conv3x3_patch_kernel<64, false>), grid, block, 0, stream, a);
   }
+  CAPNET_LAUNCH_CHECK();
+  return kOk;
+}
+
+bool conv1x1_tail_eligible(const float* y3, const float* res, long M, int Cin, int Cout) {
+  const int nkc = Cin / 32;
+  return Cin % 32 == 0 && nkc > 0 && (nkc & (nkc - 1)) == 0 && Cout % 64 == 0 && aligned16(y3) && aligned16(res) && M > 0 &&
+         M < (1l << 24) && M * (Cin > Cout ? Cin : Cout) < (1l << 31);
+}
+
+// tail_out [M][Cin] = relu(y3 * s1 + t1 + res (* s2 + t2))   (a bottleneck block's tail, bn_add_relu's arithmetic) and
+// y [M][Cout] = tail_out . w^T (the next block's stride-1 1x1 conv1) in one launch; weight image, tile width and
+// statistics rows as conv_fwd_f16x3 with k = 1. s2 / t2 null: the identity is used as it is.
+int conv1x1_fwd_tail(const float* y3, const float* s1, const float* t1, const float* res, const float* s2, const float* t2,
+                     float* tail_out, const unsigned* wimg, int bn, float* y, float* part_sum, float* part_sq, long M,
+                     int Cin, int Cout, hipStream_t stream) {
+  CAPNET_REQUIRE(y3 && s1 && t1 && res && tail_out && wimg && y && aligned16(wimg) && aligned16(tail_out) && aligned16(s1) &&
+                     aligned16(t1) && (bn == 64 || bn == 128) && Cout % bn == 0 && conv1x1_tail_eligible(y3, res, M, Cin, Cout),
+                 "conv1x1_fwd_tail: bad argument");
+  CAPNET_REQUIRE((s2 == nullptr) == (t2 == nullptr) && (!s2 || (aligned16(s2) && aligned16(t2))) &&
+                     (part_sum == nullptr) == (part_sq == nullptr), "conv1x1_fwd_tail: scale / shift and statistics come in pairs");
+  PArgs a{};
+  a.x = y3; a.in_scale = s1; a.in_shift = t1; a.res = res; a.res_scale = s2; a.res_shift = t2; a.tail_out = tail_out;
+  a.wimg = wimg; a.y = y; a.part_sum = part_sum; a.part_sq = part_sq;
+  a.M = (int)M; a.Cin = Cin; a.Cout = Cout; a.relu_in = 1; a.W = 1;
+  const int nkc = Cin / 32;
+  a.H = 0;
+  while ((1 << a.H) < nkc) ++a.H;                     // (H carries log2 of the k-steps per tile)
+  a.tiles_m = cdiv(a.M, PBM); a.tiles_n = Cout / bn;
+  magic_div((unsigned)a.tiles_n, &a.tn_mul, &a.tn_sh);
+  const char* ge = getenv("CAPNET_TAIL_WGS");
+  const int cap = ge ? atoi(ge) : 512;
+  const int total = a.tiles_m * a.tiles_n;
+  const dim3 grid(total <= cap ? total : cap), block(kThreads);
+  if (bn == 128) hipLaunchKernelGGL((conv1x1_tail_kernel<128>), grid, block, 0, stream, a);
+  else hipLaunchKernelGGL((conv1x1_tail_kernel<64>), grid, block, 0, stream, a);
   CAPNET_LAUNCH_CHECK();
   return kOk;
 }

@@ -299,11 +299,41 @@ static bool use_patch_kernel() {
   return on;
 }
 
-// conv i + the (scale, shift) of the BatchNorm that follows it
+// A bottleneck block's tail that has not run yet: out = relu(y3 * s1 + t1 + res (* s2 + t2)), [rows][C]
+struct BlockTail {
+  const float* y3; const float* s1; const float* t1;
+  const float* res; const float* s2; const float* t2;
+  float* out;
+  long rows;
+  int C;
+};
+// CAPNET_NO_TAIL_FUSION=1: every tail as its own bn_add_relu launch (A/B runs)
+static bool use_tail_fusion() {
+  static const bool on = [] { const char* e = getenv("CAPNET_NO_TAIL_FUSION"); return !(e && e[0] == '1'); }();
+  return on;
+}
+static int run_tail(const Ctx& c, const BlockTail& t) {
+  return bn_add_relu(t.y3, t.s1, t.t1, t.res, t.s2, t.t2, t.out, t.rows, t.C, c.s);
+}
+
+// conv i + the (scale, shift) of the BatchNorm that follows it. tail: the previous block's tail is still pending and
+// x is its output -- it rides in this launch where the kernel exists (a stride-1 1x1 conv1 on the split-f16 path),
+// otherwise it is run first.
 int conv_bn(const Ctx& c, int i, const float* x, long sxb, long sxh, long sxw, long sxc,
-            const float* in_scale, const float* in_shift, int relu_in, float* y) {
+            const float* in_scale, const float* in_shift, int relu_in, float* y, const BlockTail* tail = nullptr) {
   const TrunkConv& d = c.t->convs[i];
   const long M = (long)c.t->B * d.OH * d.OW;
+  static const int tail_cmin = [] { const char* e = getenv("CAPNET_TAIL_CMIN"); return e ? atoi(e) : 0; }();
+  static const int tail_cmax = [] { const char* e = getenv("CAPNET_TAIL_CMAX"); return e ? atoi(e) : 1 << 30; }();
+  const bool fuse_tail = tail && c.train && use_tail_fusion() && d.h3 && d.k == 1 && d.stride == 1 && !in_scale &&
+                         d.Cin >= tail_cmin && d.Cin <= tail_cmax &&
+                         x == tail->out && tail->C == d.Cin && tail->rows == M && sxc == 1 && sxw == d.Cin &&
+                         sxh == (long)d.W * d.Cin && sxb == (long)d.H * d.W * d.Cin &&
+                         conv1x1_tail_eligible(tail->y3, tail->res, M, d.Cin, d.Cout);
+  if (tail && !fuse_tail) {
+    const int rt = run_tail(c, *tail);
+    if (rt) return rt;
+  }
   // single pass: the occupancy model picks the tile (64x64 almost everywhere: least quantisation
   // loss on 256 CUs). Several passes sharing the chip (tail_balance off, see above): quantisation
   // is filled by the other passes, so the 128x64 tile (half the B-tile traffic and staging VALU per
@@ -321,7 +351,11 @@ int conv_bn(const Ctx& c, int i, const float* x, long sxb, long sxh, long sxw, l
     CAPNET_HIP_CHECK(hipEventRecord(e0, c.s));
   }
   int rc;
-  if (d.stem_h3) {
+  if (fuse_tail) {
+    rc = conv1x1_fwd_tail(tail->y3, tail->s1, tail->t1, tail->res, tail->s2, tail->t2, tail->out,
+                          reinterpret_cast<const unsigned*>(c.w[i]), d.x6_bn, y, c.train ? psum : nullptr,
+                          c.train ? psq : nullptr, M, d.Cin, d.Cout, c.s);
+  } else if (d.stem_h3) {
     CAPNET_REQUIRE(!in_scale && conv_stem_f16x3_eligible(x, sxb, sxc, sxh, sxw, c.t->B, d.H, d.W, d.Cin, d.Cout, d.k, d.stride, d.pad),
                    "trunk: the stem is planned for the split-f16 kernel but its operands are not eligible");
     rc = conv_stem_fwd_f16x3(x, sxb, sxc, sxh, reinterpret_cast<const unsigned*>(c.w[i]), y, c.train ? psum : nullptr,
@@ -550,6 +584,8 @@ int trunk_forward(Trunk* t, const float* images_nchw, const float* const* w_pack
     ci = 1;
   }
   int cur = 0;
+  BlockTail tail{};
+  bool have_tail = false;
   const int blocks[4] = {3, 8, 36, 3};
   for (int L = 0; L < 4; ++L) {
     for (int b = 0; b < blocks[L]; ++b) {
@@ -566,7 +602,8 @@ int trunk_forward(Trunk* t, const float* images_nchw, const float* const* w_pack
       };
       long sb, sh, sw;
       nhwc(c1, &sb, &sh, &sw);
-      rc = conv_bn(c, i1, x, sb, sh, sw, 1, nullptr, nullptr, 0, Y1);
+      rc = conv_bn(c, i1, x, sb, sh, sw, 1, nullptr, nullptr, 0, Y1, have_tail ? &tail : nullptr);
+      have_tail = false;
       if (rc) return rc;
       nhwc(c2, &sb, &sh, &sw);
       rc = conv_bn(c, i2, Y1, sb, sh, sw, 1, c.scale(i1), c.shift(i1), 1, Y2);
@@ -580,15 +617,17 @@ int trunk_forward(Trunk* t, const float* images_nchw, const float* const* w_pack
         nhwc(cd, &sb, &sh, &sw);
         rc = conv_bn(c, id, x, sb, sh, sw, 1, nullptr, nullptr, 0, D);
         if (rc) return rc;
-        rc = bn_add_relu(Y3, c.scale(i3), c.shift(i3), D, c.scale(id), c.shift(id), out, rows,
-                         c3.Cout, stream);
+        tail = BlockTail{Y3, c.scale(i3), c.shift(i3), D, c.scale(id), c.shift(id), out, rows, c3.Cout};
       } else {
-        rc = bn_add_relu(Y3, c.scale(i3), c.shift(i3), x, nullptr, nullptr, out, rows, c3.Cout,
-                         stream);
+        tail = BlockTail{Y3, c.scale(i3), c.shift(i3), x, nullptr, nullptr, out, rows, c3.Cout};
       }
-      if (rc) return rc;
+      have_tail = true;      // runs inside the next block's conv1 (conv_bn), or below after the last block
       cur ^= 1;
     }
+  }
+  if (have_tail) {
+    rc = run_tail(c, tail);
+    if (rc) return rc;
   }
   const int side = t->final_side;
   if (out_pooled) {

@@ -223,6 +223,17 @@ int capnet_conv3x3_fwd_patch(const float* x, const unsigned* image, int bn, floa
                              const float* in_shift, int relu_in, float* part_sum, float* part_sq, int B, int H, int W,
                              int Cin, int Cout, int shared_chip, capnet_stream_t stream);
 
+/* A bottleneck block's tail fused into the next block's first convolution (csrc/conv3x3_patch.hip). One launch computes
+ *   tail_out [M][Cin] = relu(y3 * s1 + t1 + res (* s2 + t2))     -- torchvision Bottleneck.forward's `out += identity;
+ *                                                                    relu(out)` behind bn3 (and the downsample's BatchNorm)
+ *   y [M][Cout]       = tail_out . w^T                            -- the next block's conv1 (1x1, stride 1)
+ * as /root/reference/stylenet/model.py:33 runs them through resnet152. s2 / t2 null: res is added as it is. Cin / 32 a
+ * power of two; weight image (capnet_conv_f16x3_pack, k = 1), bn and statistics rows as capnet_conv2d_fwd_f16x3.
+ * tail_out has exactly the values capnet_bn_add_relu would have written. */
+int capnet_conv1x1_fwd_tail(const float* y3, const float* s1, const float* t1, const float* res, const float* s2,
+                            const float* t2, float* tail_out, const unsigned* image, int bn, float* y, float* part_sum,
+                            float* part_sq, long M, int Cin, int Cout, capnet_stream_t stream);
+
 /* The stem on the same arithmetic (csrc/conv_stem.hip): 7x7, stride 2, pad 3, 3 -> 64 channels; x is the NCHW image
  * (strides in floats, unit stride along W, W % 4 == 0, 16-B aligned rows), y is NHWC [B][OH][OW][64]. Replaces
  * torchvision resnet152.conv1 as run by /root/reference/stylenet/model.py:14-24,33. Weights: capnet_conv_stem_f16x3_pack

@@ -799,3 +799,40 @@ def test_conv3x3_patch_matches_fp64(dev, B, H, W, Cin, Cout, bn, pre, shared):
         check(L.capnet_conv2d_fwd_f16x3(ptr(xd), H * W * Cin, W * Cin, Cin, ptr(img), bn, ptr(y2), ptr(sd), ptr(hd), int(pre),
                                         None, None, B, H, W, Cin, Cout, 3, 1, 1, None, None, None, 0, current_stream()))
         assert rel_err(y, y2) < 4e-6          # another order of the same fp32 accumulation
+
+
+@pytest.mark.parametrize("M,Cin,Cout,bn,ds", [(12544, 1024, 256, 128, False), (300, 256, 64, 64, True),
+                                              (3136, 2048, 512, 128, False), (1000, 64, 128, 64, True)])
+def test_conv1x1_tail_fusion_matches_its_two_kernels(dev, M, Cin, Cout, bn, ds):
+    """A block's tail + the next block's conv1 in one launch: the tail it writes is bit-for-bit bn_add_relu's, the
+    convolution is fp32-grade against fp64 (ragged tiles, 2 to 64 k-steps per tile, with and without a BatchNorm on
+    the identity branch), and equals the split-f16 1x1 kernel run on that tail to rounding."""
+    g = torch.Generator().manual_seed(M + Cin + Cout)
+    y3 = torch.randn(M, Cin, generator=g) * torch.exp(0.5 * torch.randn(M, Cin, generator=g))
+    res = torch.randn(M, Cin, generator=g)
+    s1, t1 = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g)
+    s2, t2 = (torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g)) if ds else (None, None)
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) * 0.05
+    L = lib()
+    d = lambda t: None if t is None else t.to(dev)
+    y3d, resd, s1d, t1d, s2d, t2d = d(y3), d(res), d(s1), d(t1), d(s2), d(t2)
+    want_tail = torch.empty(M, Cin, device=dev)
+    check(L.capnet_bn_add_relu(ptr(y3d), ptr(s1d), ptr(t1d), ptr(resd), ptr(s2d), ptr(t2d), ptr(want_tail), M, Cin,
+                               current_stream()))
+    img = ops.pack_conv_weight_f16x3(w.to(dev), bn)
+    tiles = L.capnet_conv1x1_tiles_m(M)
+    tail = torch.full((M, Cin), float("nan"), device=dev)
+    y = torch.full((M, Cout), float("nan"), device=dev)
+    psum = torch.full((tiles, Cout), float("nan"), device=dev)
+    psq = torch.full((tiles, Cout), float("nan"), device=dev)
+    check(L.capnet_conv1x1_fwd_tail(ptr(y3d), ptr(s1d), ptr(t1d), ptr(resd), ptr(s2d), ptr(t2d), ptr(tail), ptr(img), bn,
+                                    ptr(y), ptr(psum), ptr(psq), M, Cin, Cout, current_stream()))
+    assert torch.equal(tail, want_tail)
+    ref = want_tail.double().cpu() @ w.reshape(Cout, Cin).double().t()
+    assert rel_err(y, ref) < 3e-6
+    assert rel_err(psum.sum(0), ref.sum(0)) < 1e-5
+    assert rel_err(psq.sum(0), (ref ** 2).sum(0)) < 1e-5
+    y2 = torch.full_like(y, float("nan"))
+    check(L.capnet_conv2d_fwd_f16x3(ptr(want_tail), Cin, Cin, Cin, ptr(img), bn, ptr(y2), None, None, 0, None, None,
+                                    1, M, 1, Cin, Cout, 1, 1, 0, None, None, None, 0, current_stream()))
+    assert rel_err(y, y2) < 4e-6
