@@ -360,8 +360,10 @@ def main():
             per_s = achieved / algo          # TFLOP/s per algorithmic flop of a pass
             roofline = {"bound": "mfma",
                         "kernel": "the trunk's 155 conv launches, all on three v_mfma_f32_32x32x16_f16 products of 2-way "
-                                  "split fp32 operands per multiply (fp32-grade results): conv_f16x3_kernel (the 104 1x1 "
-                                  "convs and the 3 strided 3x3 ones, implicit GEMM over (tap, channel)), "
+                                  "split fp32 operands per multiply (fp32-grade results): conv_f16x3_kernel (55 of the 104 1x1 "
+                                  "convs and the 3 strided 3x3 ones, implicit GEMM over (tap, channel)), conv1x1_tail_kernel "
+                                  "(the 49 conv1 that absorb the previous block's bn_add_relu tail: its three passes over the "
+                                  "block output are inside these launches' time; CAPNET_NO_TAIL_FUSION=1 separates them), "
                                   "conv3x3_patch_kernel (the 47 stride-1 3x3 convs, input patch resident in LDS; "
                                   "CAPNET_NO_P3=1 puts them back on conv_f16x3_kernel) and "
                                   "conv_stem_f16x3_kernel (K = 147 issued as 176) for the 7x7 stem; "

@@ -323,10 +323,7 @@ int conv_bn(const Ctx& c, int i, const float* x, long sxb, long sxh, long sxw, l
             const float* in_scale, const float* in_shift, int relu_in, float* y, const BlockTail* tail = nullptr) {
   const TrunkConv& d = c.t->convs[i];
   const long M = (long)c.t->B * d.OH * d.OW;
-  static const int tail_cmin = [] { const char* e = getenv("CAPNET_TAIL_CMIN"); return e ? atoi(e) : 0; }();
-  static const int tail_cmax = [] { const char* e = getenv("CAPNET_TAIL_CMAX"); return e ? atoi(e) : 1 << 30; }();
   const bool fuse_tail = tail && c.train && use_tail_fusion() && d.h3 && d.k == 1 && d.stride == 1 && !in_scale &&
-                         d.Cin >= tail_cmin && d.Cin <= tail_cmax &&
                          x == tail->out && tail->C == d.Cin && tail->rows == M && sxc == 1 && sxw == d.Cin &&
                          sxh == (long)d.W * d.Cin && sxb == (long)d.H * d.W * d.Cin &&
                          conv1x1_tail_eligible(tail->y3, tail->res, M, d.Cin, d.Cout);

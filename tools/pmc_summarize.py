@@ -41,7 +41,7 @@ def main():
         for k, v in sorted(fetch.items(), key=lambda kv: -(2 * kv[1][1] + write.get(kv[0], [0, 0])[1]))[:14]:
             print("%s,%d,%.0f,%.0f" % (k.replace(",", ";"), v[0], v[1], write.get(k, [0, 0])[1]))
         return
-    convk = ("conv_f32", "conv_wino", "conv1x1_bf16x6", "conv_f16x3_kernel", "conv3x3_patch_kernel", "conv_stem_f16x3_kernel")
+    convk = ("conv_f32", "conv_wino", "conv1x1_bf16x6", "conv_f16x3_kernel", "conv3x3_patch_kernel", "conv_stem_f16x3_kernel", "conv1x1_tail_kernel")
     conv = lambda n: any(k in n for k in convk) or "conv_tail_fixup" in n
     launches = sum(v[0] for k, v in fetch.items() if any(c in k for c in convk))   # fix-ups belong to a conv
     wino = lambda n: "conv_wino" in n
@@ -57,6 +57,9 @@ def main():
     p3 = lambda n: "conv3x3_patch_kernel" in n
     p3_n = sum(v[0] for k, v in fetch.items() if p3(k))
     p3_bytes = (2.0 * sum(v[1] for k, v in fetch.items() if p3(k)) + sum(v[1] for k, v in write.items() if p3(k))) * 1024.0
+    tl = lambda n: "conv1x1_tail_kernel" in n
+    tl_n = sum(v[0] for k, v in fetch.items() if tl(k))
+    tl_bytes = (2.0 * sum(v[1] for k, v in fetch.items() if tl(k)) + sum(v[1] for k, v in write.items() if tl(k))) * 1024.0
     st = lambda n: "conv_stem_f16x3_kernel" in n
     st_n = sum(v[0] for k, v in fetch.items() if st(k))
     st_bytes = (2.0 * sum(v[1] for k, v in fetch.items() if st(k)) + sum(v[1] for k, v in write.items() if st(k))) * 1024.0
@@ -77,12 +80,17 @@ def main():
         "write_size_kb": write_kb,
         "conv_bytes_per_launch": round((2.0 * fetch_kb + write_kb) * 1024.0 / max(launches, 1)),
         "algorithmic_bytes_per_launch": round((232e6 + 2 * 90e6 * 64) / 155),
+        # with the 49 fused block tails: + 3 passes over each block output (3 365 MB per pass of the trunk at B = 64:
+        # read y3, read the identity, write the block output) - the conv1 read of that output the fusion removes
+        "algorithmic_bytes_per_launch_with_tails": round((232e6 + 2 * 90e6 * 64 + 3 * 3288e6 - 3288e6) / 155),
         "winograd_launches": wino_n,
         "winograd_bytes_per_launch": round(wino_bytes / max(wino_n, 1)),
         "f16x3_launches": h3_n,
         "f16x3_bytes_per_launch": round(h3_bytes / max(h3_n, 1)),
         "patch3x3_launches": p3_n,
         "patch3x3_bytes_per_launch": round(p3_bytes / max(p3_n, 1)),
+        "tail_conv1_launches": tl_n,
+        "tail_conv1_bytes_per_launch": round(tl_bytes / max(tl_n, 1)),
         "stem_launches": st_n,
         "stem_bytes_per_launch": round(st_bytes / max(st_n, 1)),
         "bf16x6_launches": x6_n,
@@ -92,7 +100,8 @@ def main():
         "lstm_step_launches": ls_n,
         "lstm_step_bytes_per_launch": round(ls_bytes / max(ls_n, 1)),
         "note": "FETCH_SIZE doubled (gfx950 tallies 128-B read requests at 64 B); per conv launch incl. "
-                "its tail fix-up; algorithmic = (232 MB weights + 2 x 90 MB x 64 activations) / 155 convs",
+                "its tail fix-up; algorithmic = (232 MB weights + 2 x 90 MB x 64 activations) / 155 convs; the 49 "
+                "conv1 launches that absorb a block's tail also carry its traffic (identity read, block output written)",
     }
     print(json.dumps(out, indent=1))
 
