@@ -287,6 +287,7 @@ struct Ctx {
   float momentum, eps;
   float* ws;
   hipStream_t s;
+  bool eval_ready = false;   // inference: every BatchNorm's (scale, shift) already sits in the workspace (bn_eval_multi)
   float* scale(int i) const { return ws + t->ss_off[i]; }
   float* shift(int i) const { return ws + t->ss_off[i] + t->convs[i].Cout; }
   float* bmean(int i) const { return ws + t->bs_off[i]; }
@@ -323,7 +324,7 @@ int conv_bn(const Ctx& c, int i, const float* x, long sxb, long sxh, long sxw, l
             const float* in_scale, const float* in_shift, int relu_in, float* y, const BlockTail* tail = nullptr) {
   const TrunkConv& d = c.t->convs[i];
   const long M = (long)c.t->B * d.OH * d.OW;
-  const bool fuse_tail = tail && c.train && use_tail_fusion() && d.h3 && d.k == 1 && d.stride == 1 && !in_scale &&
+  const bool fuse_tail = tail && (c.train || c.eval_ready) && use_tail_fusion() && d.h3 && d.k == 1 && d.stride == 1 && !in_scale &&
                          x == tail->out && tail->C == d.Cin && tail->rows == M && sxc == 1 && sxw == d.Cin &&
                          sxh == (long)d.W * d.Cin && sxb == (long)d.H * d.W * d.Cin &&
                          conv1x1_tail_eligible(tail->y3, tail->res, M, d.Cin, d.Cout);
@@ -410,6 +411,7 @@ int conv_bn(const Ctx& c, int i, const float* x, long sxb, long sxh, long sxw, l
   if (c.train)
     return bn_finalize(psum, psq, prows, d.Cout, M, c.gamma[i], c.beta[i],
                        c.rmean[i], c.rvar[i], c.momentum, c.eps, c.scale(i), c.shift(i), c.s);
+  if (c.eval_ready) return kOk;
   return bn_eval_scale_shift(c.gamma[i], c.beta[i], c.rmean[i], c.rvar[i], c.eps, d.Cout,
                              c.scale(i), c.shift(i), c.s);
 }
@@ -569,7 +571,25 @@ int trunk_forward(Trunk* t, const float* images_nchw, const float* const* w_pack
   float* D = workspace + t->off_d;
   int rc;
   int ci = 0;
-  if (!train) return trunk_forward_eval(c, images_nchw, out_pooled, out_map);
+  // Inference. CAPNET_EVAL_FOLDED=1: the convolutions' epilogues apply the BatchNorms (+ residual + ReLU): the least
+  // traffic, but that epilogue of the split-f16 kernel is slow (12.3 ms per pass at B = 64). Default: the training
+  // pass's kernels with every (scale, shift) computed up front from the running statistics -- no statistics, no
+  // finalize launches, BatchNorm + ReLU folded into the consumers' staging and the tails into the next conv1.
+  if (!train) {
+    const char* fe = getenv("CAPNET_EVAL_FOLDED");      // (read per call: the tests run both paths in one process)
+    if (fe && fe[0] == '1') return trunk_forward_eval(c, images_nchw, out_pooled, out_map);
+    const int n = (int)t->convs.size();
+    std::vector<const float*> g(n), b(n), rm(n), rv(n);
+    std::vector<float*> sc(n), sh(n);
+    std::vector<int> Cs(n);
+    for (int i = 0; i < n; ++i) {
+      g[i] = c.gamma[i]; b[i] = c.beta[i]; rm[i] = c.rmean[i]; rv[i] = c.rvar[i];
+      sc[i] = c.scale(i); sh[i] = c.shift(i); Cs[i] = t->convs[i].Cout;
+    }
+    rc = bn_eval_multi(n, g.data(), b.data(), rm.data(), rv.data(), Cs.data(), sc.data(), sh.data(), c.eps, c.s);
+    if (rc) return rc;
+    c.eval_ready = true;
+  }
   // stem: NCHW image read through the generic gather loader
   {
     const TrunkConv& d = t->convs[0];

@@ -124,10 +124,13 @@ def test_image_shape_errors(dev):
         enc(torch.zeros(2, 1, 224, 224, device=dev))
 
 
-def test_folded_bn_inference_trunk_matches_oracle_with_given_statistics(dev):
-    """encoder.eval(): 155 convs with the BatchNorm folded into their epilogues. Same seeded running
-    statistics on both sides (no batch statistics involved), so the comparison with the fp32 CPU
-    oracle is tight."""
+@pytest.mark.parametrize("folded", ["0", "1"])
+def test_folded_bn_inference_trunk_matches_oracle_with_given_statistics(dev, monkeypatch, folded):
+    """encoder.eval(). folded = 0 (default): the training pass's kernels with every BatchNorm's (scale, shift) computed up
+    front from the running statistics -- BatchNorm + ReLU folded into the consumers' staging, the block tails into the
+    next conv1; 1 (CAPNET_EVAL_FOLDED=1): the BatchNorms applied in the convolutions' epilogues. Same seeded running
+    statistics on both sides (no batch statistics involved), so the comparison with the fp32 CPU oracle is tight."""
+    monkeypatch.setenv("CAPNET_EVAL_FOLDED", folded)
     from oracle.resnet152_ref import EncoderCNNRef
     B = 2
     enc = EncoderCNN(300)
