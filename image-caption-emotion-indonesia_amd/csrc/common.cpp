@@ -13,4 +13,9 @@ void set_error(const char* fmt, ...) {
 
 const char* last_error() { return g_err; }
 
+LaunchEvents& launch_events() {
+  static thread_local LaunchEvents le;
+  return le;
+}
+
 }  // namespace capnet

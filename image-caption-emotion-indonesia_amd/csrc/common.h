@@ -1,6 +1,7 @@
 // Shared host/device helpers for libcapnet_hip (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <cstdio>
 #include <cstdarg>
 #include <cstring>
@@ -36,6 +37,24 @@ const char* last_error();
       capnet::set_error(__VA_ARGS__);                                            \
       return capnet::kErrInvalidArg;                                             \
     }                                                                            \
+  } while (0)
+
+// Timing events attached to ONE kernel dispatch (hipExtLaunchKernelGGL: the dispatch packet's own start / end
+// timestamps -- no marker packets in the queue, one host call instead of three). The caller (csrc/trunk.cpp) parks a pair
+// here; the next CAPNET_LAUNCH_TIMED on this thread takes it. Without a parked pair the macro is a plain launch.
+struct LaunchEvents {
+  hipEvent_t start = nullptr, stop = nullptr;
+};
+LaunchEvents& launch_events();     // thread-local
+#define CAPNET_LAUNCH_TIMED(kernel, grid, block, stream, ...)                                              \
+  do {                                                                                                      \
+    capnet::LaunchEvents& _le = capnet::launch_events();                                                    \
+    if (_le.start) {                                                                                        \
+      hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, _le.start, _le.stop, 0, __VA_ARGS__);           \
+      _le.start = _le.stop = nullptr;                                                                       \
+    } else {                                                                                                \
+      hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__);                                      \
+    }                                                                                                       \
   } while (0)
 
 #define CAPNET_LAUNCH_CHECK()                                                    \

@@ -479,11 +479,11 @@ int conv3x3_fwd_patch(const float* x, const unsigned* wimg, int bn, float* y, co
   const int ks_max = ks_env >= 0 ? ks_env : (shared_chip ? 0 : 256);
   const bool ksplit = total <= ks_max;
   if (bn == 128) {
-    if (ksplit) hipLaunchKernelGGL((conv3x3_patch_kernel<128, true>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((conv3x3_patch_kernel<128, false>), grid, block, 0, stream, a);
+    if (ksplit) CAPNET_LAUNCH_TIMED((conv3x3_patch_kernel<128, true>), grid, block, stream, a);
+    else CAPNET_LAUNCH_TIMED((conv3x3_patch_kernel<128, false>), grid, block, stream, a);
   } else {
-    if (ksplit) hipLaunchKernelGGL((conv3x3_patch_kernel<64, true>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((conv3x3_patch_kernel<64, false>), grid, block, 0, stream, a);
+    if (ksplit) CAPNET_LAUNCH_TIMED((conv3x3_patch_kernel<64, true>), grid, block, stream, a);
+    else CAPNET_LAUNCH_TIMED((conv3x3_patch_kernel<64, false>), grid, block, stream, a);
   }
   CAPNET_LAUNCH_CHECK();
   return kOk;
@@ -519,8 +519,8 @@ int conv1x1_fwd_tail(const float* y3, const float* s1, const float* t1, const fl
   const int cap = ge ? atoi(ge) : 512;
   const int total = a.tiles_m * a.tiles_n;
   const dim3 grid(total <= cap ? total : cap), block(kThreads);
-  if (bn == 128) hipLaunchKernelGGL((conv1x1_tail_kernel<128>), grid, block, 0, stream, a);
-  else hipLaunchKernelGGL((conv1x1_tail_kernel<64>), grid, block, 0, stream, a);
+  if (bn == 128) CAPNET_LAUNCH_TIMED((conv1x1_tail_kernel<128>), grid, block, stream, a);
+  else CAPNET_LAUNCH_TIMED((conv1x1_tail_kernel<64>), grid, block, stream, a);
   CAPNET_LAUNCH_CHECK();
   return kOk;
 }

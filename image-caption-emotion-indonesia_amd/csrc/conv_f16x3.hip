@@ -640,7 +640,7 @@ int conv_fwd_f16x3(const float* x, long sxb, long sxh, long sxw, const unsigned*
   const int cap = ge ? atoi(ge) : 512;
   const int total = a.tiles_m * a.tiles_n;
   const dim3 grid(total <= cap ? total : cap), block(256);
-#define CAPNET_H3_LAUNCH(BN_, PRE_, TAPS_) hipLaunchKernelGGL((conv_f16x3_kernel<BN_, PRE_, TAPS_>), grid, block, 0, stream, a)
+#define CAPNET_H3_LAUNCH(BN_, PRE_, TAPS_) CAPNET_LAUNCH_TIMED((conv_f16x3_kernel<BN_, PRE_, TAPS_>), grid, block, stream, a)
   if (k == 1) {
     if (bn == 128) { if (in_scale) CAPNET_H3_LAUNCH(128, true, 1); else CAPNET_H3_LAUNCH(128, false, 1); }
     else { if (in_scale) CAPNET_H3_LAUNCH(64, true, 1); else CAPNET_H3_LAUNCH(64, false, 1); }

@@ -274,7 +274,7 @@ int conv_stem_fwd_f16x3(const float* x, long sxb, long sxc, long sxh, const unsi
   magic_div((unsigned)a.chunks, &a.tile_mul, &a.tile_sh);
   magic_div((unsigned)a.OH, &a.oh_mul, &a.oh_sh);
   const int grid = a.tiles < kWgs ? a.tiles : kWgs;
-  hipLaunchKernelGGL(conv_stem_f16x3_kernel, dim3(grid), dim3(256), 0, stream, a);
+  CAPNET_LAUNCH_TIMED(conv_stem_f16x3_kernel, dim3(grid), dim3(256), stream, a);
   CAPNET_LAUNCH_CHECK();
   return kOk;
 }

@@ -57,6 +57,8 @@ struct Trunk {
   int timing_every = 1;   // ... on every N-th pass (an event pair is a bubble in the stream: 310 per pass cost 2.5 % images/s)
   long pass_no = 0;
   bool timing_now = false;
+  std::vector<hipEvent_t> ev_pool;    // events are created once and handed out again after every collect
+  size_t ev_next = 0;
   std::vector<hipEvent_t> ev;
   double timed_flops = 0;
 };
@@ -187,7 +189,7 @@ int trunk_create(int B, int H, int W, Trunk** out) {
 
 void trunk_destroy(Trunk* t) {
   if (!t) return;
-  for (hipEvent_t e : t->ev) (void)hipEventDestroy(e);
+  for (hipEvent_t e : t->ev_pool) (void)hipEventDestroy(e);
   delete t;
 }
 
@@ -236,8 +238,8 @@ int trunk_collect_timing(Trunk* t, double* conv_ms, long* conv_launches, double*
   *conv_ms = ms;
   *conv_launches = (long)(t->ev.size() / 2);
   *conv_flops = t->timed_flops;
-  for (hipEvent_t e : t->ev) (void)hipEventDestroy(e);
-  t->ev.clear();
+  t->ev.clear();          // (the events stay in the pool)
+  t->ev_next = 0;
   t->timed_flops = 0;
   return kOk;
 }
@@ -276,6 +278,46 @@ double trunk_flops(const Trunk* t) {
 }
 
 namespace {
+// A pair of timing events for one conv launch. Kernels launched through CAPNET_LAUNCH_TIMED (the split-f16 family) get
+// them attached to their dispatch (park = true: no hipEventRecord at all); the others are bracketed by two records.
+// CAPNET_EVENTS_LEGACY=1: bracket everything (A/B).
+static int take_events(Trunk* t, hipEvent_t* e0, hipEvent_t* e1) {
+  while (t->ev_pool.size() < t->ev_next + 2) {
+    hipEvent_t e;
+    CAPNET_HIP_CHECK(hipEventCreate(&e));
+    t->ev_pool.push_back(e);
+  }
+  *e0 = t->ev_pool[t->ev_next++];
+  *e1 = t->ev_pool[t->ev_next++];
+  return kOk;
+}
+static bool events_legacy() {
+  static const bool on = [] { const char* e = getenv("CAPNET_EVENTS_LEGACY"); return e && e[0] == '1'; }();
+  return on;
+}
+static int timing_begin(Trunk* t, bool attach, hipStream_t s, hipEvent_t* e0, hipEvent_t* e1) {
+  const int rc = take_events(t, e0, e1);
+  if (rc) return rc;
+  if (attach && !events_legacy()) {
+    launch_events().start = *e0;
+    launch_events().stop = *e1;
+  } else {
+    CAPNET_HIP_CHECK(hipEventRecord(*e0, s));
+  }
+  return kOk;
+}
+static int timing_end(Trunk* t, bool attach, hipStream_t s, hipEvent_t e0, hipEvent_t e1, double flops) {
+  if (attach && !events_legacy()) {
+    CAPNET_REQUIRE(launch_events().start == nullptr, "trunk: a conv launcher did not take its timing events");
+  } else {
+    CAPNET_HIP_CHECK(hipEventRecord(e1, s));
+  }
+  t->ev.push_back(e0);
+  t->ev.push_back(e1);
+  t->timed_flops += flops;
+  return kOk;
+}
+
 struct Ctx {
   Trunk* t;
   const float* const* w;
@@ -343,10 +385,10 @@ int conv_bn(const Ctx& c, int i, const float* x, long sxb, long sxh, long sxw, l
   float* psum = c.ws + c.t->off_part;
   float* psq = psum + (size_t)prows * d.Cout;
   hipEvent_t e0 = nullptr, e1 = nullptr;
+  const bool attach = fuse_tail || d.stem_h3 || d.h3;      // one kernel, launched through CAPNET_LAUNCH_TIMED
   if (c.t->timing_now) {
-    CAPNET_HIP_CHECK(hipEventCreate(&e0));
-    CAPNET_HIP_CHECK(hipEventCreate(&e1));
-    CAPNET_HIP_CHECK(hipEventRecord(e0, c.s));
+    const int rt = timing_begin(c.t, attach, c.s, &e0, &e1);
+    if (rt) return rt;
   }
   int rc;
   if (fuse_tail) {
@@ -398,10 +440,11 @@ int conv_bn(const Ctx& c, int i, const float* x, long sxb, long sxh, long sxw, l
                     d.Cout, d.k, d.k, d.stride, d.pad, tile, c.s);
   }
   if (c.t->timing_now) {
-    CAPNET_HIP_CHECK(hipEventRecord(e1, c.s));
-    c.t->ev.push_back(e0);
-    c.t->ev.push_back(e1);
-    c.t->timed_flops += 2.0 * (double)M * d.Cout * d.k * d.k * d.Cin;
+    if (rc) launch_events() = LaunchEvents{};
+    else {
+      const int rt = timing_end(c.t, attach, c.s, e0, e1, 2.0 * (double)M * d.Cout * d.k * d.k * d.Cin);
+      if (rt) return rt;
+    }
   }
   if (rc) return rc;
   if (c.train == 2)   // running statistics deferred to trunk_update_running
@@ -423,10 +466,10 @@ int conv_folded(const Ctx& c, int i, const float* x, const float* res, int relu,
   CAPNET_REQUIRE(d.h3 || d.x6 || d.dma1x1 || (d.kmajor && conv_v2_eligible(x, sb, sh, sw, 1, c.t->B, d.Cin, d.Cout, nullptr, nullptr)),
                  "trunk: conv %d is not eligible for the folded-BN kernel", i);
   hipEvent_t e0 = nullptr, e1 = nullptr;
+  const bool attach = d.h3;
   if (c.t->timing_now) {
-    CAPNET_HIP_CHECK(hipEventCreate(&e0));
-    CAPNET_HIP_CHECK(hipEventCreate(&e1));
-    CAPNET_HIP_CHECK(hipEventRecord(e0, c.s));
+    const int rt = timing_begin(c.t, attach, c.s, &e0, &e1);
+    if (rt) return rt;
   }
   int rc;
   if (d.h3) {
@@ -451,10 +494,11 @@ int conv_folded(const Ctx& c, int i, const float* x, const float* res, int relu,
                        c.shift(i), res, relu);
   }
   if (c.t->timing_now) {
-    CAPNET_HIP_CHECK(hipEventRecord(e1, c.s));
-    c.t->ev.push_back(e0);
-    c.t->ev.push_back(e1);
-    c.t->timed_flops += 2.0 * (double)M * d.Cout * d.k * d.k * d.Cin;
+    if (rc) launch_events() = LaunchEvents{};
+    else {
+      const int rt = timing_end(c.t, attach, c.s, e0, e1, 2.0 * (double)M * d.Cout * d.k * d.k * d.Cin);
+      if (rt) return rt;
+    }
   }
   return rc;
 }
