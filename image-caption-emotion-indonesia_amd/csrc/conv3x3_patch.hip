@@ -6,13 +6,16 @@
 // that patch at nine offsets; positions in the zero padding are masked per lane and tap. Per k-step only the packed
 // weights (the same image as conv_f16x3.hip's, 16 KB, copied verbatim) still go through registers.
 // Eight waves per workgroup, in two arrangements:
-//  * KSPLIT (launches of at most one tile per CU: the 14 x 14 and 7 x 7 maps): such a layer runs ONE workgroup per CU, and
-//    with four waves every SIMD sits idle through each LDS round trip and barrier of its only wave. The eight waves are
-//    four PAIRS on the 2 x 2 grid of 64 x (BN / 2) blocks; the two waves of a pair split K -- each takes one of the
-//    step's two k16 groups -- so the workgroup reads no more LDS than four waves would (the LDS port is as busy as the
-//    matrix pipe here). The halves meet once per tile, through LDS, each wave finishing one of the pair's 32-row blocks.
-//  * otherwise (56 x 56, 28 x 28: several tiles per CU): 4 x 2 waves of 32 rows x BN / 2 columns at <= 128 VGPRs, so that
-//    two workgroups share a CU.
+//  * 4 x 2 waves of 32 rows x BN / 2 columns at <= 128 VGPRs -- the one used whenever other kernels share the chip
+//    (several trunk passes in flight, shared_chip): two such workgroups, or one and a 250-VGPR workgroup of
+//    conv_f16x3.hip, fit a CU. It is the slower one ALONE and the faster one in the pipelined step.
+//  * KSPLIT (a pass that has the chip to itself, launches of at most one tile per CU: the 14 x 14 and 7 x 7 maps): a lone
+//    workgroup per CU whose eight waves are four PAIRS on the 2 x 2 grid of 64 x (BN / 2) blocks; the two waves of a pair
+//    split K -- each takes one of the step's two k16 groups -- so the workgroup reads no more LDS than four waves would
+//    (the LDS port is as busy as the matrix pipe here). The halves meet once per tile, through LDS, each wave finishing
+//    one of the pair's 32-row blocks. 185 VGPRs: beside other kernels it keeps their workgroups off the CU.
+// conv1x1_tail_kernel (below): a bottleneck block's tail relu(bn3(y3) + identity) as the staging step of the next
+// block's stride-1 1x1 conv1, same wave arrangement and barrier discipline.
 #include <cstdlib>
 
 #include "common.h"
