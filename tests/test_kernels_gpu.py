@@ -1,6 +1,7 @@
 """GPU parity of the individual HIP kernels against plain torch CPU references (fp64 where the
 op is a contraction). Everything goes through the C ABI (capnet._lib / capnet.ops)."""
 import ctypes as C
+import random
 
 import pytest
 import torch
@@ -836,3 +837,74 @@ def test_conv1x1_tail_fusion_matches_its_two_kernels(dev, M, Cin, Cout, bn, ds):
     check(L.capnet_conv2d_fwd_f16x3(ptr(want_tail), Cin, Cin, Cin, ptr(img), bn, ptr(y2), None, None, 0, None, None,
                                     1, M, 1, Cin, Cout, 1, 1, 0, None, None, None, 0, current_stream()))
     assert rel_err(y, y2) < 4e-6
+
+
+def test_conv3x3_patch_random_shape_sweep(dev):
+    """24 seeded random shapes (maps 3..56 wide, 1..4 images, channel counts off the trunk's grid, both wave arrangements)
+    against fp64: the patch kernel's masks, image boundaries inside a tile and ragged tiles."""
+    rng = random.Random(20261004)
+    L = lib()
+    worst = 0.0
+    for case in range(24):
+        B, H, W = rng.randint(1, 4), rng.randint(3, 56), rng.randint(3, 56)
+        Cin, Cout = rng.choice([32, 64, 96, 128]), rng.choice([64, 128, 192, 256])
+        pre, shared = rng.random() < 0.7, rng.randint(0, 1)
+        bn = 128 if Cout % 128 == 0 else 64
+        g = torch.Generator().manual_seed(1000 + case)
+        x = torch.randn(B, Cin, H, W, generator=g)
+        w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05
+        scale = torch.rand(Cin, generator=g) - 0.3 if pre else None
+        shift = torch.randn(Cin, generator=g) if pre else None
+        xin = torch.relu(x * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)).double() if pre else x.double()
+        M = B * H * W
+        ref = torch.nn.functional.conv2d(xin, w.double(), padding=1).permute(0, 2, 3, 1).reshape(M, Cout)
+        xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+        img = ops.pack_conv_weight_f16x3(w.to(dev), bn)
+        y = torch.full((M, Cout), float("nan"), device=dev)
+        tiles = L.capnet_conv1x1_tiles_m(M)
+        psum = torch.full((tiles, Cout), float("nan"), device=dev)
+        psq = torch.full((tiles, Cout), float("nan"), device=dev)
+        sd, hd = (scale.to(dev), shift.to(dev)) if pre else (None, None)
+        check(L.capnet_conv3x3_fwd_patch(ptr(xd), ptr(img), bn, ptr(y), ptr(sd), ptr(hd), int(pre), ptr(psum), ptr(psq),
+                                         B, H, W, Cin, Cout, shared, current_stream()))
+        e = rel_err(y, ref)
+        worst = max(worst, e)
+        assert e < 3e-6, (case, B, H, W, Cin, Cout, pre, shared, e)
+        assert rel_err(psum.sum(0), ref.sum(0)) < 1e-5, (case, "sum")
+        assert rel_err(psq.sum(0), (ref ** 2).sum(0)) < 1e-5, (case, "sq")
+    print("patch kernel sweep: worst max-norm error %.2e" % worst)
+
+
+def test_conv1x1_tail_random_shape_sweep(dev):
+    """20 seeded random shapes of the fused tail + conv1 (1..5000 rows, 1 to 16 k-steps per tile, with and without a
+    BatchNorm on the identity): the tail bit-for-bit bn_add_relu's, the product against fp64."""
+    rng = random.Random(4102026)
+    L = lib()
+    for case in range(20):
+        M = rng.choice([1, 7, 127, 128, 129, 300, 1000, 2049, 5000])
+        Cin, Cout = rng.choice([32, 64, 128, 256, 512]), rng.choice([64, 128, 192, 256])
+        ds = rng.random() < 0.4
+        bn = 128 if Cout % 128 == 0 else 64
+        g = torch.Generator().manual_seed(2000 + case)
+        y3, res = torch.randn(M, Cin, generator=g), torch.randn(M, Cin, generator=g)
+        s1, t1 = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g)
+        s2, t2 = (torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g)) if ds else (None, None)
+        w = torch.randn(Cout, Cin, 1, 1, generator=g) * 0.05
+        d = lambda t: None if t is None else t.to(dev)
+        y3d, resd, s1d, t1d, s2d, t2d = d(y3), d(res), d(s1), d(t1), d(s2), d(t2)
+        want = torch.empty(M, Cin, device=dev)
+        check(L.capnet_bn_add_relu(ptr(y3d), ptr(s1d), ptr(t1d), ptr(resd), ptr(s2d), ptr(t2d), ptr(want), M, Cin,
+                                   current_stream()))
+        img = ops.pack_conv_weight_f16x3(w.to(dev), bn)
+        tiles = L.capnet_conv1x1_tiles_m(M)
+        tail = torch.full((M, Cin), float("nan"), device=dev)
+        y = torch.full((M, Cout), float("nan"), device=dev)
+        psum = torch.full((tiles, Cout), float("nan"), device=dev)
+        psq = torch.full((tiles, Cout), float("nan"), device=dev)
+        check(L.capnet_conv1x1_fwd_tail(ptr(y3d), ptr(s1d), ptr(t1d), ptr(resd), ptr(s2d), ptr(t2d), ptr(tail), ptr(img),
+                                        bn, ptr(y), ptr(psum), ptr(psq), M, Cin, Cout, current_stream()))
+        assert torch.equal(tail, want), (case, M, Cin, Cout, ds)
+        ref = want.double().cpu() @ w.reshape(Cout, Cin).double().t()
+        assert rel_err(y, ref) < 3e-6, (case, M, Cin, Cout, ds)
+        assert rel_err(psum.sum(0), ref.sum(0)) < 1e-5, (case, "sum")
+        assert rel_err(psq.sum(0), (ref ** 2).sum(0)) < 1e-5, (case, "sq")
