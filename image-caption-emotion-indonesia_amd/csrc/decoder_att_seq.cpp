@@ -96,11 +96,6 @@ int check(const AttDims& d, const int* bs) {
 
 struct GateOrderA { int gi, gf, go, gg, tanh_out; };  // column block of each gate role
 
-int cpy(float* dst, const float* src, size_t n, hipStream_t s) {
-  CAPNET_HIP_CHECK(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, s));
-  return kOk;
-}
-
 }  // namespace
 
 size_t att_saved_floats(const AttDims& d) { return make_alayout(d).total; }
@@ -143,25 +138,29 @@ int att_seq_forward(const AttDims& d, const int* bs, const unsigned char* tf,
   // ---- pack weights
   const bool fac = d.cell == kCellFactored;
   const GateOrderA go = fac ? GateOrderA{0, 1, 2, 3, 0} : GateOrderA{0, 1, 3, 2, 1};
-  if (fac) {
-    for (int g = 0; g < 4; ++g) {
-      RC(cpy(sv + L.Vcat + (size_t)g * F * XW, w.Vw[g], (size_t)F * XW, s));
-      RC(cpy(sv + L.Scat + (size_t)g * F * F, w.Sw[g], (size_t)F * F, s));
-      RC(cpy(sv + L.Ucat + (size_t)g * H * F, w.Uw[g], (size_t)H * F, s));
-      RC(cpy(sv + L.Wz + (size_t)g * H * H, w.Ww[g], (size_t)H * H, s));
-      RC(cpy(sv + L.bV + (size_t)g * F, w.Vb[g], F, s));
-      RC(cpy(sv + L.bS + (size_t)g * F, w.Sb[g], F, s));
-      RC(vec_add(w.Ub[g], w.Wb[g], sv + L.bz + (size_t)g * H, H, s));
+  {
+    CopyTable ct;      // one launch for the whole packing
+    if (fac) {
+      for (int g = 0; g < 4; ++g) {
+        ct.add(sv + L.Vcat + (size_t)g * F * XW, w.Vw[g], (size_t)F * XW);
+        ct.add(sv + L.Scat + (size_t)g * F * F, w.Sw[g], (size_t)F * F);
+        ct.add(sv + L.Ucat + (size_t)g * H * F, w.Uw[g], (size_t)H * F);
+        ct.add(sv + L.Wz + (size_t)g * H * H, w.Ww[g], (size_t)H * H);
+        ct.add(sv + L.bV + (size_t)g * F, w.Vb[g], F);
+        ct.add(sv + L.bS + (size_t)g * F, w.Sb[g], F);
+        ct.add(sv + L.bz + (size_t)g * H, w.Ub[g], H, w.Wb[g]);
+      }
+    } else {
+      ct.add(sv + L.Vcat, w.Vw[0], (size_t)4 * H * XW);          // weight_ih
+      ct.add(sv + L.Wz, w.Ww[0], (size_t)4 * H * H);             // weight_hh
+      ct.add(sv + L.bz, w.Vb[0], 4 * H, w.Wb[0]);                // bias_ih + bias_hh
     }
-  } else {
-    RC(cpy(sv + L.Vcat, w.Vw[0], (size_t)4 * H * XW, s));          // weight_ih
-    RC(cpy(sv + L.Wz, w.Ww[0], (size_t)4 * H * H, s));             // weight_hh
-    RC(vec_add(w.Vb[0], w.Wb[0], sv + L.bz, 4 * H, s));            // bias_ih + bias_hh
+    ct.add(sv + L.Wz + (size_t)4 * H * H, w.dec_att_w, (size_t)A * H);
+    ct.add(sv + L.Wz + (size_t)(4 * H + A) * H, w.f_beta_w, (size_t)C * H);
+    ct.add(sv + L.bz + 4 * H, w.dec_att_b, A);
+    ct.add(sv + L.bz + 4 * H + A, w.f_beta_b, C);
+    RC(multi_copy(ct, s));
   }
-  RC(cpy(sv + L.Wz + (size_t)4 * H * H, w.dec_att_w, (size_t)A * H, s));
-  RC(cpy(sv + L.Wz + (size_t)(4 * H + A) * H, w.f_beta_w, (size_t)C * H, s));
-  RC(cpy(sv + L.bz + 4 * H, w.dec_att_b, A, s));
-  RC(cpy(sv + L.bz + 4 * H + A, w.f_beta_b, C, s));
 
   // ---- time-invariant parts
   RC(global_avgpool(feat, sv + L.mean, d.B, P, C, s));

@@ -186,6 +186,20 @@ int embedding_fwd(const long long* idx, int n, const float* emb, int E, int V, f
 int packed_targets(const SeqMeta& m, const long long* captions, int T, long long* out,
                    hipStream_t stream);
 int vec_add(const float* a, const float* b, float* out, int n, hipStream_t stream);
+// dst[i] = src[i] (+ src2[i] where given), up to 40 items in one launch
+struct CopyTable {
+  static constexpr int kMax = 40;
+  const float* src[kMax];
+  const float* src2[kMax];
+  float* dst[kMax];
+  size_t n[kMax];
+  int count = 0;
+  void add(float* d, const float* a, size_t len, const float* b = nullptr) {
+    if (count < kMax) { src[count] = a; src2[count] = b; dst[count] = d; n[count] = len; }
+    ++count;      // (an overflow is caught by multi_copy)
+  }
+};
+int multi_copy(const CopyTable& t, hipStream_t stream);
 int lstm_pointwise_fwd(float* pre, long ldp, const float* c_prev, float* c_out, float* h_out, int b,
                        int H, int gi, int gf, int go, int gg, int tanh_out, hipStream_t stream);
 int lstm_pointwise_bwd(const float* gates, long ldg, const float* c, const float* c_prev,

@@ -168,6 +168,45 @@ int vec_add(const float* a, const float* b, float* out, int n, hipStream_t strea
   return kOk;
 }
 
+// ---- many small device-to-device copies / sums in ONE launch --------------------------------
+// dst[i] = src[i] (+ src2[i]): the per-forward weight packing of the attention decoder was 28 hipMemcpyAsync + 4
+// vec_add on the decoder's serial chain.
+__global__ __launch_bounds__(256) void multi_copy_kernel(const CopyTable t) {
+  const int it = blockIdx.y;
+  const float* __restrict__ a = t.src[it];
+  const float* __restrict__ b = t.src2[it];
+  float* __restrict__ d = t.dst[it];
+  const size_t n = t.n[it];
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const bool v4 = (n % 4 == 0) && ((((size_t)a | (size_t)d | (size_t)b) & 15) == 0);
+  if (v4) {
+    const float4* a4 = reinterpret_cast<const float4*>(a);
+    const float4* b4 = reinterpret_cast<const float4*>(b);
+    float4* d4 = reinterpret_cast<float4*>(d);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n / 4; i += stride) {
+      float4 v = a4[i];
+      if (b) { const float4 w = b4[i]; v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w; }
+      d4[i] = v;
+    }
+  } else {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) d[i] = b ? a[i] + b[i] : a[i];
+  }
+}
+
+int multi_copy(const CopyTable& t, hipStream_t stream) {
+  CAPNET_REQUIRE(t.count > 0 && t.count <= CopyTable::kMax, "multi_copy: %d items", t.count);
+  size_t nmax = 0;
+  for (int i = 0; i < t.count; ++i) {
+    CAPNET_REQUIRE(t.src[i] && t.dst[i] && t.n[i] > 0, "multi_copy: item %d", i);
+    nmax = t.n[i] > nmax ? t.n[i] : nmax;
+  }
+  const size_t want = (nmax / 4 + 255) / 256;
+  const int bx = (int)(want < 1 ? 1 : (want > 256 ? 256 : want));
+  hipLaunchKernelGGL(multi_copy_kernel, dim3(bx, t.count), dim3(256), 0, stream, t);
+  CAPNET_LAUNCH_CHECK();
+  return kOk;
+}
+
 // ---- LSTM gate pointwise ---------------------------------------------------------------
 // pre: [b][4H] pre-activations, column block gi/gf/go/gg selects the gate. In place:
 // pre is overwritten with the ACTIVATED gates (saved for backward).
