@@ -3,6 +3,8 @@
 // Semantics follow torch.nn.BatchNorm2d as used by torchvision's resnet152 under
 // encoder.train() (stylenet/train_multitask.py:367, stylenet/model.py:23-24): batch mean and
 // BIASED variance normalise, running_var is updated with the UNBIASED variance, momentum 0.1.
+#include <cstdlib>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -14,6 +16,10 @@ namespace capnet {
 // 16 channels (one 64-B segment) x 64 partial rows per workgroup: C/16 workgroups, and each
 // thread keeps 16 independent loads in flight -- the kernel is pure latency otherwise.
 constexpr int kFinCh = 16, kFinRows = 64;
+// ... and for at most 128 partial rows (the 14 x 14 and 7 x 7 maps: 119 of the trunk's 155 BatchNorms) 16 rows = 256
+// threads: beside the convolutions' eight-wave workgroups a 1 024-thread block waits for a CU with sixteen free wave
+// slots, a 256-thread one for four
+constexpr int kFinRowsSmall = 16, kFinSmallMaxTiles = 128;
 
 // running statistic <- (1 - momentum) running + momentum batch, with ONE rounding pattern wherever it is applied: the
 // update fused into bn_finalize and the deferred bn_running_update_kernel (TrunkPipeline) must agree bit for bit, and
@@ -22,30 +28,31 @@ __device__ __forceinline__ float bn_running_blend(float running, float batch, fl
   return __builtin_fmaf(momentum, batch, (1.f - momentum) * running);
 }
 
-__global__ __launch_bounds__(kFinCh* kFinRows) void bn_finalize_kernel(
+template <int ROWS>
+__global__ __launch_bounds__(kFinCh* ROWS) void bn_finalize_kernel(
     const float* __restrict__ part_sum, const float* __restrict__ part_sq, int tiles, int C,
     double inv_count, double unbias, const float* __restrict__ gamma,
     const float* __restrict__ beta, float* __restrict__ running_mean,
     float* __restrict__ running_var, float momentum, float eps, float* __restrict__ scale,
     float* __restrict__ shift, float* __restrict__ batch_mean, float* __restrict__ batch_var) {
-  __shared__ double s_sum[kFinRows][kFinCh + 1];
-  __shared__ double s_sq[kFinRows][kFinCh + 1];
+  __shared__ double s_sum[ROWS][kFinCh + 1];
+  __shared__ double s_sq[ROWS][kFinCh + 1];
   const int cx = threadIdx.x % kFinCh, ry = threadIdx.x / kFinCh;
   const int c = blockIdx.x * kFinCh + cx;
   double s = 0.0, q = 0.0;
   if (c < C) {
     // batches of 8 independent (clamped, masked) loads per thread: the reduction is pure latency
-    for (int t = ry; t < tiles; t += 8 * kFinRows) {
+    for (int t = ry; t < tiles; t += 8 * ROWS) {
       float a[8], b[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const int tu = min(t + u * kFinRows, tiles - 1);
+        const int tu = min(t + u * ROWS, tiles - 1);
         a[u] = part_sum[(long)tu * C + c];
         b[u] = part_sq[(long)tu * C + c];
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const bool ok = t + u * kFinRows < tiles;
+        const bool ok = t + u * ROWS < tiles;
         s += ok ? (double)a[u] : 0.0;
         q += ok ? (double)b[u] : 0.0;
       }
@@ -56,7 +63,7 @@ __global__ __launch_bounds__(kFinCh* kFinRows) void bn_finalize_kernel(
   __syncthreads();
   if (ry == 0 && c < C) {
 #pragma unroll 8
-    for (int r = 1; r < kFinRows; ++r) {
+    for (int r = 1; r < ROWS; ++r) {
       s += s_sum[r][cx];
       q += s_sq[r][cx];
     }
@@ -89,9 +96,15 @@ int bn_finalize(const float* part_sum, const float* part_sq, int tiles, int C, l
   CAPNET_REQUIRE((batch_mean == nullptr) == (batch_var == nullptr), "bn_finalize: batch stat pair");
   const double inv = 1.0 / (double)count;
   const double unbias = count > 1 ? (double)count / (double)(count - 1) : 1.0;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, kFinCh)), dim3(kFinCh * kFinRows), 0,
-                     stream, part_sum, part_sq, tiles, C, inv, unbias, gamma, beta, running_mean,
-                     running_var, momentum, eps, scale, shift, batch_mean, batch_var);
+  static const bool small_on = [] { const char* e = getenv("CAPNET_FIN_SMALL"); return !(e && e[0] == '0'); }();
+  if (small_on && tiles <= kFinSmallMaxTiles)
+    hipLaunchKernelGGL(bn_finalize_kernel<kFinRowsSmall>, dim3(cdiv(C, kFinCh)), dim3(kFinCh * kFinRowsSmall), 0,
+                       stream, part_sum, part_sq, tiles, C, inv, unbias, gamma, beta, running_mean,
+                       running_var, momentum, eps, scale, shift, batch_mean, batch_var);
+  else
+    hipLaunchKernelGGL(bn_finalize_kernel<kFinRows>, dim3(cdiv(C, kFinCh)), dim3(kFinCh * kFinRows), 0,
+                       stream, part_sum, part_sq, tiles, C, inv, unbias, gamma, beta, running_mean,
+                       running_var, momentum, eps, scale, shift, batch_mean, batch_var);
   CAPNET_LAUNCH_CHECK();
   return kOk;
 }
