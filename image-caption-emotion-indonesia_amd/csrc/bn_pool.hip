@@ -18,7 +18,8 @@ namespace capnet {
 constexpr int kFinCh = 16, kFinRows = 64;
 // ... and for at most 128 partial rows (the 14 x 14 and 7 x 7 maps: 119 of the trunk's 155 BatchNorms) 16 rows = 256
 // threads: beside the convolutions' eight-wave workgroups a 1 024-thread block waits for a CU with sixteen free wave
-// slots, a 256-thread one for four
+// slots, a 256-thread one for four (+1.2 % images/s in the pipelined step; 512 threads up to 512 partial rows: +0.5 %;
+// CAPNET_FIN_SMALL=0 / CAPNET_FIN_MID=0 for A/B)
 constexpr int kFinRowsSmall = 16, kFinSmallMaxTiles = 128;
 
 // running statistic <- (1 - momentum) running + momentum batch, with ONE rounding pattern wherever it is applied: the
@@ -97,8 +98,13 @@ int bn_finalize(const float* part_sum, const float* part_sq, int tiles, int C, l
   const double inv = 1.0 / (double)count;
   const double unbias = count > 1 ? (double)count / (double)(count - 1) : 1.0;
   static const bool small_on = [] { const char* e = getenv("CAPNET_FIN_SMALL"); return !(e && e[0] == '0'); }();
+  static const bool mid_on = [] { const char* e = getenv("CAPNET_FIN_MID"); return !(e && e[0] == '0'); }();
   if (small_on && tiles <= kFinSmallMaxTiles)
     hipLaunchKernelGGL(bn_finalize_kernel<kFinRowsSmall>, dim3(cdiv(C, kFinCh)), dim3(kFinCh * kFinRowsSmall), 0,
+                       stream, part_sum, part_sq, tiles, C, inv, unbias, gamma, beta, running_mean,
+                       running_var, momentum, eps, scale, shift, batch_mean, batch_var);
+  else if (mid_on && tiles <= 512)
+    hipLaunchKernelGGL(bn_finalize_kernel<32>, dim3(cdiv(C, kFinCh)), dim3(kFinCh * 32), 0,
                        stream, part_sum, part_sq, tiles, C, inv, unbias, gamma, beta, running_mean,
                        running_var, momentum, eps, scale, shift, batch_mean, batch_var);
   else
