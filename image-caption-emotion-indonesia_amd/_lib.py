@@ -49,25 +49,15 @@ SIGNATURES = {
     "capnet_conv2d_fwd": (_i, [_vp, _l, _l, _l, _l, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _i,
                                _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "capnet_trunk_conv_kmajor": (_i, [_vp, _i]),
-    "capnet_trunk_conv_x6_bn": (_i, [_vp, _i]),
+    "capnet_trunk_conv_tile_n": (_i, [_vp, _i]),
     "capnet_pack_conv_weight_kmajor": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "capnet_conv2d_fwd_kmajor": (_i, [_vp, _l, _l, _l, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _i,
                                       _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
-    "capnet_pack_conv_weight_wino": (_i, [_vp, _vp, _i, _i, _vp]),
-    "capnet_conv_wino_weight_floats": (_sz, [_i, _i]),
-    "capnet_conv_wino_tiles_m": (_i, [_i, _i, _i]),
-    "capnet_conv2d_fwd_wino": (_i, [_vp, _l, _l, _l, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i,
-                                    _vp, _vp, _i, _vp]),
     "capnet_sgemm_nt_dma_eligible": (_i, [_i, _i, _i, _vp, _l, _vp, _l, _vp, _l]),
     "capnet_sgemm_nt_dma": (_i, [_i, _i, _i, _vp, _l, _vp, _vp, _vp, _vp]),
     "capnet_conv1x1_tiles_m": (_i, [_l]),
     "capnet_conv1x1_fwd_dma": (_i, [_vp, _l, _l, _l, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp,
                                     _vp, _i, _vp]),
-    "capnet_conv1x1_bf16x6_weight_words": (_sz, [_i, _i]),
-    "capnet_conv1x1_bf16x6_bn": (_i, [_l, _i]),
-    "capnet_conv1x1_bf16x6_pack": (_i, [_vp, _vp, _i, _i, _i, _vp]),
-    "capnet_conv1x1_fwd_bf16x6": (_i, [_vp, _l, _l, _l, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i,
-                                       _i, _vp, _vp, _vp, _i, _vp]),
     "capnet_conv1x1_f16x3_weight_words": (_sz, [_i, _i]),
     "capnet_conv1x1_f16x3_bn": (_i, [_l, _i]),
     "capnet_conv1x1_f16x3_pack": (_i, [_vp, _vp, _i, _i, _i, _vp]),

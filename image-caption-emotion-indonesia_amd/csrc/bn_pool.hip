@@ -97,13 +97,11 @@ int bn_finalize(const float* part_sum, const float* part_sq, int tiles, int C, l
   CAPNET_REQUIRE((batch_mean == nullptr) == (batch_var == nullptr), "bn_finalize: batch stat pair");
   const double inv = 1.0 / (double)count;
   const double unbias = count > 1 ? (double)count / (double)(count - 1) : 1.0;
-  static const bool small_on = [] { const char* e = getenv("CAPNET_FIN_SMALL"); return !(e && e[0] == '0'); }();
-  static const bool mid_on = [] { const char* e = getenv("CAPNET_FIN_MID"); return !(e && e[0] == '0'); }();
-  if (small_on && tiles <= kFinSmallMaxTiles)
+  if (tiles <= kFinSmallMaxTiles)
     hipLaunchKernelGGL(bn_finalize_kernel<kFinRowsSmall>, dim3(cdiv(C, kFinCh)), dim3(kFinCh * kFinRowsSmall), 0,
                        stream, part_sum, part_sq, tiles, C, inv, unbias, gamma, beta, running_mean,
                        running_var, momentum, eps, scale, shift, batch_mean, batch_var);
-  else if (mid_on && tiles <= 512)
+  else if (tiles <= 512)
     hipLaunchKernelGGL(bn_finalize_kernel<32>, dim3(cdiv(C, kFinCh)), dim3(kFinCh * 32), 0,
                        stream, part_sum, part_sq, tiles, C, inv, unbias, gamma, beta, running_mean,
                        running_var, momentum, eps, scale, shift, batch_mean, batch_var);

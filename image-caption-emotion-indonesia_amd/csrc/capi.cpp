@@ -46,21 +46,6 @@ int capnet_conv1x1_fwd_dma(const float* x, long sxb, long sxh, long sxw, const f
                          S(stream), out_scale, out_shift, res, relu_out);
 }
 
-size_t capnet_conv1x1_bf16x6_weight_words(int Cin, int Cout) { return conv1x1_bf16x6_weight_words(Cin, Cout); }
-int capnet_conv1x1_bf16x6_bn(long M, int Cout) { return conv1x1_bf16x6_bn(M, Cout); }
-int capnet_conv1x1_bf16x6_pack(const float* w_oi, unsigned* image, int Cout, int Cin, int bn,
-                               capnet_stream_t stream) {
-  return conv1x1_bf16x6_pack(w_oi, image, Cout, Cin, bn, S(stream));
-}
-int capnet_conv1x1_fwd_bf16x6(const float* x, long sxb, long sxh, long sxw, const unsigned* image, int bn,
-                              float* y, const float* in_scale, const float* in_shift, int relu_in,
-                              float* part_sum, float* part_sq, int B, int H, int W, int Cin, int Cout,
-                              int stride, const float* out_scale, const float* out_shift,
-                              const float* res, int relu_out, capnet_stream_t stream) {
-  return conv1x1_fwd_bf16x6(x, sxb, sxh, sxw, image, bn, y, in_scale, in_shift, relu_in, part_sum, part_sq, B,
-                            H, W, Cin, Cout, stride, S(stream), out_scale, out_shift, res, relu_out);
-}
-
 size_t capnet_conv1x1_f16x3_weight_words(int Cin, int Cout) { return conv1x1_f16x3_weight_words(Cin, Cout); }
 int capnet_conv1x1_f16x3_bn(long M, int Cout) { return conv1x1_f16x3_bn(M, Cout); }
 int capnet_conv1x1_f16x3_pack(const float* w_oi, unsigned* image, int Cout, int Cin, int bn,
@@ -181,7 +166,7 @@ double capnet_trunk_conv_flops(const capnet_trunk_t* t, int i) {
 int capnet_trunk_conv_kmajor(const capnet_trunk_t* t, int i) {
   return trunk_conv_kmajor(reinterpret_cast<const Trunk*>(t), i);
 }
-int capnet_trunk_conv_x6_bn(const capnet_trunk_t* t, int i) { return trunk_conv_x6_bn(reinterpret_cast<const Trunk*>(t), i); }
+int capnet_trunk_conv_tile_n(const capnet_trunk_t* t, int i) { return trunk_conv_tile_n(reinterpret_cast<const Trunk*>(t), i); }
 int capnet_pack_conv_weight_kmajor(const float* w_oihw, float* out, int Cout, int Cin, int KH,
                                    int KW, int k_rows, capnet_stream_t stream) {
   return pack_conv_weight_kmajor(w_oihw, out, Cout, Cin, KH, KW, k_rows, S(stream));
@@ -193,20 +178,6 @@ int capnet_conv2d_fwd_kmajor(const float* x, long sxb, long sxh, long sxw, const
                              float* slabs, capnet_stream_t stream) {
   return conv2d_fwd_v2(x, sxb, sxh, sxw, w_kmajor, k_rows, y, in_scale, in_shift, relu_in, part_sum,
                        part_sq, B, H, W, Cin, Cout, KH, KW, stride, pad, tile, slabs, S(stream));
-}
-int capnet_pack_conv_weight_wino(const float* w_oihw, float* out, int Cout, int Cin,
-                                 capnet_stream_t stream) {
-  return pack_conv_weight_wino(w_oihw, out, Cout, Cin, S(stream));
-}
-size_t capnet_conv_wino_weight_floats(int Cin, int Cout) { return conv_wino_weight_floats(Cin, Cout); }
-int capnet_conv_wino_tiles_m(int B, int H, int W) { return conv_wino_tiles_m(B, H, W); }
-int capnet_conv2d_fwd_wino(const float* x, long sxb, long sxh, long sxw, const float* w_wino, float* y,
-                           const float* in_scale, const float* in_shift, int relu_in,
-                           float* part_sum, float* part_sq, int B, int H, int W, int Cin, int Cout,
-                           const float* out_scale, const float* out_shift, int relu_out,
-                           capnet_stream_t stream) {
-  return conv2d_fwd_wino(x, sxb, sxh, sxw, w_wino, y, in_scale, in_shift, relu_in, part_sum, part_sq, B,
-                         H, W, Cin, Cout, S(stream), out_scale, out_shift, relu_out);
 }
 size_t capnet_conv_kmajor_slab_floats(int M, int Cout, int k_rows, int tile) {
   return conv_v2_slab_floats(M, Cout, k_rows, tile);

@@ -469,17 +469,15 @@ int conv3x3_fwd_patch(const float* x, const unsigned* wimg, int bn, float* y, co
   magic_div((unsigned)a.tiles_n, &a.tn_mul, &a.tn_sh);
   magic_div((unsigned)(H * W), &a.hw_mul, &a.hw_sh);
   magic_div((unsigned)W, &a.w_mul, &a.w_sh);
-  const char* ge = getenv("CAPNET_P3_WGS");
-  const int cap = ge ? atoi(ge) : 512;
+  const int cap = 512;
   const int total = a.tiles_m * a.tiles_n;
   const dim3 grid(total <= cap ? total : cap), block(kThreads);
   // at most one tile per CU and nothing else on the chip: a workgroup is alone on its CU, the pairs split K (see the
   // top of the file). Beside other passes' kernels (shared_chip) the <= 128-VGPR arrangement wins although it is the
   // slower one alone: a 185-VGPR workgroup of 8 waves keeps every other conv workgroup off its CU. Measured in the
   // pipelined step: 8 319 images/s without K split, 8 227 with it on the 7 x 7 maps only, 7 981 on 14 x 14 and 7 x 7,
-  // 8 097 on the implicit-GEMM kernel (CAPNET_P3_KSPLIT_MAX overrides the bound on the tile count).
-  static const int ks_env = [] { const char* e = getenv("CAPNET_P3_KSPLIT_MAX"); return e ? atoi(e) : -1; }();
-  const int ks_max = ks_env >= 0 ? ks_env : (shared_chip ? 0 : 256);
+  // 8 097 on the implicit-GEMM kernel.
+  const int ks_max = shared_chip ? 0 : 256;
   const bool ksplit = total <= ks_max;
   if (bn == 128) {
     if (ksplit) CAPNET_LAUNCH_TIMED((conv3x3_patch_kernel<128, true>), grid, block, stream, a);
@@ -518,8 +516,7 @@ int conv1x1_fwd_tail(const float* y3, const float* s1, const float* t1, const fl
   while ((1 << a.H) < nkc) ++a.H;                     // (H carries log2 of the k-steps per tile)
   a.tiles_m = cdiv(a.M, PBM); a.tiles_n = Cout / bn;
   magic_div((unsigned)a.tiles_n, &a.tn_mul, &a.tn_sh);
-  const char* ge = getenv("CAPNET_TAIL_WGS");
-  const int cap = ge ? atoi(ge) : 512;
+  const int cap = 512;
   const int total = a.tiles_m * a.tiles_n;
   const dim3 grid(total <= cap ? total : cap), block(kThreads);
   if (bn == 128) CAPNET_LAUNCH_TIMED((conv1x1_tail_kernel<128>), grid, block, stream, a);

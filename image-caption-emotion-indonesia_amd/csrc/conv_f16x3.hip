@@ -76,9 +76,7 @@ struct HArgs {
   int relu_out;
   int M, Cin, Cout, relu_in;
   int H, W, pad;             // input map and zero padding (3x3 convolutions)
-  int abl;   // diagnostics (CAPNET_H3_ABLATE): 4 no statistics, 8 no output stores, 32 every wait vmcnt(0), 256 no loads in the loop
   int tiles_m, tiles_n;
-  long long* stamps;   // diagnostics (CAPNET_H3_STAMPS = device address): workgroup 0 records 4 clock values per step
   unsigned tn_mul, tn_sh;
   int OW, OHW, stride, sxb, sxh, sxw;
   unsigned ohw_mul, ohw_sh, ow_mul, ow_sh;
@@ -134,17 +132,9 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const HArgs g) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kStage + 4 * BN * 4 + kFold];
   float* scratch = reinterpret_cast<float*>(lds + 2 * kStage);
   const float* fold = reinterpret_cast<const float*>(lds + 2 * kStage + 4 * BN * 4);    // scale 2^4 | shift 2^4
-  __shared__ long long st[4 * 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 31, lh = lane >> 5;
-  const bool diag = g.stamps != nullptr && blockIdx.x == 0;
-  auto stamp = [&](int it, int j) {
-    if (diag && it < 64) {
-      const long long t = __builtin_readcyclecounter();
-      if (tid == 0) st[4 * it + j] = t;
-    }
-  };
   const int total = g.tiles_m * g.tiles_n, G = (int)gridDim.x;
   const int nkc = g.Cin / HBK;               // steps per tap
   const int nk = TAPS * nkc;
@@ -193,11 +183,39 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const HArgs g) {
   // Loads are only ever issued for steps that exist and every issued set is consumed (landed): a register
   // written by a load nobody consumes is free for the compiler to reuse at once, and the load would land in
   // whatever lives there by then.
+  // ONE asm statement per step: s_nop 4 (the SGPR bases may come straight from a v_readlane reload: mfma_core.h,
+  // gload16) + the NBR weight-image loads + the four activation loads (immediate offsets off one base). Outputs
+  // are early-clobber: no destination may share a register with an offset a later load of the statement reads.
+  const unsigned voffB = (unsigned)tid * 16u + 4096u;      // cells tid, tid + 256 at immediate offsets -4096 / 0 (13-bit signed field)
   auto issue = [&](HRegs<NBR>& R) {
-#pragma unroll
-    for (int q = 0; q < NBR; ++q) gload16(R.b[q], i_sB, (unsigned)((tid + 256 * q) * 16));
-#pragma unroll
-    for (int q = 0; q < 4; ++q) gload16(R.a[q], i_sA + 4 * q, i_avoff);
+    if constexpr (NBR == 4) {
+      asm volatile(
+          "s_nop 4\n\t"
+          "global_load_dwordx4 %0, %8, %10 offset:-4096\n\t"
+          "global_load_dwordx4 %1, %8, %10\n\t"
+          "global_load_dwordx4 %2, %11, %10 offset:-4096\n\t"
+          "global_load_dwordx4 %3, %11, %10\n\t"
+          "global_load_dwordx4 %4, %9, %12\n\t"
+          "global_load_dwordx4 %5, %9, %12 offset:16\n\t"
+          "global_load_dwordx4 %6, %9, %12 offset:32\n\t"
+          "global_load_dwordx4 %7, %9, %12 offset:48"
+          : "=&v"(R.b[0]), "=&v"(R.b[1]), "=&v"(R.b[2]), "=&v"(R.b[3]), "=&v"(R.a[0]), "=&v"(R.a[1]), "=&v"(R.a[2]),
+            "=&v"(R.a[3])
+          : "v"(voffB), "v"(i_avoff), "s"(i_sB), "v"(voffB + 8192u), "s"(i_sA)
+          : "memory");
+    } else {
+      asm volatile(
+          "s_nop 4\n\t"
+          "global_load_dwordx4 %0, %6, %8 offset:-4096\n\t"
+          "global_load_dwordx4 %1, %6, %8\n\t"
+          "global_load_dwordx4 %2, %7, %9\n\t"
+          "global_load_dwordx4 %3, %7, %9 offset:16\n\t"
+          "global_load_dwordx4 %4, %7, %9 offset:32\n\t"
+          "global_load_dwordx4 %5, %7, %9 offset:48"
+          : "=&v"(R.b[0]), "=&v"(R.b[1]), "=&v"(R.a[0]), "=&v"(R.a[1]), "=&v"(R.a[2]), "=&v"(R.a[3])
+          : "v"(voffB), "v"(i_avoff), "s"(i_sB), "s"(i_sA)
+          : "memory");
+    }
     if (TAPS > 1) {
       R.lo = i_ok ? lo : 0.f;
       R.hi = i_ok ? (PRE ? __builtin_inff() : 1.f) : 0.f;
@@ -215,9 +233,9 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const HArgs g) {
     }
   };
   auto landed = [&](HRegs<NBR>& R) {
-    asm volatile("" : "+v"(R.a[0]), "+v"(R.a[1]), "+v"(R.a[2]), "+v"(R.a[3])::"memory");
+    CAPNET_LANDED4(R.a[0], R.a[1], R.a[2], R.a[3]);
 #pragma unroll
-    for (int q = 0; q < NBR; ++q) asm volatile("" : "+v"(R.b[q]));
+    for (int q = 0; q < NBR; ++q) CAPNET_LANDED1(R.b[q]);
   };
 
   f32x16 acc[2][NT];
@@ -373,7 +391,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const HArgs g) {
     __builtin_amdgcn_sched_barrier(0);
     head(HP + 1);
     __builtin_amdgcn_sched_barrier(0);
-    if (do_issue && !(g.abl & 256)) issue(R);
+    if (do_issue) issue(R);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) Tc.ah[mt] = af[1][mt][0];
 #pragma unroll
@@ -409,8 +427,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const HArgs g) {
         }
       }
     }
-    if (plain && (g.abl & 8)) {
-    } else if (plain) {
+    if (plain) {
       // 32 NT unconditional stores (the count the waits after this epilogue rely on). A variant that turned the 32 x 32
       // blocks through LDS to store 16 B per lane took the same 5 400 cycles per tile (the burst of every workgroup's
       // 64 KB, not the instruction count, sets it) and is gone.
@@ -422,7 +439,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const HArgs g) {
           unsigned off = ((unsigned)(m0 + wm * 64 + mt * 32 + 4 * lh) * (unsigned)g.Cout + (unsigned)n) * 4u;
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            asm volatile("global_store_dword %0, %1, %2" ::"v"(off), "v"(acc[mt][nt][r]), "s"(g.y) : "memory");
+            gstore32(g.y, off, acc[mt][nt][r]);
             off += ((r & 3) == 3 ? 5u : 1u) * rstep;
           }
         }
@@ -445,14 +462,14 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const HArgs g) {
                 if (g.res) v += *reinterpret_cast<const float*>(reinterpret_cast<const char*>(g.res) + off);
                 if (g.relu_out) v = fmaxf(v, 0.f);
               }
-              asm volatile("global_store_dword %0, %1, %2" ::"v"(off), "v"(v), "s"(g.y) : "memory");
+              gstore32(g.y, off, v);
             }
             if ((r & 3) == 3) { row += 5; off += 5u * rstep; } else { row += 1; off += rstep; }
           }
         }
       }
     }
-    if (g.part_sum && !(g.abl & 4)) {
+    if (g.part_sum) {
       using T = TileCfg<HBM, BN, 16>;
       block_col_stats<T>(acc, scratch, g.part_sum + (long)tm * g.Cout, g.part_sq + (long)tm * g.Cout, n0, g.Cout);
       __syncthreads();       // scratch is reused by the next tile's statistics
@@ -460,7 +477,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const HArgs g) {
     zero_acc();
     // a plain tile put exactly 32 NT stores behind the loads in flight; anything else (ragged rows, the folded
     // epilogue's own loads) is not counted on: the next wait drains the queue
-    after_epi = (plain && !(g.abl & 8)) ? 2 : -1;
+    after_epi = plain ? 2 : -1;
   };
 
   HRegs<NBR> R0, R1;
@@ -481,17 +498,13 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const HArgs g) {
   // registers into the stage nobody reads again -- because a branch there splits the scheduling region.
   HTail T0, T1;
   auto step = [&](HRegs<NBR>& R, int stage, int it, HTail& Tc, const HTail& Tp, bool second) {
-    stamp(it, 0);
-    if ((g.abl & 32) || it + 2 >= n_it) { h_wait_vmcnt<0>(); after_epi = 0; }     // nothing younger in flight
+    if (it + 2 >= n_it) { h_wait_vmcnt<0>(); after_epi = 0; }     // nothing younger in flight
     else if (after_epi > 0) { h_wait_vmcnt<kWaitEpi>(); --after_epi; }
     else if (after_epi < 0) { h_wait_vmcnt<0>(); after_epi = 0; }
     else h_wait_vmcnt<NLD>();
-    stamp(it, 1);
     landed(R);
     body(R, stage, Tc, Tp, second || ckt > 0, it + 3 < n_it);
-    stamp(it, 2);
     __syncthreads();
-    stamp(it, 3);
     ++ckt;
     if (second && ckt == nk) {
       tail(Tc);
@@ -503,12 +516,6 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const HArgs g) {
   for (int it = 0; it < n_it; it += 2) {
     step(R1, 0, it, T0, T1, false);
     step(R0, 1, it + 1, T1, T0, true);
-  }
-  if (diag) {
-    __syncthreads();
-    if (tid < 64) {
-      for (int j = 0; j < 4; ++j) g.stamps[4 * tid + j] = st[4 * tid + j];
-    }
   }
   h_wait_vmcnt<0>();       // nothing of this workgroup may still be in flight when its LDS is handed on
 }
@@ -624,8 +631,6 @@ int conv_fwd_f16x3(const float* x, long sxb, long sxh, long sxw, const unsigned*
   a.x = x; a.wimg = wimg; a.y = y; a.in_scale = in_scale; a.in_shift = in_shift;
   a.part_sum = part_sum; a.part_sq = part_sq;
   a.out_scale = out_scale; a.out_shift = out_shift; a.res = res; a.relu_out = relu_out;
-  { const char* e = getenv("CAPNET_H3_ABLATE"); a.abl = e ? atoi(e) : 0; }
-  { const char* e = getenv("CAPNET_H3_STAMPS"); a.stamps = e ? reinterpret_cast<long long*>(strtoull(e, nullptr, 0)) : nullptr; }
   a.M = Bn * OH * OW; a.Cin = Cin; a.Cout = Cout; a.relu_in = relu_in;
   a.H = H; a.W = W; a.pad = pad;
   a.tiles_m = cdiv(a.M, HBM); a.tiles_n = Cout / bn;
@@ -636,8 +641,7 @@ int conv_fwd_f16x3(const float* x, long sxb, long sxh, long sxw, const unsigned*
   magic_div((unsigned)OW, &a.ow_mul, &a.ow_sh);
   // persistent: two workgroups per CU walk the tiles (a multiple of 8, so that a workgroup stays on its XCD's share
   // of the tile order)
-  const char* ge = getenv("CAPNET_H3_WGS");
-  const int cap = ge ? atoi(ge) : 512;
+  const int cap = 512;
   const int total = a.tiles_m * a.tiles_n;
   const dim3 grid(total <= cap ? total : cap), block(256);
 #define CAPNET_H3_LAUNCH(BN_, PRE_, TAPS_) CAPNET_LAUNCH_TIMED((conv_f16x3_kernel<BN_, PRE_, TAPS_>), grid, block, stream, a)

@@ -183,20 +183,16 @@ __global__ __launch_bounds__(kGemmThreads) void conv_f32_v2_kernel(ConvArgs2 g) 
     }
   };
   const int awr = (4 * kc) * LDA + rl;  // A store index inside a stage
+  // Every load and DMA of the tile has landed after this wait (vmcnt retires in order); CAPNET_LANDED makes the
+  // loaded registers defined HERE for the compiler. Called unconditionally, also where no tile was requested
+  // (nothing in flight then): a wait under the same condition as the issue is correct, but the ISA checker
+  // (tools/isa_inflight_check.py) follows every path and cannot know that two branches take the same side.
+  auto landed = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (PASSES == 2) CAPNET_LANDED2(av[0], av[PASSES - 1]); else CAPNET_LANDED1(av[0]);
+    if (pre) CAPNET_LANDED2(scv, shv);
+  };
   auto store = [&](int stage) {
-    // every load and DMA of this tile has landed after this wait (vmcnt retires in order); the
-    // "+v" operands make the loaded registers defined HERE for the compiler
-    if (pre) {
-      if (PASSES == 2)
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(av[0]), "+v"(av[PASSES - 1]), "+v"(scv), "+v"(shv)::"memory");
-      else
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(av[0]), "+v"(scv), "+v"(shv)::"memory");
-    } else {
-      if (PASSES == 2)
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(av[0]), "+v"(av[PASSES - 1])::"memory");
-      else
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(av[0])::"memory");
-    }
     float* d0 = lds + stage * A_ST + awr;
 #pragma unroll
     for (int ps = 0; ps < PASSES; ++ps) {
@@ -278,6 +274,7 @@ __global__ __launch_bounds__(kGemmThreads) void conv_f32_v2_kernel(ConvArgs2 g) 
 
   snapshot();
   issue(0, kt0);
+  landed();
   store(0);
   __syncthreads();
   int kt = kt0;
@@ -286,6 +283,7 @@ __global__ __launch_bounds__(kGemmThreads) void conv_f32_v2_kernel(ConvArgs2 g) 
     snapshot();
     issue(1, kt + 1);
     compute(0);
+    landed();
     store(1);
     __syncthreads();
     const bool more = kt + 2 < kt1;
@@ -294,6 +292,7 @@ __global__ __launch_bounds__(kGemmThreads) void conv_f32_v2_kernel(ConvArgs2 g) 
       issue(0, kt + 2);
     }
     compute(1);
+    landed();
     if (more) store(0);
     __syncthreads();
   }
@@ -352,7 +351,7 @@ __global__ __launch_bounds__(kGemmThreads) void conv_f32_v2_kernel(ConvArgs2 g) 
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const unsigned off = base + (unsigned)((r & 3) + 8 * (r >> 2)) * step;
-          asm volatile("global_store_dword %0, %1, %2" ::"v"(off), "v"(acc[mt][nt][r]), "s"(g.y) : "memory");
+          gstore32(g.y, off, acc[mt][nt][r]);
         }
       }
     }

@@ -80,7 +80,7 @@ __device__ __forceinline__ void glds16_imm(const float* sbase, unsigned voff_byt
   asm volatile(
       "s_mov_b32 %0, m0\n\t"
       "s_add_u32 m0, %2, %4\n\t"
-      "s_nop 0\n\t"
+      "s_nop 2\n\t"               // 5 wait states in all: M0 (1) and an SGPR base fresh from a VALU write (5), mfma_core.h
       "global_load_lds_dwordx4 %1, %3 offset:%5\n\t"
       "s_mov_b32 m0, %0"
       : "=&s"(keep)
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256, DBK == 32 ? 2 : 4) void nt_dma_kernel(const Nt
             } else {
               v += bv;
             }
-            asm volatile("global_store_dword %0, %1, %2" ::"v"(off), "v"(v), "s"(g.C) : "memory");
+            gstore32(g.C, off, v);
           } else {
             acc[mt][nt][r] = 0.f;      // rows past M stay out of the statistics below
           }
@@ -323,15 +323,10 @@ int launch_nt(const NtArgs& a, int BN, int bk, hipStream_t stream) {
 }
 
 int pick_bn(int N) {
-  const char* f = getenv("CAPNET_DMA_BN");    // diagnostics: force the 128 x 64 tile
-  if (f && f[0] == '6') return 64;
   return N % 128 == 0 ? 128 : 64;
 }
 
 int pick_bk(int K, int tiles) {
-  const char* f = getenv("CAPNET_DMA_BK");    // diagnostics
-  if (f && f[0] == '3') return K % 32 == 0 ? 32 : 16;
-  if (f && f[0] == '1') return 16;
   return (K % 32 == 0 && K >= 512 && tiles >= 512) ? 32 : 16;
 }
 

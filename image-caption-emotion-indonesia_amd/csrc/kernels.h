@@ -39,17 +39,6 @@ size_t conv_v2_slab_floats(int M, int Cout, int Kw, int tile);
 int conv_v2_auto_tile(int M, int Cout, int Kw);
 void conv_v2_plan(int M, int Cout, int Kw, int tile, int* out);
 int conv_tiles_m(int M, int tile);
-// conv_wino.hip (3x3 / stride 1 / pad 1 as Winograd F(2x2,3x3); weights packed by pack_conv_weight_wino)
-bool conv_wino_shape_ok(int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
-size_t conv_wino_weight_floats(int Cin, int Cout);
-int conv_wino_tiles_m(int Bn, int H, int W);
-int pack_conv_weight_wino(const float* w_oihw, float* out, int Cout, int Cin, hipStream_t stream);
-int conv2d_fwd_wino(const float* x, long sxb, long sxh, long sxw, const float* wp, float* y,
-                    const float* in_scale, const float* in_shift, int relu_in, float* part_sum,
-                    float* part_sq, int Bn, int H, int W, int Cin, int Cout, hipStream_t stream,
-                    const float* out_scale = nullptr, const float* out_shift = nullptr,
-                    int relu_out = 0);
-
 // gemm_dma.hip: C = A . B^T with both operands K-contiguous, LDS-DMA staging (1x1 convs, vocabulary projection)
 bool sgemm_nt_dma_eligible(int M, int N, int K, const float* A, long lda, const float* B, long ldb,
                            const float* C, long ldc);
@@ -62,19 +51,6 @@ int conv1x1_fwd_dma(const float* x, long sxb, long sxh, long sxw, const float* w
                     float* part_sum, float* part_sq, int Bn, int H, int W, int Cin, int Cout, int stride,
                     hipStream_t stream, const float* out_scale = nullptr, const float* out_shift = nullptr,
                     const float* res = nullptr, int relu_out = 0);
-
-// conv_bf16x6.hip: 1x1 convolution as six bf16 MFMA products of 3-way split fp32 operands (fp32-grade results)
-bool conv1x1_bf16x6_eligible(const float* x, long sxb, long sxh, long sxw, long sxc, int Bn, int H, int W,
-                             int Cin, int Cout, int stride, const float* in_scale, const float* in_shift);
-int conv1x1_bf16x6_tiles_m(long M);
-int conv1x1_bf16x6_bn(long M, int Cout);
-size_t conv1x1_bf16x6_weight_words(int Cin, int Cout);
-int conv1x1_bf16x6_pack(const float* w, unsigned* img, int Cout, int Cin, int bn, hipStream_t stream);
-int conv1x1_fwd_bf16x6(const float* x, long sxb, long sxh, long sxw, const unsigned* wimg, int bn, float* y,
-                       const float* in_scale, const float* in_shift, int relu_in, float* part_sum,
-                       float* part_sq, int Bn, int H, int W, int Cin, int Cout, int stride,
-                       hipStream_t stream, const float* out_scale = nullptr, const float* out_shift = nullptr,
-                       const float* res = nullptr, int relu_out = 0);
 
 // conv_f16x3.hip: 1x1 convolution as three f16 MFMA products of 2-way split, power-of-two scaled fp32 operands
 // (fp32-grade results; the default for Cin % 64 == 0)
@@ -154,7 +130,7 @@ int trunk_num_convs(const Trunk* t);
 int trunk_final_side(const Trunk* t);
 int trunk_conv_shape(const Trunk* t, int i, int* cout, int* cin, int* k, int* stride, int* kw);
 int trunk_conv_kmajor(const Trunk* t, int i);
-int trunk_conv_x6_bn(const Trunk* t, int i);
+int trunk_conv_tile_n(const Trunk* t, int i);
 double trunk_flops(const Trunk* t);
 double trunk_conv_flops(const Trunk* t, int i);
 int trunk_set_timing(Trunk* t, int enable);

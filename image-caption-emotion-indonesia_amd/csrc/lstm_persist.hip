@@ -40,6 +40,7 @@
 
 #include "common.h"
 #include "kernels.h"
+#include "mfma_core.h"
 
 namespace capnet {
 
@@ -142,11 +143,17 @@ __device__ __forceinline__ void persist_mfma(const pf32x4 (&av)[RB][2], const pf
   pf32x4 acc[persist_max_chains(RB)];
 #pragma unroll
   for (int c = 0; c < NRB * NS; ++c) acc[c] = pf32x4{0.f, 0.f, 0.f, 0.f};
+  // (input-only markers for tools/isa_inflight_check.py: a "+v" tie here made hipcc copy the still-stale registers
+  //  above the wait in some of the eight instantiations a step branches to -- mfma_core.h, CAPNET_LANDED_IN)
   wait_vmcnt<RB + YOUNG>();
+#pragma unroll
+  for (int r = 0; r < RB; ++r) CAPNET_LANDED_IN1(av[r][0]);
   __builtin_amdgcn_sched_barrier(0);
   persist_mfma_half<RB, NRB, 0>(av, wq, acc);
   __builtin_amdgcn_sched_barrier(0);
   wait_vmcnt<YOUNG>();
+#pragma unroll
+  for (int r = 0; r < RB; ++r) CAPNET_LANDED_IN1(av[r][1]);
   __builtin_amdgcn_sched_barrier(0);
   persist_mfma_half<RB, NRB, 1>(av, wq, acc);
 #pragma unroll

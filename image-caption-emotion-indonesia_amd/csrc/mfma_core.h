@@ -300,10 +300,13 @@ __device__ __forceinline__ unsigned fast_div(unsigned n, unsigned mul, unsigned 
 // it to the other waves.
 __device__ __forceinline__ void glds16(const float* sbase, int voff_bytes, unsigned lds_byte_addr) {
   unsigned keep;
+  // s_nop 2: with the two SALU instructions in front of it, five wait states lie between anything the compiler
+  // placed ahead of this statement and the DMA -- what a VMEM instruction needs after a VALU write of an SGPR it
+  // reads (see gload16 below); it also covers the one state M0 needs.
   asm volatile(
       "s_mov_b32 %0, m0\n\t"
       "s_mov_b32 m0, %2\n\t"
-      "s_nop 0\n\t"
+      "s_nop 2\n\t"
       "global_load_lds_dwordx4 %1, %3\n\t"
       "s_mov_b32 m0, %0"
       : "=&s"(keep)
@@ -314,9 +317,41 @@ __device__ __forceinline__ void glds16(const float* sbase, int voff_bytes, unsig
 // 16-B global load, address = uniform 64-bit base (SGPR pair) + per-lane 32-bit byte offset.
 // Inline asm for the same reason as glds16: hipcc's own loads in this loop got 64-bit VALU
 // address arithmetic and an s_waitcnt vmcnt(0) that drained the LDS-DMA before they issued.
-// The result is NOT valid until wait_loads() (vmcnt is counted by hand).
+// The result is NOT valid until the counted s_waitcnt, and the compiler does not know that: between this
+// statement and the CAPNET_LANDED that follows the wait, dst must not be read, copied, spilled or re-used.
+// The compiler is not obliged to honour that; tools/isa_inflight_check.py (tests/test_isa_cpu.py) verifies
+// on the shipped ISA, path by path, that it did.
+//
+// s_nop 4 -- the cause of round 2's unexplained GPU memory faults. gfx950 needs FIVE wait states between a VALU
+// instruction that writes an SGPR and a vector-memory instruction that reads it. The compiler pads that hazard for
+// its own instructions but does not look inside an asm statement, and it does produce such VALU writes: the
+// reload of a spilled SGPR is v_readlane_b32 sN, vSPILL, lane. Whenever register allocation put the reload of the
+// base pair directly in front of the asm load (or store), the instruction went out with the OLD base: a wild
+// address. Every asm statement with an "s" address operand therefore opens with its own wait states
+// (tools/isa_inflight_check.py checks this, too: check_sgpr_hazard).
 __device__ __forceinline__ void gload16(f32x4& dst, const float* sbase, unsigned voff_bytes) {
-  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff_bytes), "s"(sbase) : "memory");
+  asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=&v"(dst) : "v"(voff_bytes), "s"(sbase) : "memory");
 }
+// 4-byte store through a 64-bit VGPR address: no SGPR operand inside the statement, so the hazard above cannot
+// arise (the address is one v_lshl_add_u64 of compiler code). Asm, not C++, because the hand-counted vmcnt waits
+// of the persistent conv kernels rely on the exact number of stores an epilogue issues.
+__device__ __forceinline__ void gstore32(float* base, unsigned off_bytes, float v) {
+  float* p = reinterpret_cast<float*>(reinterpret_cast<char*>(base) + off_bytes);
+  asm volatile("global_store_dword %0, %1, off" ::"v"(p), "v"(v) : "memory");
+}
+// "These registers of hand-issued loads have landed" -- placed behind the counted wait. Ties the registers
+// (the values the program uses from here on are this statement's outputs) and leaves a marker in the
+// assembly for the checker.
+// Two forms. CAPNET_LANDEDn ties the registers ("+v": what the program uses afterwards are this statement's outputs, so
+// no consumer can be scheduled above it). The tie is a two-address constraint, and where several branches each land
+// the same registers hipcc satisfied it with a v_mov copy ABOVE the wait -- a copy of stale data (found by the checker
+// in lstm_persist.hip). CAPNET_LANDED_INn only reads the registers (no new value, nothing to copy); the consumers
+// are held back by the __builtin_amdgcn_sched_barrier(0) that must follow it.
+#define CAPNET_LANDED_IN1(a) asm volatile("; capnet.landed %0" ::"v"(a) : "memory")
+#define CAPNET_LANDED_IN4(a, b, c, d) asm volatile("; capnet.landed %0 %1 %2 %3" ::"v"(a), "v"(b), "v"(c), "v"(d) : "memory")
+#define CAPNET_LANDED1(a) asm volatile("; capnet.landed %0" : "+v"(a)::"memory")
+#define CAPNET_LANDED2(a, b) asm volatile("; capnet.landed %0 %1" : "+v"(a), "+v"(b)::"memory")
+#define CAPNET_LANDED4(a, b, c, d) \
+  asm volatile("; capnet.landed %0 %1 %2 %3" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)::"memory")
 
 }  // namespace capnet

@@ -13,6 +13,7 @@
 //     --[bn2+relu on load] conv3--> Y3 raw (+stats);  [X --convD--> D raw (+stats)]
 //   OUT = relu(bn3(Y3) + (bnD(D) | X))         (bn_add_relu)
 #include <algorithm>
+#include <cstdint>
 #include <cstdlib>
 #include <cstring>
 #include <cstdio>
@@ -30,11 +31,8 @@ struct TrunkConv {
   int OH, OW;  // output spatial size
   int Kw;      // packed K extent (rows of the K-major image / row stride of the row-major one)
   bool kmajor; // weights packed [Kw][Cout] for conv_f32_v2 (else [Cout][Kw] for conv_f32)
-  bool wino;   // 3x3 / stride 1 on an even map: Winograd F(2x2,3x3) (conv_wino.hip), its own weight image
-  bool dma1x1; // 1x1 on an activated input (conv1, downsample): LDS-DMA NT core (gemm_dma.hip), weights as [Cout][Cin]
-  bool x6;     // 1x1: six bf16 MFMA products of 3-way split fp32 operands (conv_bf16x6.hip), its own weight image
-  int x6_bn;   // tile width that image was laid out for
-  bool h3;     // Cin % 64 == 0, 1x1 or 3x3: three f16 MFMA products of 2-way split operands (conv_f16x3.hip); wins over x6 / Winograd
+  bool h3;     // Cin % 64 == 0, 1x1 or 3x3: three f16 MFMA products of 2-way split operands (conv_f16x3.hip and its siblings)
+  int tile_n;  // tile width the split-f16 weight image was laid out for
   bool stem_h3 = false;   // the 7x7 / 2 stem on the same arithmetic, NCHW image in (conv_stem.hip)
 };
 
@@ -53,6 +51,10 @@ struct Trunk {
   // partially filled last round and the slabs + fix-up launches only cost (measured +2 % images/s
   // without them), so the pipeline turns it off
   bool tail_balance = true;
+  // A/B and fallback switches, read from the environment when the plan is made (tests/test_encoder_gpu.py runs a
+  // trunk under each): CAPNET_NO_P3=1 the stride-1 3x3 convolutions on the implicit-GEMM kernel instead of the patch
+  // kernel; CAPNET_NO_TAIL_FUSION=1 every block tail as its own bn_add_relu launch
+  bool use_patch = true, fuse_tails = true;
   bool timing = false;
   int timing_every = 1;   // ... on every N-th pass (an event pair is a bubble in the stream: 310 per pass cost 2.5 % images/s)
   long pass_no = 0;
@@ -71,38 +73,12 @@ int trunk_create(int B, int H, int W, Trunk** out) {
                  "trunk_create: batch %d image %dx%d (sides must be multiples of 32)", B, H, W);
   Trunk* t = new Trunk();
   t->B = B; t->H = H; t->W = W;
-  // CAPNET_NO_WINOGRAD=1: every 3x3 through the direct implicit-GEMM kernel (A/B runs, diagnostics)
-  const char* now = getenv("CAPNET_NO_WINOGRAD");
-  const bool use_wino = !(now && now[0] == '1');
-  // CAPNET_DMA1X1=1: conv1 / downsample through the LDS-DMA NT core (gemm_dma.hip) instead of the
-  // K-major kernel. Off by default: measured in the pipelined step on one MI355X it is slower
-  // (4876 vs 5177 images/s) although it has no VALU in its k-loop -- see DESIGN 4e.
-  const char* dma = getenv("CAPNET_DMA1X1");
-  const bool use_dma = dma && dma[0] == '1';
-  // 1x1 convolutions on the bf16 matrix cores with split operands (fp32-grade results);
-  // CAPNET_NO_X6=1 keeps them on the f32-MFMA K-major kernel (A/B runs)
-  const char* nox = getenv("CAPNET_NO_X6");
-  const bool use_x6 = !(nox && nox[0] == '1');
-  // ... and, where Cin allows, on the f16 matrix cores with 2-way split operands: half the matrix work of the
-  // bf16 split at the same fp32-grade accuracy; CAPNET_NO_H3=1 keeps the bf16 split (A/B runs)
-  const char* noh = getenv("CAPNET_NO_H3");
-  const bool use_h3 = use_x6 && !(noh && noh[0] == '1');
-  // the 3x3 convolutions through the same kernel (implicit GEMM over (tap, channel)): CAPNET_H3_3X3 = a string of map
-  // sides, e.g. "56,28,7" = where the input map has that side; "all" / "none"; default: see below
-  const char* h33 = getenv("CAPNET_H3_3X3");
-  auto h3_3x3_on = [&](int side, int stride) {
-    if (!use_h3) return false;
-    if (h33) {
-      if (!strcmp(h33, "all")) return true;
-      if (!strcmp(h33, "none")) return false;
-      char key[16];
-      snprintf(key, sizeof key, "%d", side);
-      const char* f = strstr(h33, key);
-      return f != nullptr;
-    }
-    (void)stride;
-    return true;
-  };
+  auto env_on = [](const char* name) { const char* e = getenv(name); return e && e[0] == '1'; };
+  // CAPNET_NO_H3=1: the whole trunk on the f32-MFMA kernels (conv_f32_v2.hip / conv_f32.hip), the family that also
+  // serves shapes the split-f16 kernels do not take
+  const bool use_h3 = !env_on("CAPNET_NO_H3");
+  t->use_patch = !env_on("CAPNET_NO_P3");
+  t->fuse_tails = !env_on("CAPNET_NO_TAIL_FUSION");
   auto add = [&](int cin, int cout, int k, int stride, int pad, int h, int w, bool activated_input = false) {
     TrunkConv c;
     c.Cin = cin; c.Cout = cout; c.k = k; c.stride = stride; c.pad = pad; c.H = h; c.W = w;
@@ -110,24 +86,24 @@ int trunk_create(int B, int H, int W, Trunk** out) {
     c.OW = (w + 2 * pad - k) / stride + 1;
     c.Kw = round_up(k * k * cin, 16);
     c.kmajor = (cin % 16 == 0) && (cout % 64 == 0);
-    c.wino = use_wino && c.kmajor && conv_wino_shape_ok(h, w, cin, cout, k, k, stride, pad);
-    c.dma1x1 = use_dma && activated_input && k == 1 && pad == 0 && cin % 16 == 0 && cout % 64 == 0;
-    c.x6 = use_x6 && !c.dma1x1 && k == 1 && pad == 0 && cin % 16 == 0 && cout % 64 == 0;
-    c.h3 = use_h3 && c.x6 && cin % 64 == 0 && (activated_input || cin <= 512);
-    if (c.h3) c.x6 = false;
-    if (k == 3 && pad == 1 && cin % 64 == 0 && cout % 64 == 0 && cin <= 512 && h3_3x3_on(h, stride)) {
-      c.h3 = true;
-      c.wino = false;
+    // (a folded input needs its BatchNorm's scale / shift in LDS: Cin <= 512)
+    c.h3 = use_h3 && cin % 64 == 0 && cout % 64 == 0 && ((k == 1 && pad == 0 && (activated_input || cin <= 512)) || (k == 3 && pad == 1 && cin <= 512));
+    // ... and the kernels' 32-bit offset arithmetic must cover the whole tensor at this batch size: checked here,
+    // on the dense NHWC strides every trunk tensor has, so that a shape they do not take is PLANNED for the f32 kernels
+    // (with its K-major weight image) instead of failing at launch time
+    if (c.h3) {
+      const float* aligned = reinterpret_cast<const float*>(uintptr_t(256));
+      c.h3 = conv_f16x3_eligible(aligned, (long)h * w * cin, (long)w * cin, cin, 1, B, h, w, cin, cout, k, stride, pad,
+                                 activated_input ? nullptr : aligned, activated_input ? nullptr : aligned);
     }
-    c.x6_bn = c.x6 ? conv1x1_bf16x6_bn((long)B * c.OH * c.OW, cout) : c.h3 ? conv1x1_f16x3_bn((long)B * c.OH * c.OW, cout) : 0;
+    c.tile_n = c.h3 ? conv1x1_f16x3_bn((long)B * c.OH * c.OW, cout) : 0;
     t->convs.push_back(c);
     return c;
   };
   TrunkConv stem = add(3, 64, 7, 2, 3, H, W);
   {
     // CAPNET_NO_STEM_H3=1 keeps the stem on the generic f32 gather kernel (A/B runs)
-    const char* e = getenv("CAPNET_NO_STEM_H3");
-    t->convs[0].stem_h3 = use_h3 && !(e && e[0] == '1') && W % 4 == 0;
+    t->convs[0].stem_h3 = use_h3 && !env_on("CAPNET_NO_STEM_H3") && W % 4 == 0;
   }
   int h = (stem.OH + 2 - 3) / 2 + 1, w = (stem.OW + 2 - 3) / 2 + 1;  // maxpool
   int inplanes = 64;
@@ -170,8 +146,7 @@ int trunk_create(int B, int H, int W, Trunk** out) {
     const long M = (long)B * c.OH * c.OW;
     const int tile = c.kmajor ? conv_v2_auto_tile((int)M, c.Cout, c.Kw) : conv_auto_tile((int)M, c.Cout);
     max_part = std::max(max_part, (size_t)conv_tiles_m((int)M, tile) * c.Cout);
-    if (c.wino) max_part = std::max(max_part, (size_t)conv_wino_tiles_m(B, c.H, c.W) * c.Cout);
-    if (c.dma1x1 || c.x6 || c.h3) max_part = std::max(max_part, (size_t)conv1x1_tiles_m(M) * c.Cout);
+    if (c.h3) max_part = std::max(max_part, (size_t)conv1x1_tiles_m(M) * c.Cout);
     if (c.stem_h3) max_part = std::max(max_part, (size_t)conv_stem_f16x3_part_rows(B, c.H, c.W) * c.Cout);
   }
   t->off_part = take(2 * max_part);
@@ -256,12 +231,12 @@ int trunk_conv_shape(const Trunk* t, int i, int* cout, int* cin, int* k, int* st
 
 int trunk_conv_kmajor(const Trunk* t, int i) {
   if (i < 0 || i >= (int)t->convs.size()) return 0;
-  return t->convs[i].stem_h3 ? 6 : t->convs[i].h3 ? 5 : t->convs[i].x6 ? 4 : t->convs[i].dma1x1 ? 3 : t->convs[i].wino ? 2 : (t->convs[i].kmajor ? 1 : 0);
+  return t->convs[i].stem_h3 ? 6 : t->convs[i].h3 ? 5 : (t->convs[i].kmajor ? 1 : 0);
 }
 
-int trunk_conv_x6_bn(const Trunk* t, int i) {
+int trunk_conv_tile_n(const Trunk* t, int i) {
   if (i < 0 || i >= (int)t->convs.size()) return 0;
-  return t->convs[i].x6_bn;
+  return t->convs[i].tile_n;
 }
 
 double trunk_conv_flops(const Trunk* t, int i) {
@@ -280,7 +255,6 @@ double trunk_flops(const Trunk* t) {
 namespace {
 // A pair of timing events for one conv launch. Kernels launched through CAPNET_LAUNCH_TIMED (the split-f16 family) get
 // them attached to their dispatch (park = true: no hipEventRecord at all); the others are bracketed by two records.
-// CAPNET_EVENTS_LEGACY=1: bracket everything (A/B).
 static int take_events(Trunk* t, hipEvent_t* e0, hipEvent_t* e1) {
   while (t->ev_pool.size() < t->ev_next + 2) {
     hipEvent_t e;
@@ -291,14 +265,10 @@ static int take_events(Trunk* t, hipEvent_t* e0, hipEvent_t* e1) {
   *e1 = t->ev_pool[t->ev_next++];
   return kOk;
 }
-static bool events_legacy() {
-  static const bool on = [] { const char* e = getenv("CAPNET_EVENTS_LEGACY"); return e && e[0] == '1'; }();
-  return on;
-}
 static int timing_begin(Trunk* t, bool attach, hipStream_t s, hipEvent_t* e0, hipEvent_t* e1) {
   const int rc = take_events(t, e0, e1);
   if (rc) return rc;
-  if (attach && !events_legacy()) {
+  if (attach) {
     launch_events().start = *e0;
     launch_events().stop = *e1;
   } else {
@@ -307,7 +277,7 @@ static int timing_begin(Trunk* t, bool attach, hipStream_t s, hipEvent_t* e0, hi
   return kOk;
 }
 static int timing_end(Trunk* t, bool attach, hipStream_t s, hipEvent_t e0, hipEvent_t e1, double flops) {
-  if (attach && !events_legacy()) {
+  if (attach) {
     CAPNET_REQUIRE(launch_events().start == nullptr, "trunk: a conv launcher did not take its timing events");
   } else {
     CAPNET_HIP_CHECK(hipEventRecord(e1, s));
@@ -336,12 +306,6 @@ struct Ctx {
   float* bvar(int i) const { return ws + t->bs_off[i] + t->convs[i].Cout; }
 };
 
-// CAPNET_NO_P3=1: the stride-1 3x3 convolutions stay on the implicit-GEMM kernel (A/B runs)
-static bool use_patch_kernel() {
-  static const bool on = [] { const char* e = getenv("CAPNET_NO_P3"); return !(e && e[0] == '1'); }();
-  return on;
-}
-
 // A bottleneck block's tail that has not run yet: out = relu(y3 * s1 + t1 + res (* s2 + t2)), [rows][C]
 struct BlockTail {
   const float* y3; const float* s1; const float* t1;
@@ -350,11 +314,6 @@ struct BlockTail {
   long rows;
   int C;
 };
-// CAPNET_NO_TAIL_FUSION=1: every tail as its own bn_add_relu launch (A/B runs)
-static bool use_tail_fusion() {
-  static const bool on = [] { const char* e = getenv("CAPNET_NO_TAIL_FUSION"); return !(e && e[0] == '1'); }();
-  return on;
-}
 static int run_tail(const Ctx& c, const BlockTail& t) {
   return bn_add_relu(t.y3, t.s1, t.t1, t.res, t.s2, t.t2, t.out, t.rows, t.C, c.s);
 }
@@ -366,7 +325,7 @@ int conv_bn(const Ctx& c, int i, const float* x, long sxb, long sxh, long sxw, l
             const float* in_scale, const float* in_shift, int relu_in, float* y, const BlockTail* tail = nullptr) {
   const TrunkConv& d = c.t->convs[i];
   const long M = (long)c.t->B * d.OH * d.OW;
-  const bool fuse_tail = tail && (c.train || c.eval_ready) && use_tail_fusion() && d.h3 && d.k == 1 && d.stride == 1 && !in_scale &&
+  const bool fuse_tail = tail && (c.train || c.eval_ready) && c.t->fuse_tails && d.h3 && d.k == 1 && d.stride == 1 && !in_scale &&
                          x == tail->out && tail->C == d.Cin && tail->rows == M && sxc == 1 && sxw == d.Cin &&
                          sxh == (long)d.W * d.Cin && sxb == (long)d.H * d.W * d.Cin &&
                          conv1x1_tail_eligible(tail->y3, tail->res, M, d.Cin, d.Cout);
@@ -381,7 +340,7 @@ int conv_bn(const Ctx& c, int i, const float* x, long sxb, long sxh, long sxw, l
   int tile = d.kmajor ? conv_v2_auto_tile((int)M, d.Cout, d.Kw) : conv_auto_tile((int)M, d.Cout);
   if (d.kmajor && !c.t->tail_balance && M >= 5000) tile = 12864;
   // rows of the statistics partials this conv writes
-  const int prows = d.stem_h3 ? conv_stem_f16x3_part_rows(c.t->B, d.H, d.W) : (d.dma1x1 || d.x6 || d.h3) ? conv1x1_tiles_m(M) : d.wino ? conv_wino_tiles_m(c.t->B, d.H, d.W) : conv_tiles_m((int)M, tile);
+  const int prows = d.stem_h3 ? conv_stem_f16x3_part_rows(c.t->B, d.H, d.W) : d.h3 ? conv1x1_tiles_m(M) : conv_tiles_m((int)M, tile);
   float* psum = c.ws + c.t->off_part;
   float* psq = psum + (size_t)prows * d.Cout;
   hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -393,40 +352,25 @@ int conv_bn(const Ctx& c, int i, const float* x, long sxb, long sxh, long sxw, l
   int rc;
   if (fuse_tail) {
     rc = conv1x1_fwd_tail(tail->y3, tail->s1, tail->t1, tail->res, tail->s2, tail->t2, tail->out,
-                          reinterpret_cast<const unsigned*>(c.w[i]), d.x6_bn, y, c.train ? psum : nullptr,
+                          reinterpret_cast<const unsigned*>(c.w[i]), d.tile_n, y, c.train ? psum : nullptr,
                           c.train ? psq : nullptr, M, d.Cin, d.Cout, c.s);
   } else if (d.stem_h3) {
     CAPNET_REQUIRE(!in_scale && conv_stem_f16x3_eligible(x, sxb, sxc, sxh, sxw, c.t->B, d.H, d.W, d.Cin, d.Cout, d.k, d.stride, d.pad),
                    "trunk: the stem is planned for the split-f16 kernel but its operands are not eligible");
     rc = conv_stem_fwd_f16x3(x, sxb, sxc, sxh, reinterpret_cast<const unsigned*>(c.w[i]), y, c.train ? psum : nullptr,
                              c.train ? psq : nullptr, c.t->B, d.H, d.W, c.s);
-  } else if (d.h3 && d.k == 3 && use_patch_kernel() &&
+  } else if (d.h3 && d.k == 3 && c.t->use_patch &&
              conv3x3_patch_eligible(x, sxb, sxh, sxw, sxc, c.t->B, d.H, d.W, d.Cin, d.Cout, d.k, d.stride, d.pad, in_scale, in_shift)) {
     // stride-1 3x3: the tile's input patch staged once instead of once per tap (conv3x3_patch.hip), same weight image
-    rc = conv3x3_fwd_patch(x, reinterpret_cast<const unsigned*>(c.w[i]), d.x6_bn, y, in_scale, in_shift, relu_in,
+    rc = conv3x3_fwd_patch(x, reinterpret_cast<const unsigned*>(c.w[i]), d.tile_n, y, in_scale, in_shift, relu_in,
                            c.train ? psum : nullptr, c.train ? psq : nullptr, c.t->B, d.H, d.W, d.Cin, d.Cout, c.s,
                            !c.t->tail_balance);
   } else if (d.h3) {
     CAPNET_REQUIRE(conv_f16x3_eligible(x, sxb, sxh, sxw, sxc, c.t->B, d.H, d.W, d.Cin, d.Cout, d.k, d.stride, d.pad, in_scale, in_shift),
                    "trunk: conv %d planned for the split-f16 kernel but its operands are not eligible", i);
-    rc = conv_fwd_f16x3(x, sxb, sxh, sxw, reinterpret_cast<const unsigned*>(c.w[i]), d.x6_bn, y, in_scale,
+    rc = conv_fwd_f16x3(x, sxb, sxh, sxw, reinterpret_cast<const unsigned*>(c.w[i]), d.tile_n, y, in_scale,
                         in_shift, relu_in, c.train ? psum : nullptr, c.train ? psq : nullptr, c.t->B, d.H,
                         d.W, d.Cin, d.Cout, d.k, d.stride, d.pad, c.s);
-  } else if (d.x6) {
-    CAPNET_REQUIRE(conv1x1_bf16x6_eligible(x, sxb, sxh, sxw, sxc, c.t->B, d.H, d.W, d.Cin, d.Cout, d.stride, in_scale, in_shift),
-                   "trunk: conv %d planned for the split-bf16 kernel but its operands are not eligible", i);
-    rc = conv1x1_fwd_bf16x6(x, sxb, sxh, sxw, reinterpret_cast<const unsigned*>(c.w[i]), d.x6_bn, y, in_scale,
-                            in_shift, relu_in, c.train ? psum : nullptr, c.train ? psq : nullptr, c.t->B, d.H,
-                            d.W, d.Cin, d.Cout, d.stride, c.s);
-  } else if (d.dma1x1) {
-    CAPNET_REQUIRE(!in_scale && conv1x1_dma_eligible(x, sxb, sxh, sxw, sxc, c.t->B, d.H, d.W, d.Cin, d.Cout, d.stride),
-                   "trunk: conv %d planned for the LDS-DMA 1x1 kernel but its operands are not eligible", i);
-    rc = conv1x1_fwd_dma(x, sxb, sxh, sxw, c.w[i], y, c.train ? psum : nullptr, c.train ? psq : nullptr, c.t->B,
-                         d.H, d.W, d.Cin, d.Cout, d.stride, c.s);
-  } else if (d.wino) {
-    CAPNET_REQUIRE(sxc == 1, "trunk: conv %d planned for the Winograd kernel needs channel-contiguous input", i);
-    rc = conv2d_fwd_wino(x, sxb, sxh, sxw, c.w[i], y, in_scale, in_shift, relu_in, c.train ? psum : nullptr,
-                         c.train ? psq : nullptr, c.t->B, d.H, d.W, d.Cin, d.Cout, c.s);
   } else if (d.kmajor) {
     CAPNET_REQUIRE(conv_v2_eligible(x, sxb, sxh, sxw, sxc, c.t->B, d.Cin, d.Cout, in_scale, in_shift),
                    "trunk: conv %d planned for the K-major kernel but its operands are not eligible", i);
@@ -463,7 +407,7 @@ int conv_folded(const Ctx& c, int i, const float* x, const float* res, int relu,
   const TrunkConv& d = c.t->convs[i];
   const long M = (long)c.t->B * d.OH * d.OW;
   const long sw = d.Cin, sh = (long)d.W * d.Cin, sb = (long)d.H * d.W * d.Cin;
-  CAPNET_REQUIRE(d.h3 || d.x6 || d.dma1x1 || (d.kmajor && conv_v2_eligible(x, sb, sh, sw, 1, c.t->B, d.Cin, d.Cout, nullptr, nullptr)),
+  CAPNET_REQUIRE(d.h3 || (d.kmajor && conv_v2_eligible(x, sb, sh, sw, 1, c.t->B, d.Cin, d.Cout, nullptr, nullptr)),
                  "trunk: conv %d is not eligible for the folded-BN kernel", i);
   hipEvent_t e0 = nullptr, e1 = nullptr;
   const bool attach = d.h3;
@@ -473,20 +417,9 @@ int conv_folded(const Ctx& c, int i, const float* x, const float* res, int relu,
   }
   int rc;
   if (d.h3) {
-    rc = conv_fwd_f16x3(x, sb, sh, sw, reinterpret_cast<const unsigned*>(c.w[i]), d.x6_bn, y, nullptr, nullptr,
+    rc = conv_fwd_f16x3(x, sb, sh, sw, reinterpret_cast<const unsigned*>(c.w[i]), d.tile_n, y, nullptr, nullptr,
                         0, nullptr, nullptr, c.t->B, d.H, d.W, d.Cin, d.Cout, d.k, d.stride, d.pad, c.s, c.scale(i),
                         c.shift(i), res, relu);
-  } else if (d.x6) {
-    rc = conv1x1_fwd_bf16x6(x, sb, sh, sw, reinterpret_cast<const unsigned*>(c.w[i]), d.x6_bn, y, nullptr, nullptr,
-                            0, nullptr, nullptr, c.t->B, d.H, d.W, d.Cin, d.Cout, d.stride, c.s, c.scale(i),
-                            c.shift(i), res, relu);
-  } else if (d.dma1x1) {
-    rc = conv1x1_fwd_dma(x, sb, sh, sw, c.w[i], y, nullptr, nullptr, c.t->B, d.H, d.W, d.Cin, d.Cout, d.stride,
-                         c.s, c.scale(i), c.shift(i), res, relu);
-  } else if (d.wino) {
-    CAPNET_REQUIRE(res == nullptr, "trunk: conv %d (Winograd) has no residual input", i);
-    rc = conv2d_fwd_wino(x, sb, sh, sw, c.w[i], y, nullptr, nullptr, 0, nullptr, nullptr, c.t->B, d.H, d.W,
-                         d.Cin, d.Cout, c.s, c.scale(i), c.shift(i), relu);
   } else {
     rc = conv2d_fwd_v2(x, sb, sh, sw, c.w[i], d.Kw, y, nullptr, nullptr, 0, nullptr, nullptr,
                        c.t->B, d.H, d.W, d.Cin, d.Cout, d.k, d.k, d.stride, d.pad, 0,

@@ -178,18 +178,12 @@ class _TrunkRunner:
                 if tuple(c.weight.shape) != (cout, cin, k, k) or c.stride != stride:
                     raise CapnetError("conv %d: module shape %s does not match the plan" %
                                       (i, tuple(c.weight.shape)))
-                # 0 rows, 1 K-major, 2 Winograd, 3 as stored (a 1x1 OIHW weight IS [Cout][Cin]), 4 split bf16, 5 split f16, 6 the stem's split f16
+                # 0 rows, 1 K-major (the f32-MFMA kernels), 5 split f16, 6 the stem's split f16
                 kind = L.capnet_trunk_conv_kmajor(plan["handle"], i)
                 if kind == 6:
                     packed.append(ops.pack_conv_weight_stem_f16x3(c.weight.detach()))
                 elif kind == 5:
-                    packed.append(ops.pack_conv_weight_f16x3(c.weight.detach(), L.capnet_trunk_conv_x6_bn(plan["handle"], i)))
-                elif kind == 4:
-                    packed.append(ops.pack_conv_weight_bf16x6(c.weight.detach(), L.capnet_trunk_conv_x6_bn(plan["handle"], i)))
-                elif kind == 3:
-                    packed.append(c.weight.detach().reshape(cout, cin).contiguous())
-                elif kind == 2:
-                    packed.append(ops.pack_conv_weight_wino(c.weight.detach()))
+                    packed.append(ops.pack_conv_weight_f16x3(c.weight.detach(), L.capnet_trunk_conv_tile_n(plan["handle"], i)))
                 else:
                     packed.append(ops.pack_conv_weight(c.weight.detach(), kw, kmajor=kind == 1))
             self.packed, self.packed_key = packed, key

@@ -240,34 +240,6 @@ def pack_conv_weight(w_oihw, row_stride, kmajor=False):
     return out
 
 
-def pack_conv_weight_wino(w_oihw):
-    """OIHW 3x3 weights -> the Winograd F(2x2,3x3) image of capnet_conv2d_fwd_wino
-    ([Cin/8][Cout/64][16][64][8], U = G g G^T)."""
-    _need_cuda(w_oihw)
-    w = _c(w_oihw)
-    co, ci, kh, kw = w.shape
-    if (kh, kw) != (3, 3):
-        raise CapnetError("pack_conv_weight_wino: 3x3 weights only")
-    out = torch.empty(_lib.lib().capnet_conv_wino_weight_floats(ci, co), dtype=torch.float32, device=w.device)
-    check(_lib.lib().capnet_pack_conv_weight_wino(ptr(w), ptr(out), co, ci, current_stream()),
-          "capnet_pack_conv_weight_wino")
-    return out
-
-
-def pack_conv_weight_bf16x6(w_oihw, bn):
-    """1x1 OIHW weights -> the split-bf16 image of capnet_conv1x1_fwd_bf16x6 for tile width bn
-    (three bf16 pieces per weight, laid out as the kernel's LDS image)."""
-    _need_cuda(w_oihw)
-    w = _c(w_oihw)
-    co, ci, kh, kw = w.shape
-    if (kh, kw) != (1, 1):
-        raise CapnetError("pack_conv_weight_bf16x6: 1x1 weights only")
-    out = torch.empty(_lib.lib().capnet_conv1x1_bf16x6_weight_words(ci, co), dtype=torch.int32, device=w.device)
-    check(_lib.lib().capnet_conv1x1_bf16x6_pack(ptr(w), ptr(out), co, ci, int(bn), current_stream()),
-          "capnet_conv1x1_bf16x6_pack")
-    return out
-
-
 def pack_conv_weight_f16x3(w_oihw, bn):
     """1x1 or 3x3 OIHW weights -> header + the split-f16 image of capnet_conv2d_fwd_f16x3 for tile width bn
     (two f16 pieces per weight scaled by the per-tensor power of two in the header, laid out as the

@@ -121,19 +121,14 @@ int capnet_trunk_set_timing(capnet_trunk_t* t, int enable);
 int capnet_trunk_collect_timing(capnet_trunk_t* t, double* conv_ms, long* conv_launches,
                                 double* conv_flops);
 /* Weight image convolution i expects: 0 = rows [Cout][row_stride] (capnet_pack_conv_weight),
- * 1 = K-major [row_stride][Cout] (capnet_pack_conv_weight_kmajor; streamed to LDS by LDS-DMA),
- * 2 = Winograd F(2x2,3x3) (capnet_pack_conv_weight_wino: the 3x3 / stride-1 convolutions on even
- * maps, unless the trunk was created with CAPNET_NO_WINOGRAD=1 in the environment),
- * 3 = the 1x1 weight as stored, [Cout][Cin] (capnet_conv1x1_fwd_dma; only when the trunk was
- * created with CAPNET_DMA1X1=1: an experiment, slower than image 1 in the pipelined step),
- * 4 = the split-bf16 image of a 1x1 convolution (capnet_conv1x1_bf16x6_pack with tile width
- * capnet_trunk_conv_x6_bn(t, i); 1x1 convolutions image 5 does not take, unless CAPNET_NO_X6=1),
- * 5 = the split-f16 image of a 1x1 convolution (capnet_conv1x1_f16x3_pack with tile width
- * capnet_trunk_conv_x6_bn(t, i); every 1x1 convolution with Cin % 64 == 0 unless CAPNET_NO_H3=1; the 3x3 ones through
- * capnet_conv_f16x3_pack),
- * 6 = the split-f16 image of the stem (capnet_conv_stem_f16x3_pack; unless CAPNET_NO_H3=1 or CAPNET_NO_STEM_H3=1). */
+ * 1 = K-major [row_stride][Cout] (capnet_pack_conv_weight_kmajor; streamed to LDS by LDS-DMA) -- the f32-MFMA kernels,
+ * which take every convolution when the trunk is created with CAPNET_NO_H3=1 in the environment and otherwise those the
+ * split-f16 kernels do not (none in ResNet-152),
+ * 5 = the split-f16 image of a 1x1 or 3x3 convolution (capnet_conv_f16x3_pack with tile width
+ * capnet_trunk_conv_tile_n(t, i)),
+ * 6 = the split-f16 image of the stem (capnet_conv_stem_f16x3_pack; unless CAPNET_NO_STEM_H3=1). */
 int capnet_trunk_conv_kmajor(const capnet_trunk_t* t, int i);
-int capnet_trunk_conv_x6_bn(const capnet_trunk_t* t, int i);
+int capnet_trunk_conv_tile_n(const capnet_trunk_t* t, int i);
 int capnet_pack_conv_weight_kmajor(const float* w_oihw, float* out, int Cout, int Cin, int KH,
                                    int KW, int k_rows, capnet_stream_t stream);
 /* OIHW (torch Conv2d.weight) -> packed rows */
@@ -168,29 +163,13 @@ int capnet_conv1x1_fwd_dma(const float* x, long sxb, long sxh, long sxw, const f
                            int stride, const float* out_scale, const float* out_shift, const float* res,
                            int relu_out, capnet_stream_t stream);
 
-/* 1x1 convolution with fp32-grade results on the bf16 matrix cores (csrc/conv_bf16x6.hip): both
- * operands split into three bf16 pieces, six partial products per multiply, fp32 accumulation; rms
- * error against fp64 at or below the f32-MFMA kernels'. Weights: capnet_conv1x1_bf16x6_pack of the
- * [Cout][Cin] matrix for tile width bn = capnet_conv1x1_bf16x6_bn(M, Cout)
- * (capnet_conv1x1_bf16x6_weight_words 32-bit words). Statistics rows: capnet_conv1x1_tiles_m(M).
- * in_scale / in_shift / relu_in: BatchNorm + ReLU of the producer applied on load; out_scale / out_shift /
- * res / relu_out: folded inference epilogue (then no statistics). */
-size_t capnet_conv1x1_bf16x6_weight_words(int Cin, int Cout);
-int capnet_conv1x1_bf16x6_bn(long M, int Cout);
-int capnet_conv1x1_bf16x6_pack(const float* w_oi, unsigned* image, int Cout, int Cin, int bn,
-                               capnet_stream_t stream);
-int capnet_conv1x1_fwd_bf16x6(const float* x, long sxb, long sxh, long sxw, const unsigned* image, int bn,
-                              float* y, const float* in_scale, const float* in_shift, int relu_in,
-                              float* part_sum, float* part_sq, int B, int H, int W, int Cin, int Cout,
-                              int stride, const float* out_scale, const float* out_shift,
-                              const float* res, int relu_out, capnet_stream_t stream);
-
 /* 1x1 convolution with fp32-grade results from three f16 MFMA products per multiply (csrc/conv_f16x3.hip):
  * both operands scaled by a power of two and split into two f16 pieces (activations by 2^4, weights by a
  * per-tensor 2^ew kept in the image's header), fp32 accumulation, the accumulators scaled back exactly;
  * rms error against fp64 at or below the f32-MFMA kernels' for |x| < 4094. Needs Cin % 64 == 0,
- * Cout % 64 == 0 and, with a folded input (in_scale), Cin <= 512. Same arguments as the bf16x6 entry
- * points; weights: capnet_conv1x1_f16x3_pack for tile width bn = capnet_conv1x1_f16x3_bn(M, Cout). */
+ * Cout % 64 == 0 and, with a folded input (in_scale), Cin <= 512. in_scale / in_shift / relu_in: BatchNorm + ReLU of the
+ * producer applied on load; out_scale / out_shift / res / relu_out: folded inference epilogue (then no statistics);
+ * statistics rows: capnet_conv1x1_tiles_m(M). Weights: capnet_conv1x1_f16x3_pack for tile width bn = capnet_conv1x1_f16x3_bn(M, Cout). */
 size_t capnet_conv1x1_f16x3_weight_words(int Cin, int Cout);
 int capnet_conv1x1_f16x3_bn(long M, int Cout);
 int capnet_conv1x1_f16x3_pack(const float* w_oi, unsigned* image, int Cout, int Cin, int bn,
@@ -252,23 +231,6 @@ int capnet_conv2d_fwd_kmajor(const float* x, long sxb, long sxh, long sxw, const
                              int relu_in, float* part_sum, float* part_sq, int B, int H, int W,
                              int Cin, int Cout, int KH, int KW, int stride, int pad, int tile,
                              float* slabs, capnet_stream_t stream);
-/* 3x3 / stride 1 / pad 1 convolution as Winograd F(2x2,3x3) on the f32 matrix cores (the conv2
- * of the bottlenecks outside the stride-2 blocks; call site of the arithmetic it replaces:
- * torchvision resnet Bottleneck.conv2 via stylenet/model.py:15-18,24): 2.25x fewer multiplies
- * than the direct sum, 4e-7 rms relative error against fp64. Needs even H and W, Cin % 8 == 0,
- * Cout % 64 == 0, NHWC channel-contiguous input. Weights: capnet_pack_conv_weight_wino
- * (capnet_conv_wino_weight_floats floats). Either raw output + capnet_conv_wino_tiles_m rows of
- * part_sum / part_sq (train-mode BatchNorm statistics), or, with out_scale / out_shift given,
- * y = act(conv * out_scale[n] + out_shift[n]) (folded inference BatchNorm, no statistics). */
-int capnet_pack_conv_weight_wino(const float* w_oihw, float* out, int Cout, int Cin,
-                                 capnet_stream_t stream);
-size_t capnet_conv_wino_weight_floats(int Cin, int Cout);
-int capnet_conv_wino_tiles_m(int B, int H, int W);
-int capnet_conv2d_fwd_wino(const float* x, long sxb, long sxh, long sxw, const float* w_wino, float* y,
-                           const float* in_scale, const float* in_shift, int relu_in,
-                           float* part_sum, float* part_sq, int B, int H, int W, int Cin, int Cout,
-                           const float* out_scale, const float* out_shift, int relu_out,
-                           capnet_stream_t stream);
 /* `slabs` (may be NULL = no tail balancing): scratch of capnet_conv_kmajor_slab_floats floats.
  * When the tile count is not a multiple of the 256 CUs, the tiles past the last full round are
  * cut into K-slices (fp32 partial slabs, summed in a fixed order by a fix-up launch) so that

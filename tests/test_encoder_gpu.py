@@ -164,50 +164,54 @@ def test_folded_bn_inference_trunk_matches_oracle_with_given_statistics(dev, mon
     assert torch.equal(enc.resnet[1].running_mean.cpu(), st["resnet.1.running_mean"])
 
 
-def test_winograd_trunk_agrees_with_the_direct_kernels(dev, monkeypatch):
-    """The 45 stride-1 3x3 convolutions run as Winograd F(2x2,3x3) (csrc/conv_wino.hip); a trunk
-    planned with CAPNET_NO_WINOGRAD=1 runs them through the direct implicit-GEMM kernel. Same
-    weights, same batch of 8: train-mode features, running statistics and the folded-BN inference
-    features must agree far inside the tolerance the fixture is held to."""
+def _trunk_run(dev, monkeypatch, st, imgs, env):
+    """A fresh encoder planned under the given environment switches (read by capnet_trunk_create): plan kinds,
+    train-mode pooled features, one running mean afterwards, inference features."""
     L = capnet._lib.lib()
-    imgs = synthetic.make_batch(8, 100, seed=2)[0].to(dev)
+    for k in ("CAPNET_NO_H3", "CAPNET_NO_STEM_H3", "CAPNET_NO_P3", "CAPNET_NO_TAIL_FUSION"):
+        monkeypatch.delenv(k, raising=False)
+    for k in env:
+        monkeypatch.setenv(k, "1")
+    enc = EncoderCNN(300)
+    enc.load_state_dict({k: v.clone() for k, v in st.items()})
+    enc.to(dev).train()
+    runner = enc._trunk()
+    plan = runner._plan(imgs.shape[0], 224, 224, dev)            # the environment is read here
+    kinds = [L.capnet_trunk_conv_kmajor(plan["handle"], i) for i in range(155)]
+    pooled, _ = runner.forward(imgs.to(dev), True, True, False)
+    rm = enc.resnet[6][5].bn2.running_mean.clone()
+    ev, _ = runner.forward(imgs.to(dev), False, True, False)
+    return kinds, pooled, rm, ev
 
-    monkeypatch.setenv("CAPNET_H3_3X3", "none")       # (by default the 3x3 convolutions run on the split-f16 kernel)
 
-    def run(no_wino):
-        if no_wino:
-            monkeypatch.setenv("CAPNET_NO_WINOGRAD", "1")
-        else:
-            monkeypatch.delenv("CAPNET_NO_WINOGRAD", raising=False)
-        enc = EncoderCNN(300)
-        enc.load_state_dict(_encoder_state(enc))
-        enc.to(dev).train()
-        runner = enc._trunk()
-        plan = runner._plan(8, 224, 224, dev)            # the environment is read here
-        kinds = [L.capnet_trunk_conv_kmajor(plan["handle"], i) for i in range(155)]
-        pooled, _ = runner.forward(imgs, True, True, False)
-        rm = enc.resnet[6][5].bn2.running_mean.clone()
-        ev, _ = runner.forward(imgs, False, True, False)
-        return kinds, pooled, rm, ev
-
-    k_w, p_w, rm_w, e_w = run(False)
-    k_d, p_d, rm_d, e_d = run(True)
-    assert k_w.count(2) == 45 and k_d.count(2) == 0
-    errs = rel_err(p_w, p_d), rel_err(rm_w, rm_d), rel_err(e_w, e_d)
-    print("winograd vs direct trunk: train features %.2e, running mean %.2e, eval features %.2e" % errs)
-    # train-mode BatchNorm over 8 images amplifies rounding differences (both variants are 9.2e-4
-    # from the fp64 fixture at B=3, the fp32 oracle 7.4e-4): measured 5.8e-4 / 1e-6 / 3.4e-5
+@pytest.mark.parametrize("switch", ["CAPNET_NO_H3", "CAPNET_NO_STEM_H3", "CAPNET_NO_P3", "CAPNET_NO_TAIL_FUSION"])
+def test_every_trunk_switch_is_a_working_configuration(dev, monkeypatch, switch):
+    """Each environment switch the library still reads selects other kernels for part of the trunk (the f32-MFMA
+    family for everything / for the stem, the implicit-GEMM kernel for the stride-1 3x3 convolutions, stand-alone
+    bn_add_relu tails). Same weights, same batch of 8: train-mode features, running statistics and inference features
+    must agree with the default plan inside the tolerance the fixture is held to (measured: 6e-4 / 1e-6 / 4e-5 for
+    fp32-grade kernels that differ in summation order)."""
+    enc0 = EncoderCNN(300)
+    st = _encoder_state(enc0)
+    imgs = synthetic.make_batch(8, 100, seed=2)[0]
+    k0, p0, rm0, e0 = _trunk_run(dev, monkeypatch, st, imgs, [])
+    k1, p1, rm1, e1 = _trunk_run(dev, monkeypatch, st, imgs, [switch])
+    assert k0.count(5) == 154 and k0[0] == 6
+    if switch == "CAPNET_NO_H3":
+        assert k1.count(5) == 0 and k1.count(6) == 0
+    if switch == "CAPNET_NO_STEM_H3":
+        assert k1[0] in (0, 1) and k1.count(5) == 154
+    errs = rel_err(p1, p0), rel_err(rm1, rm0), rel_err(e1, e0)
+    print("%s vs default trunk: train features %.2e, running mean %.2e, eval features %.2e" % ((switch,) + errs))
     assert errs[0] < TOL and errs[1] < 1e-4 and errs[2] < 2e-4
 
 
-def test_split_operand_trunks_are_as_close_to_fp64_as_the_f32_trunk(dev, monkeypatch):
-    """The 1x1 convolutions run on split operands (three f16 products, csrc/conv_f16x3.hip; six bf16
-    products where Cin % 64 != 0, csrc/conv_bf16x6.hip). Train-mode features of a batch of 8 against the
-    same network in fp64 on the CPU: neither split may sit further from fp64 than the all-f32-MFMA trunk
-    (CAPNET_NO_X6=1) does -- train-mode BatchNorm over 8 images amplifies every rounding difference, so
-    this is the comparison the whole-step parity tests feel."""
+def test_split_f16_trunk_is_as_close_to_fp64_as_the_f32_trunk(dev, monkeypatch):
+    """The convolutions run on split operands (three f16 products, csrc/conv_f16x3.hip and its siblings).
+    Train-mode features of a batch of 8 against the same network in fp64 on the CPU: the split-f16 trunk may not sit
+    further from fp64 than the all-f32-MFMA trunk (CAPNET_NO_H3=1) does -- train-mode BatchNorm over 8 images
+    amplifies every rounding difference, so this is the comparison the whole-step parity tests feel."""
     from oracle.resnet152_ref import EncoderCNNRef
-    L = capnet._lib.lib()
     B = 8
     imgs = synthetic.make_batch(B, 100, seed=2)[0]
     enc0 = EncoderCNN(300)
@@ -218,26 +222,11 @@ def test_split_operand_trunks_are_as_close_to_fp64_as_the_f32_trunk(dev, monkeyp
     torch.set_num_threads(16)
     with torch.no_grad():
         want = ref.resnet(imgs.double()).reshape(B, -1)
+    k32, p32, _, _ = _trunk_run(dev, monkeypatch, st, imgs, ["CAPNET_NO_H3"])
+    kh, ph, _, _ = _trunk_run(dev, monkeypatch, st, imgs, [])
+    e32, eh = rel_err(p32, want), rel_err(ph, want)
+    print("train features vs fp64 at B=8: f32 MFMA %.2e, split f16 %.2e (layers on f16: %d of 155)" % (e32, eh, kh.count(5) + kh.count(6)))
+    assert k32.count(5) == 0 and kh.count(5) == 154
+    assert eh < 1.5 * e32 + 1e-5
 
-    def run(env):
-        for k in ("CAPNET_NO_X6", "CAPNET_NO_H3"):
-            monkeypatch.delenv(k, raising=False)
-        for k in env:
-            monkeypatch.setenv(k, "1")
-        enc = EncoderCNN(300)
-        enc.load_state_dict({k: v.clone() for k, v in st.items()})
-        enc.to(dev).train()
-        runner = enc._trunk()
-        plan = runner._plan(B, 224, 224, dev)            # the environment is read here
-        kinds = [L.capnet_trunk_conv_kmajor(plan["handle"], i) for i in range(155)]
-        pooled, _ = runner.forward(imgs.to(dev), True, True, False)
-        return kinds, rel_err(pooled, want)
 
-    k32, e32 = run(["CAPNET_NO_X6"])
-    kb, eb = run(["CAPNET_NO_H3"])
-    kh, eh = run([])
-    print("train features vs fp64 at B=8: f32 MFMA %.2e, split bf16 %.2e, split f16 %.2e (layers on f16: %d of 155)"
-          % (e32, eb, eh, kh.count(5)))
-    # default plan: the 104 1x1 and the 50 3x3 convolutions on the split-f16 kernel, the stem on the f32 kernel
-    assert k32.count(4) == 0 and k32.count(5) == 0 and kb.count(5) == 0 and kb.count(4) > 90 and kh.count(5) == 154
-    assert eb < 1.5 * e32 + 1e-5 and eh < 1.5 * e32 + 1e-5

@@ -1,5 +1,5 @@
 """Register-only wave reductions (ds_bpermute vs DPP) beside a conv kernel: does the conv kernel disturb them?
-    python tools/bperm_beside.py [h3|x6|none]"""
+    python tools/bperm_beside.py [h3|none]"""
 import ctypes as C, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import capnet
@@ -14,7 +14,7 @@ x = torch.randn(Bc, H, H, Cin, device=dev); w = torch.randn(Cout, Cin, device=de
 y = torch.empty(M, Cout, device=dev)
 t = L.capnet_conv1x1_tiles_m(M)
 ps, pq = torch.empty(t, Cout, device=dev), torch.empty(t, Cout, device=dev)
-name = {"h3": "f16x3", "x6": "bf16x6"}.get(KIND)
+name = {"h3": "f16x3"}.get(KIND)
 if name:
     img = torch.empty(getattr(L, "capnet_conv1x1_%s_weight_words" % name)(Cin, Cout), dtype=torch.int32, device=dev)
     check(getattr(L, "capnet_conv1x1_%s_pack" % name)(ptr(w), ptr(img), Cout, Cin, 128, C.c_void_p(torch.cuda.current_stream().cuda_stream)))

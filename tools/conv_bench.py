@@ -29,7 +29,6 @@ def main():
     ap.add_argument("--shapes", default=",".join(SHAPES))
     ap.add_argument("--no-pre", action="store_true")
     ap.add_argument("--no-tail", action="store_true", help="disable the K-sliced tail balancing")
-    ap.add_argument("--wino", action="store_true", help="Winograd F(2x2,3x3) kernel on the 3x3 stride-1 shapes")
     ap.add_argument("--h3", action="store_true", help="split-f16 kernel (1x1 and 3x3 shapes with Cin % 64 == 0)")
     ap.add_argument("--v1", action="store_true", help="row-major-weight kernel (conv_f32.hip)")
     args = ap.parse_args()
@@ -54,13 +53,6 @@ def main():
         sc = torch.rand(Cin, device=dev) + 0.5
         sh = torch.randn(Cin, device=dev)
 
-        use_wino = args.wino and k == 3 and stride == 1 and H % 2 == 0
-        if use_wino:
-            ww = ops.pack_conv_weight_wino(w)
-            wt = lib().capnet_conv_wino_tiles_m(B, H, H)
-            ps = torch.empty(wt, Cout, device=dev)
-            pq = torch.empty(wt, Cout, device=dev)
-
         use_h3 = args.h3 and Cin % 64 == 0 and Cout % 64 == 0 and k in (1, 3)
         if use_h3:
             bn = 128 if Cout % 128 == 0 else 64
@@ -75,12 +67,6 @@ def main():
                                                     None if args.no_pre else ptr(sc), None if args.no_pre else ptr(sh),
                                                     0 if args.no_pre else 1, ptr(ps), ptr(pq), B, H, H, Cin, Cout, k, stride, pad,
                                                     None, None, None, 0, current_stream()))
-                return
-            if use_wino:
-                check(lib().capnet_conv2d_fwd_wino(ptr(x), H * H * Cin, H * Cin, Cin, ptr(ww), ptr(y),
-                                                   None if args.no_pre else ptr(sc), None if args.no_pre else ptr(sh),
-                                                   0 if args.no_pre else 1, ptr(ps), ptr(pq), B, H, H, Cin, Cout,
-                                                   None, None, 0, current_stream()))
                 return
             if not args.v1:
                 check(lib().capnet_conv2d_fwd_kmajor(ptr(x), H * H * Cin, H * Cin, Cin, ptr(wp), Kw, ptr(y),
