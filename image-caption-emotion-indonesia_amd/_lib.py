@@ -121,7 +121,8 @@ SIGNATURES = {
     "capnet_att_loss_bwd": (_i, [_vp, _vp, _i, _i, _i, C.c_float, _vp, _vp]),
     "capnet_clamp_adam": (_i, [_i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp),
                                C.POINTER(_vp), C.POINTER(_l), _ip, C.c_float, C.c_float,
-                               C.c_float, C.c_float, C.c_float, _i, _vp]),
+                               C.c_float, C.c_float, C.c_float, _i, _vp, _vp]),
+    "capnet_lstm_persist_set_mode": (_i, [_i]),
     "capnet_trunk_set_timing": (_i, [_vp, _i]),
     "capnet_trunk_collect_timing": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(_l),
                                          C.POINTER(C.c_double)]),

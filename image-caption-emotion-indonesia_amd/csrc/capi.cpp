@@ -280,6 +280,7 @@ int capnet_lstm_step_fused_stamped(const float* h_prev, const float* w_frag, flo
 int capnet_lstm_step_fused_supported(int b, int H) { return lstm_step_fused_supported(b, H) ? 1 : 0; }
 
 int capnet_lstm_persist_supported(int b, int H) { return lstm_persist_supported(b, H) ? 1 : 0; }
+int capnet_lstm_persist_set_mode(int mode) { return lstm_persist_set_mode(mode); }
 size_t capnet_lstm_persist_w_floats(void) { return lstm_persist_w_floats(); }
 size_t capnet_lstm_persist_ctl_ints(void) { return lstm_persist_ctl_ints(); }
 int capnet_lstm_persist_pack(const float* w_cat, float* w_img, int cell, capnet_stream_t stream) {
@@ -455,9 +456,9 @@ int capnet_att_loss_bwd(const float* gout, const float* colsum, int B, int steps
 int capnet_clamp_adam(int n, float* const* params, float* const* grads, float* const* exp_avg,
                       float* const* exp_avg_sq, const long* numel, const int* step, float lr,
                       float beta1, float beta2, float eps, float clip, int write_grad,
-                      capnet_stream_t stream) {
+                      const int* skip_flag, capnet_stream_t stream) {
   return clamp_adam(n, params, grads, exp_avg, exp_avg_sq, numel, step, lr, beta1, beta2, eps, clip,
-                    write_grad, S(stream));
+                    write_grad, skip_flag, S(stream));
 }
 
 int capnet_trunk_set_timing(capnet_trunk_t* t, int enable) {

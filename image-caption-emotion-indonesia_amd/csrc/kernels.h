@@ -249,9 +249,10 @@ int att_loss_fwd(const float* nll, const float* alphas, int B, int steps, int P,
                  float* colsum, float* out, hipStream_t stream);
 int att_loss_bwd(const float* gout, const float* colsum, int B, int steps, int P, float alpha_c,
                  float* dalphas, hipStream_t stream);
+int lstm_persist_set_mode(int mode);
 int clamp_adam(int n_tensors, float* const* params, float* const* grads, float* const* exp_avg,
                float* const* exp_avg_sq, const long* numel, const int* step, float lr, float b1,
-               float b2, float eps, float clip, int write_grad, hipStream_t stream);
+               float b2, float eps, float clip, int write_grad, const int* skip_flag, hipStream_t stream);
 int pack_tensors(int n_tensors, float* const* tensors, const long* numel, float* flat, int dir,
                  float scale, hipStream_t stream);
 int clamp_inplace(float* x, long n, float lo, float hi, hipStream_t stream);

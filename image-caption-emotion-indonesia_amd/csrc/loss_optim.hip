@@ -126,8 +126,11 @@ struct AdamTable {
 // torch.optim.Adam (no amsgrad, no weight decay), single-tensor formulation:
 //   m = lerp(m, g, 1-b1) ; v = b2*v + (1-b2)*g*g
 //   p -= step_size * m / (sqrt(v) / sqrt_bc2 + eps)
+// skip_flag (may be null): the device-side error word of the step (token id out of range, target out of range, a
+// persistent-LSTM wait that expired). While it is non-zero the gradients are garbage: nothing is updated.
 __global__ __launch_bounds__(256) void clamp_adam_kernel(AdamTable t, float b1, float b2, float eps,
-                                                         float clip, int write_grad) {
+                                                         float clip, int write_grad, const int* __restrict__ skip_flag) {
+  if (skip_flag && *skip_flag != 0) return;
   int ti = 0;
   const int blk = blockIdx.x;
   while (ti + 1 < t.count && blk >= t.chunk_start[ti + 1]) ++ti;
@@ -159,7 +162,7 @@ __global__ __launch_bounds__(256) void clamp_adam_kernel(AdamTable t, float b1, 
 
 int clamp_adam(int n_tensors, float* const* params, float* const* grads, float* const* exp_avg,
                float* const* exp_avg_sq, const long* numel, const int* step, float lr, float b1,
-               float b2, float eps, float clip, int write_grad, hipStream_t stream) {
+               float b2, float eps, float clip, int write_grad, const int* skip_flag, hipStream_t stream) {
   CAPNET_REQUIRE(n_tensors >= 0 && (n_tensors == 0 || (params && grads && exp_avg && exp_avg_sq &&
                                                        numel && step)),
                  "clamp_adam: bad argument");
@@ -186,7 +189,7 @@ int clamp_adam(int n_tensors, float* const* params, float* const* grads, float* 
     t.chunk_start[t.count] = chunks;
     if (t.count == 0) break;
     hipLaunchKernelGGL(clamp_adam_kernel, dim3(chunks), dim3(256), 0, stream, t, b1, b2, eps, clip,
-                       write_grad);
+                       write_grad, skip_flag);
   }
   CAPNET_LAUNCH_CHECK();
   return kOk;

@@ -34,8 +34,13 @@
 // the form the guide measures as valid across XCDs. Both modes run the same code; only the cache
 // policy of the h / flag stores differs.
 // Every spin is bounded: a workgroup that waits too long (co-residency lost, a peer died) raises the
-// abort word, sets bit 2 of err_flag and every workgroup leaves; the host sees the flag at its next
-// check and the caller falls back to launch-per-step (CAPNET_NO_PERSISTENT_LSTM=1).
+// abort word, sets bit 2 of err_flag and every workgroup leaves. The hiddens of that segment are then
+// garbage and so is everything computed from them; what keeps the TRAINING STATE intact is that the
+// optimizer kernel reads the same flag and leaves parameters and moments alone while it is set
+// (loss_optim.hip, clamp_adam). The host sees the flag at its next capnet.ops.check_device_errors(),
+// which switches the process to the launch-per-step path (lstm_persist_set_mode) and reports the
+// dropped steps. Both rare paths -- SAFE mode and the abort -- can be forced for tests
+// (lstm_persist_set_mode bits 1 and 2; tests/test_lstm_persist_gpu.py).
 #include <cstdlib>
 
 #include "common.h"
@@ -218,8 +223,9 @@ __global__ __launch_bounds__(256) void lstm_persist_kernel(const PersistArgs a) 
       if (++spins > kSpinBound || ((spins & 255) == 0 && ld_sc1_i32(&ctl[kCtlAbort]) != 0)) break;
       __builtin_amdgcn_s_sleep(4);
     }
+    if (a.cfg & 1024) ok = 0;              // test hook: pretend the handshake timed out
     if (lane == 0) {
-      s_local = ok && same;
+      s_local = ok && same && !(a.cfg & 512);   // (bit 9: SAFE mode forced)
       if (!ok) {
         s_abort = 1;
         st_sc1_i32(&ctl[kCtlAbort], 1);
@@ -428,6 +434,19 @@ __global__ __launch_bounds__(256) void lstm_persist_pack_kernel(const float* __r
 size_t lstm_persist_w_floats() { return 4ul * kPH * kPH; }
 size_t lstm_persist_ctl_ints() { return kCtlInts; }
 
+// Process-wide mode of the persistent path: bit 0 off (launch per step everywhere), bit 1 SAFE mode forced
+// (write-through hand-off although the shard shares an XCD), bit 2 inject a handshake timeout (tests).
+// Starts from CAPNET_NO_PERSISTENT_LSTM=1 in the environment.
+static int& persist_mode() {
+  static int mode = [] { const char* off = getenv("CAPNET_NO_PERSISTENT_LSTM"); return (off && off[0] == '1') ? 1 : 0; }();
+  return mode;
+}
+int lstm_persist_set_mode(int mode) {
+  const int old = persist_mode();
+  if (mode >= 0) persist_mode() = mode & 7;
+  return old;
+}
+
 // One-time residency check: what a cooperative launch would verify (all 256 workgroups can be
 // resident at once on an idle device), without paying its per-launch cost.
 static int persist_device_ok() {
@@ -444,13 +463,12 @@ static int persist_device_ok() {
     (void)hipGetLastError();
     return cached = 0;
   }
-  const char* off = getenv("CAPNET_NO_PERSISTENT_LSTM");
-  cached = (cus >= kPGrid && per_cu >= 1 && !(off && off[0] == '1')) ? 1 : 0;
+  cached = (cus >= kPGrid && per_cu >= 1) ? 1 : 0;
   return cached;
 }
 
 bool lstm_persist_supported(int b, int H) {
-  return H == kPH && b >= 1 && b <= 8 * kPMaxRows && persist_device_ok();
+  return H == kPH && b >= 1 && b <= 8 * kPMaxRows && !(persist_mode() & 1) && persist_device_ok();
 }
 
 int lstm_persist_pack(const float* Wcat, float* Wp, int gi, int gf, int go, int gg, hipStream_t stream) {
@@ -475,7 +493,8 @@ int lstm_persist_run(const float* Wp, float* G, float* Cst, float* hiddens, cons
   a.Wp = Wp; a.G = G; a.Cst = Cst; a.hiddens = hiddens; a.ctl = ctl; a.err_flag = err_flag;
   a.stamps = stamps;
   a.t0 = t0; a.t1 = t1; a.seg = seg;
-  a.cfg = gi | (gf << 2) | (go << 4) | (gg << 6) | ((tanh_out ? 1 : 0) << 8);
+  a.cfg = gi | (gf << 2) | (go << 4) | (gg << 6) | ((tanh_out ? 1 : 0) << 8) | ((persist_mode() & 2) ? 512 : 0) |
+          ((persist_mode() & 4) ? 1024 : 0);
   for (int t = 0; t <= t1; ++t) a.off[t] = off[t];
   int prev = 1 << 30;
   for (int t = (t0 > 0 ? t0 - 1 : 0); t < t1; ++t) {

@@ -43,14 +43,24 @@ def err_flag(device):
     return f
 
 
+_ERR_BITS = {1: "token id out of range", 2: "target out of range",
+             4: "a bounded wait of the persistent LSTM kernel expired (its 256 workgroups were not co-resident in time); "
+                "the process now runs one launch per LSTM step, as CAPNET_NO_PERSISTENT_LSTM=1 does from the start"}
+
+
 def check_device_errors():
-    """Synchronising check of the device-side error flags (call where the loop already syncs)."""
+    """Synchronising check of the device-side error flags (call where the loop already syncs).
+
+    While a flag is set capnet.optim.Adam's update kernel leaves parameters and moments alone (capnet_clamp_adam's
+    skip_flag), so the steps between the fault and this check were DROPPED, not applied with garbage gradients."""
     for f in _err_flags.values():
         v = int(f.item())
         if v:
             f.zero_()
-            raise CapnetError("device-side error flag %d: %s" %
-                              (v, {1: "token id out of range", 2: "target out of range"}.get(v, "?")))
+            if v & 4:
+                _lib.lib().capnet_lstm_persist_set_mode(1)
+            raise CapnetError("device-side error flag %d: %s. The optimizer steps since the previous check were skipped."
+                              % (v, "; ".join(m for b, m in _ERR_BITS.items() if v & b) or "?"))
 
 
 # ---------------------------------------------------------------------------------------
@@ -268,7 +278,8 @@ def pack_conv_weight_stem_f16x3(w_oihw):
 
 def clamp_adam(params, grads, exp_avg, exp_avg_sq, steps, lr, beta1, beta2, eps, clip,
                write_grad=True):
-    """Fused element-wise clamp + Adam over a list of tensors (in place)."""
+    """Fused element-wise clamp + Adam over a list of tensors (in place); a no-op on the device while the
+    device's error word is set (check_device_errors)."""
     n = len(params)
     if n == 0:
         return
@@ -280,7 +291,7 @@ def clamp_adam(params, grads, exp_avg, exp_avg_sq, steps, lr, beta1, beta2, eps,
     check(_lib.lib().capnet_clamp_adam(n, ptr_array(params), ptr_array(grads), ptr_array(exp_avg),
                                        ptr_array(exp_avg_sq), numel, int_array(steps), lr, beta1,
                                        beta2, eps, clip if clip else 0.0, int(write_grad),
-                                       current_stream()), "capnet_clamp_adam")
+                                       ptr(err_flag(params[0].device)), current_stream()), "capnet_clamp_adam")
 
 
 # ---------------------------------------------------------------------------------------

@@ -394,9 +394,15 @@ int capnet_lstm_step_fused_supported(int b, int H);
  *   batch_sizes  [t1] non-increasing rows per step (host array)
  *   ctl          capnet_lstm_persist_ctl_ints() ints, zeroed once before the first segment of a
  *                forward pass; segment = 1, 2, ... numbers the launches that share it
- *   err_flag     bit 2 is set if a bounded wait expired (the results are then invalid)
+ *   err_flag     bit 2 (value 4) is set if a bounded wait expired (the results are then invalid; capnet_clamp_adam
+ *                given the same word skips its update)
  *   stamps       NULL, or ([t1-t0][256][8] + [256][2]) uint64 s_memtime readings (diagnostic instantiation) */
 int capnet_lstm_persist_supported(int b, int H);
+/* Process-wide mode of the persistent path; returns the previous mode, mode < 0 only queries. Bit 0: off (one launch
+ * per step everywhere; the initial value when CAPNET_NO_PERSISTENT_LSTM=1 is in the environment). Bits 1 and 2 force
+ * the two rare paths for tests: the cross-XCD (write-through) hand-off, and a handshake time-out (every workgroup
+ * leaves, err_flag |= 4). */
+int capnet_lstm_persist_set_mode(int mode);
 size_t capnet_lstm_persist_w_floats(void);
 size_t capnet_lstm_persist_ctl_ints(void);
 int capnet_lstm_persist_pack(const float* w_cat, float* w_img, int cell, capnet_stream_t stream);
@@ -446,11 +452,14 @@ int capnet_topk_correct(const float* logits, long ld, int N, int V, const long l
 /* ---- optimiser: utils.clip_gradient (element-wise clamp, stylenet/utils.py:51-60) fused with
  * torch.optim.Adam.step (stylenet/train_multitask.py:166-167,389; no weight decay, no amsgrad).
  * Host arrays of n device pointers / sizes / per-tensor step counts (>= 1, already
- * incremented). clip <= 0 disables the clamp; write_grad != 0 also stores the clamped grad. */
+ * incremented). clip <= 0 disables the clamp; write_grad != 0 also stores the clamped grad.
+ * skip_flag: NULL, or the device error word the step's kernels were given (err_flag): while it is non-zero
+ * the launch leaves parameters, moments and gradients untouched -- a step whose inputs were invalid (token id or
+ * target out of range, an expired wait of the persistent LSTM kernel) is dropped, not applied. */
 int capnet_clamp_adam(int n, float* const* params, float* const* grads, float* const* exp_avg,
                       float* const* exp_avg_sq, const long* numel, const int* step, float lr,
                       float beta1, float beta2, float eps, float clip, int write_grad,
-                      capnet_stream_t stream);
+                      const int* skip_flag, capnet_stream_t stream);
 
 /* targets = pack_padded_sequence(captions, lengths, batch_first=True)[0]
  * (stylenet/train_multitask.py:377-379); batch_sizes is a host array. out: [sum(batch_sizes)]. */

@@ -159,3 +159,65 @@ def test_persistent_rejects_bad_arguments(dev):
     assert L.capnet_lstm_persist_run(*args([4, 4], 1, 1, 1)) != 0        # empty range
     assert L.capnet_lstm_persist_run(*args([4, 4], 0, 2, 0)) != 0        # segment tags start at 1
     assert b"lstm_persist_run" in L.capnet_last_error()
+
+
+@pytest.fixture
+def persist_mode():
+    """Sets capnet_lstm_persist_set_mode for one test and restores the previous mode."""
+    L = capnet.lib()
+    old = L.capnet_lstm_persist_set_mode(-1)
+    yield lambda m: L.capnet_lstm_persist_set_mode(m)
+    L.capnet_lstm_persist_set_mode(old)
+
+
+def test_safe_mode_equals_local_mode(dev, persist_mode):
+    """the cross-XCD form of the hand-off (every h byte and flag stored write-through) is chosen at run
+    time by placement and never ran in the tests. Forced here (mode bit 1): bit-identical to LOCAL mode, also across
+    segment cuts; the control block's diagnostics word says which mode each shard took."""
+    L = capnet.lib()
+    if not L.capnet_lstm_persist_supported(64, H):
+        pytest.skip("persistent kernel not supported on this device")
+    bs = CASES["b96"]
+    W, pre = _case(11, bs)
+    local = _run(dev, W, pre, bs, 1, [(0, len(bs))])
+    persist_mode(2)
+    safe = _run(dev, W, pre, bs, 1, [(0, 3), (3, len(bs))])
+    for a, b in zip(local, safe):
+        assert torch.equal(a, b)
+
+
+def test_abort_path_raises_the_flag_and_every_workgroup_leaves(dev, persist_mode):
+    """An expired wait (injected: mode bit 2) must end the launch -- no workgroup may keep spinning --, set bit 2 of
+    err_flag, and the optimizer kernel given that word must leave the parameters alone. check_device_errors() names
+    the cause and switches the process to the launch-per-step path."""
+    from capnet import ops
+    L = capnet.lib()
+    if not L.capnet_lstm_persist_supported(64, H):
+        pytest.skip("persistent kernel not supported on this device")
+    bs = [64] * 4
+    W, pre = _case(3, bs)
+    persist_mode(4)
+    img = torch.empty(L.capnet_lstm_persist_w_floats(), device=dev)
+    check(L.capnet_lstm_persist_pack(W.to(dev).data_ptr(), img.data_ptr(), 0, current_stream()))
+    G = pre.clone().to(dev)
+    Cst = torch.zeros(sum(bs), H, device=dev)
+    hid = torch.zeros(sum(bs), H, device=dev)
+    ctl = torch.zeros(L.capnet_lstm_persist_ctl_ints(), dtype=torch.int32, device=dev)
+    err = ops.err_flag(dev)
+    err.zero_()
+    check(L.capnet_lstm_persist_run(img.data_ptr(), G.data_ptr(), Cst.data_ptr(), hid.data_ptr(), int_array(bs), 0, 4, H, 0,
+                                    1, ctl.data_ptr(), err.data_ptr(), None, current_stream()))
+    torch.cuda.synchronize()            # returns: every workgroup left
+    assert int(err.item()) == 4
+    # the guarded update is a no-op while the flag is set
+    p = torch.ones(1000, device=dev); g = torch.full((1000,), 0.3, device=dev)
+    m = torch.zeros_like(p); v = torch.zeros_like(p)
+    ops.clamp_adam([p], [g], [m], [v], [1], 1e-2, 0.9, 0.999, 1e-8, 0.5)
+    torch.cuda.synchronize()
+    assert torch.equal(p, torch.ones_like(p)) and float(m.abs().max()) == 0.0
+    with pytest.raises(capnet.CapnetError, match="persistent LSTM"):
+        ops.check_device_errors()
+    assert L.capnet_lstm_persist_set_mode(-1) == 1 and not L.capnet_lstm_persist_supported(64, H)
+    ops.clamp_adam([p], [g], [m], [v], [1], 1e-2, 0.9, 0.999, 1e-8, 0.5)   # flag cleared: the update runs
+    torch.cuda.synchronize()
+    assert float((p - 1).abs().max()) > 1e-3

@@ -54,34 +54,38 @@ def test_three_train_steps_match_the_cpu_oracle(dev, kind, B, steps):
     random.seed(3)
     tfs = [[random.random() < 0.8 for _ in range(max(lengths))] for _ in range(steps)]
 
-    # ---- CPU oracle
-    ref_enc = EncoderCNNRef(300)
-    ref_enc.load_state_dict({k: v.clone() for k, v in est.items()})
-    ref_enc.train()
-    p_ref = {k: v.clone() for k, v in p.items()}
-    opt_ref = S.AdamRef(lr=lr)
-    ref_losses = []
-    for it in range(steps):
-        leaves = {k: v.detach().clone().requires_grad_(True) for k, v in p_ref.items()}
-        feats = ref_enc(imgs)
-        if kind == "nic":
-            logits = D.lstm_forward(leaves, captions, lengths, feats, tfs[it])
-        else:
-            logits = D.factored_lstm_forward(leaves, captions, lengths, feats, tfs[it], "factual")
-        loss = Fn.cross_entropy(logits, D.packed_targets(captions, lengths))
-        ref_enc.zero_grad()
-        loss.backward()
-        grads = {k: v.grad for k, v in leaves.items()}
-        S.clip_gradient_(grads.values(), clip)
-        with torch.no_grad():
-            hp = {("enc." + k): v for k, v in ref_enc.named_parameters() if not k.startswith("resnet.")}
-            hg = {k: v.grad for k, v in hp.items()}
-            S.clip_gradient_([g for g in hg.values() if g is not None], clip)
-            both, both_g = dict(p_ref), dict(grads)
-            both.update(hp)
-            both_g.update(hg)
-            opt_ref.step(both, both_g)
-        ref_losses.append(float(loss.detach()))
+    # ---- CPU oracle (fp32 = the reference's arithmetic; fp64 = the same step without rounding noise)
+    def oracle_losses(dtype):
+        ref_enc = EncoderCNNRef(300)
+        ref_enc.load_state_dict({k: v.clone() for k, v in est.items()})
+        ref_enc.to(dtype).train()
+        p_ref = {k: v.clone().to(dtype) for k, v in p.items()}
+        opt_ref = S.AdamRef(lr=lr)
+        out = []
+        for it in range(steps):
+            leaves = {k: v.detach().clone().requires_grad_(True) for k, v in p_ref.items()}
+            feats = ref_enc(imgs.to(dtype))
+            if kind == "nic":
+                logits = D.lstm_forward(leaves, captions, lengths, feats, tfs[it])
+            else:
+                logits = D.factored_lstm_forward(leaves, captions, lengths, feats, tfs[it], "factual")
+            loss = Fn.cross_entropy(logits, D.packed_targets(captions, lengths))
+            ref_enc.zero_grad()
+            loss.backward()
+            grads = {k: v.grad for k, v in leaves.items()}
+            S.clip_gradient_(grads.values(), clip)
+            with torch.no_grad():
+                hp = {("enc." + k): v for k, v in ref_enc.named_parameters() if not k.startswith("resnet.")}
+                hg = {k: v.grad for k, v in hp.items()}
+                S.clip_gradient_([g for g in hg.values() if g is not None], clip)
+                both, both_g = dict(p_ref), dict(grads)
+                both.update(hp)
+                both_g.update(hg)
+                opt_ref.step(both, both_g)
+            out.append(float(loss.detach()))
+        return out
+    ref_losses = oracle_losses(torch.float32)
+    ref64 = oracle_losses(torch.float64) if B < 64 else None
 
     # ---- GPU product
     enc.to(dev).train()
@@ -94,14 +98,22 @@ def test_three_train_steps_match_the_cpu_oracle(dev, kind, B, steps):
     for it in range(steps):
         got.append(float(train_step(enc, dec, opt, crit, imgs_d, caps_d, lengths, clip, tf_mask=tfs[it]).item()))
     capnet.ops.check_device_errors()
-    print(kind, "oracle", ref_losses, "gpu", got)
-    # The first loss is the forward parity; at BASELINE's batch of 64 every step is held to 1e-4. With 8
-    # images, train-mode BatchNorm through 152 layers leaves any two fp32-grade trunks ~7e-4 apart in their
-    # features (the f32-MFMA, split-bf16 and split-f16 1x1 kernels are that far from each other and from the
-    # network in fp64, tests/test_encoder_gpu.py::test_split_operand_trunks_...; the CPU oracle is no closer),
-    # and Adam's first, sign-like updates carry that into the later losses: measured 1.2e-4 at most.
+    print(kind, "oracle", ref_losses, "gpu", got, "oracle in fp64", ref64)
+    # North star: 1e-4 relative on the training loss. The first loss is the forward parity and is held to it, and at
+    # BASELINE's batch of 64 so is every step. With 8 images, train-mode BatchNorm through 152 layers leaves any two
+    # fp32-grade trunks ~7e-4 apart in their features and Adam's first, sign-like updates carry that into the later
+    # losses -- for the reference's own fp32 arithmetic as much as for this one. That is SHOWN here, not assumed: the
+    # same three steps in float64 say how far the fp32 CPU oracle itself is from the exact step, and the GPU may be no
+    # further from the exact step than 1e-4 or 1.25 x that, whichever is larger (measured: oracle 0.6-1.3e-4, GPU
+    # 0.4-1.2e-4 on steps 2-3).
     for i, (a, b) in enumerate(zip(got, ref_losses)):
-        assert abs(a - b) / abs(b) < (1e-4 if (i == 0 or B >= 64) else 2.5e-4), (got, ref_losses)
+        if i == 0 or B >= 64:
+            assert abs(a - b) / abs(b) < 1e-4, (got, ref_losses)
+        else:
+            e_cpu = abs(b - ref64[i]) / abs(ref64[i])
+            e_gpu = abs(a - ref64[i]) / abs(ref64[i])
+            print("step %d: fp32 oracle vs fp64 %.2e, GPU vs fp64 %.2e, GPU vs fp32 oracle %.2e" % (i, e_cpu, e_gpu, abs(a - b) / abs(b)))
+            assert e_gpu < max(1e-4, 1.25 * e_cpu), (got, ref_losses, ref64)
     assert ref_losses[-1] < ref_losses[0]     # the updates did something
 
 
@@ -517,3 +529,111 @@ def test_decoder_beside_trunk_passes_is_reproducible(dev):
             out, al = fwd()
         torch.cuda.synchronize()
         assert torch.equal(out, ref_out) and torch.equal(al, ref_al), rep
+
+
+def _trunk_passes_in_flight(enc, dev, B, n=3, seed=70):
+    """-> a function that queues one train-mode trunk pass of batch B on each of n streams (as TrunkPipeline does)."""
+    streams = [torch.cuda.Stream() for _ in range(n)]
+    imgs = [synthetic.make_batch(B, 100, seed=seed + k)[0].to(dev) for k in range(n)]
+
+    def launch():
+        for k, st in enumerate(streams):
+            st.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st):
+                enc(imgs[k], slot=k, defer_stats=True)
+    return launch
+
+
+def test_kernels_we_do_not_build_are_exact_beside_the_trunk(dev):
+    """VERDICT r2 / ADVICE r2: this library is built without packed-fp32 VALU because a v_pk_fma_f32 on freshly
+    loaded registers returned stale lanes beside the split-f16 conv kernels (records in
+    profiles/round3_pk_hazard_probe.txt). torch's element-wise kernels and RCCL's reduction are NOT built with that
+    flag, and capnet.parallel overlaps the gradient all-reduce + update with the next trunk passes. Guard: an fp32 sum
+    of two freshly written buffers of the flat gradient's size (14.2 M floats = 57 MB), through torch.add, through an
+    in-place add_ with a scale (the fused multiply-add form) and through dist.all_reduce in a single-rank RCCL group
+    (all RCCL can be asked for on a one-GPU box: it refuses two ranks per device), on a side stream beside three
+    full-size trunk passes -- bitwise equal to the same operations alone, 4 rounds."""
+    import os
+    import torch.distributed as dist
+    n = 14_195_588
+    g = torch.Generator().manual_seed(9)
+    src_a = torch.randn(n, generator=g).to(dev)
+    src_b = torch.randn(n, generator=g).to(dev)
+    a, b = torch.empty_like(src_a), torch.empty_like(src_b)
+    own_group = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29653")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        own_group = True
+
+    def ops_under_test():
+        a.copy_(src_a)                       # freshly written operands, as the packed gradient is
+        b.copy_(src_b)
+        c = torch.add(a, b)
+        d = a.clone().add_(b, alpha=0.37)
+        r = a.clone()
+        dist.all_reduce(r, op=dist.ReduceOp.SUM)
+        return c, d, r
+
+    try:
+        ref = ops_under_test()
+        torch.cuda.synchronize()
+        assert torch.equal(ref[2], src_a)
+        enc = EncoderCNN(300)
+        enc.load_state_dict(_encoder_state(enc))
+        enc.to(dev).train()
+        launch = _trunk_passes_in_flight(enc, dev, 64)
+        launch()
+        torch.cuda.synchronize()            # plans, workspaces, packed weights
+        side = torch.cuda.Stream(priority=-1)
+        for rep in range(4):
+            launch()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                got = ops_under_test()
+            torch.cuda.synchronize()
+            for name, x, y in zip(("torch.add", "add_(alpha)", "all_reduce"), got, ref):
+                assert torch.equal(x, y), (rep, name, int((x != y).sum()))
+    finally:
+        if own_group:
+            dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("B", [64, 96])
+def test_persistent_lstm_beside_full_size_trunk_passes(dev, B):
+    """the persistent LSTM kernel needs its 256 workgroups co-resident while up to three trunk
+    passes' persistent conv workgroups fill the chip. DecoderFactoredLSTM forward at the bench's batch on a side
+    stream beside three full-size trunk passes: bit-equal to alone, no device error flag."""
+    from capnet import ops as cops
+    V = 8192
+    dec = DecoderFactoredLSTM(300, 512, 512, V, 1, dropout=0.0)
+    dec.load_state_dict(synthetic.decoder_state(dec.state_dict(), seed=1234))
+    dec.to(dev).train()
+    enc = EncoderCNN(300)
+    enc.load_state_dict(_encoder_state(enc))
+    enc.to(dev).train()
+    _, caps, lens = synthetic.make_batch(B, V, seed=3)
+    feats = torch.randn(B, 300, generator=torch.Generator().manual_seed(1)).to(dev)
+    cd = caps.to(dev)
+    tf = [True] * max(lens)                 # one persistent launch over all steps
+
+    def fwd():
+        with torch.no_grad():
+            return dec(cd, lens, feats, tf_mask=tf)
+    ref = fwd()
+    torch.cuda.synchronize()
+    cops.check_device_errors()
+    launch = _trunk_passes_in_flight(enc, dev, B)
+    launch()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream(priority=-1)
+    for rep in range(4):
+        launch()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            out = fwd()
+        torch.cuda.synchronize()
+        cops.check_device_errors()
+        assert torch.equal(out, ref), rep
