@@ -83,9 +83,10 @@ def test_reference_loop_body_runs_unmodified_over_the_capnet_modules(dev):
     for a, b in zip(ref_style, fused):
         assert abs(a - b) / abs(b) < 1e-6
     assert fused[-1] < fused[0]
-    # and the parameters the two optimisers left behind agree
+    # and the parameters the two optimisers left behind agree (on average: Adam's first steps are sign-like, so single
+    # elements whose gradient is of the order of eps = 1e-8 move by up to lr either way on a last-bit difference)
     for (k, p), q in zip(decoder.state_dict().items(), dec.state_dict().values()):
-        assert torch.allclose(p, q, rtol=0, atol=2e-6), k
+        assert float((p - q).abs().mean()) < 1e-6 and float((p - q).abs().max()) <= 3 * 2 * LR, k
 
 
 def test_checkpoint_round_trip_resumes_to_the_same_loss(dev, tmp_path):
