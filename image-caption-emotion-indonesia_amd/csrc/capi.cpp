@@ -46,6 +46,11 @@ int capnet_conv1x1_fwd_dma(const float* x, long sxb, long sxh, long sxw, const f
                          S(stream), out_scale, out_shift, res, relu_out);
 }
 
+int capnet_conv1x1_fwd_areg(const float* x, const unsigned* image, int bn, float* y, const float* in_scale,
+                            const float* in_shift, int relu_in, float* part_sum, float* part_sq, long M, int Cin, int Cout,
+                            int in_exp, capnet_stream_t stream) {
+  return conv1x1_fwd_areg(x, image, bn, y, in_scale, in_shift, relu_in, part_sum, part_sq, M, Cin, Cout, in_exp, S(stream));
+}
 size_t capnet_conv1x1_f16x3_weight_words(int Cin, int Cout) { return conv1x1_f16x3_weight_words(Cin, Cout); }
 int capnet_conv1x1_f16x3_bn(long M, int Cout) { return conv1x1_f16x3_bn(M, Cout); }
 int capnet_conv1x1_f16x3_pack(const float* w_oi, unsigned* image, int Cout, int Cin, int bn,

@@ -83,6 +83,11 @@ bool conv3x3_patch_eligible(const float* x, long sxb, long sxh, long sxw, long s
 int conv3x3_fwd_patch(const float* x, const unsigned* wimg, int bn, float* y, const float* in_scale, const float* in_shift,
                       int relu_in, float* part_sum, float* part_sq, int Bn, int H, int W, int Cin, int Cout,
                       hipStream_t stream, bool shared_chip = false);
+// Stride-1 1x1 convolutions with Cin = 64 / 128 / 256 (conv3 of stages 1-3) with the A operand resident in registers
+// (conv1x1_areg.hip): dense [M][Cin] input, same weight image, tile width and statistics rows as conv_fwd_f16x3
+bool conv1x1_areg_eligible(const float* x, long M, int Cin, int Cout, int bn, const float* in_scale, const float* in_shift);
+int conv1x1_fwd_areg(const float* x, const unsigned* wimg, int bn, float* y, const float* in_scale, const float* in_shift,
+                     int relu_in, float* part_sum, float* part_sq, long M, int Cin, int Cout, int in_exp, hipStream_t stream);
 // A bottleneck block's tail (bn_add_relu) fused into the next block's stride-1 1x1 conv1 (conv3x3_patch.hip)
 bool conv1x1_tail_eligible(const float* y3, const float* res, long M, int Cin, int Cout);
 int conv1x1_fwd_tail(const float* y3, const float* s1, const float* t1, const float* res, const float* s2, const float* t2,

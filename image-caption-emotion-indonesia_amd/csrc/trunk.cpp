@@ -54,7 +54,8 @@ struct Trunk {
   // A/B and fallback switches, read from the environment when the plan is made (tests/test_encoder_gpu.py runs a
   // trunk under each): CAPNET_NO_P3=1 the stride-1 3x3 convolutions on the implicit-GEMM kernel instead of the patch
   // kernel; CAPNET_NO_TAIL_FUSION=1 every block tail as its own bn_add_relu launch
-  bool use_patch = true, fuse_tails = true;
+  // CAPNET_NO_AREG=1 conv3 of stages 1-3 on the tiled split-f16 kernel instead of the A-in-registers one
+  bool use_patch = true, fuse_tails = true, use_areg = true;
   bool timing = false;
   int timing_every = 1;   // ... on every N-th pass (an event pair is a bubble in the stream: 310 per pass cost 2.5 % images/s)
   long pass_no = 0;
@@ -79,6 +80,7 @@ int trunk_create(int B, int H, int W, Trunk** out) {
   const bool use_h3 = !env_on("CAPNET_NO_H3");
   t->use_patch = !env_on("CAPNET_NO_P3");
   t->fuse_tails = !env_on("CAPNET_NO_TAIL_FUSION");
+  t->use_areg = !env_on("CAPNET_NO_AREG");
   auto add = [&](int cin, int cout, int k, int stride, int pad, int h, int w, bool activated_input = false) {
     TrunkConv c;
     c.Cin = cin; c.Cout = cout; c.k = k; c.stride = stride; c.pad = pad; c.H = h; c.W = w;
@@ -365,6 +367,11 @@ int conv_bn(const Ctx& c, int i, const float* x, long sxb, long sxh, long sxw, l
     rc = conv3x3_fwd_patch(x, reinterpret_cast<const unsigned*>(c.w[i]), d.tile_n, y, in_scale, in_shift, relu_in,
                            c.train ? psum : nullptr, c.train ? psq : nullptr, c.t->B, d.H, d.W, d.Cin, d.Cout, c.s,
                            !c.t->tail_balance);
+  } else if (d.h3 && d.k == 1 && d.stride == 1 && c.t->use_areg && sxc == 1 && sxw == d.Cin && sxh == (long)d.W * d.Cin &&
+             sxb == (long)d.H * d.W * d.Cin && conv1x1_areg_eligible(x, M, d.Cin, d.Cout, d.tile_n, in_scale, in_shift)) {
+    // short K (conv3 of stages 1-3): the A operand folded and split once per 128 rows, resident in registers
+    rc = conv1x1_fwd_areg(x, reinterpret_cast<const unsigned*>(c.w[i]), d.tile_n, y, in_scale, in_shift, relu_in,
+                          c.train ? psum : nullptr, c.train ? psq : nullptr, M, d.Cin, d.Cout, 0, c.s);
   } else if (d.h3) {
     CAPNET_REQUIRE(conv_f16x3_eligible(x, sxb, sxh, sxw, sxc, c.t->B, d.H, d.W, d.Cin, d.Cout, d.k, d.stride, d.pad, in_scale, in_shift),
                    "trunk: conv %d planned for the split-f16 kernel but its operands are not eligible", i);

@@ -170,6 +170,13 @@ int capnet_conv1x1_fwd_dma(const float* x, long sxb, long sxh, long sxw, const f
  * Cout % 64 == 0 and, with a folded input (in_scale), Cin <= 512. in_scale / in_shift / relu_in: BatchNorm + ReLU of the
  * producer applied on load; out_scale / out_shift / res / relu_out: folded inference epilogue (then no statistics);
  * statistics rows: capnet_conv1x1_tiles_m(M). Weights: capnet_conv1x1_f16x3_pack for tile width bn = capnet_conv1x1_f16x3_bn(M, Cout). */
+/* The same convolution for a dense [M][Cin] input with Cin = 64 / 128 / 256 (conv3 of the bottlenecks of stages 1-3) with
+ * the A operand resident in registers (csrc/conv1x1_areg.hip): every 128 rows are folded and split once for all output
+ * columns. Same weight image (capnet_conv1x1_f16x3_pack, tile width bn), statistics rows capnet_conv1x1_tiles_m(M).
+ * in_exp: the input is scaled by 2^in_exp on its way into the f16 planes and the result scaled back (exact). */
+int capnet_conv1x1_fwd_areg(const float* x, const unsigned* image, int bn, float* y, const float* in_scale,
+                            const float* in_shift, int relu_in, float* part_sum, float* part_sq, long M, int Cin, int Cout,
+                            int in_exp, capnet_stream_t stream);
 size_t capnet_conv1x1_f16x3_weight_words(int Cin, int Cout);
 int capnet_conv1x1_f16x3_bn(long M, int Cout);
 int capnet_conv1x1_f16x3_pack(const float* w_oi, unsigned* image, int Cout, int Cin, int bn,

@@ -168,7 +168,7 @@ def _trunk_run(dev, monkeypatch, st, imgs, env):
     """A fresh encoder planned under the given environment switches (read by capnet_trunk_create): plan kinds,
     train-mode pooled features, one running mean afterwards, inference features."""
     L = capnet._lib.lib()
-    for k in ("CAPNET_NO_H3", "CAPNET_NO_STEM_H3", "CAPNET_NO_P3", "CAPNET_NO_TAIL_FUSION"):
+    for k in ("CAPNET_NO_H3", "CAPNET_NO_STEM_H3", "CAPNET_NO_P3", "CAPNET_NO_TAIL_FUSION", "CAPNET_NO_AREG"):
         monkeypatch.delenv(k, raising=False)
     for k in env:
         monkeypatch.setenv(k, "1")
@@ -184,11 +184,11 @@ def _trunk_run(dev, monkeypatch, st, imgs, env):
     return kinds, pooled, rm, ev
 
 
-@pytest.mark.parametrize("switch", ["CAPNET_NO_H3", "CAPNET_NO_STEM_H3", "CAPNET_NO_P3", "CAPNET_NO_TAIL_FUSION"])
+@pytest.mark.parametrize("switch", ["CAPNET_NO_H3", "CAPNET_NO_STEM_H3", "CAPNET_NO_P3", "CAPNET_NO_TAIL_FUSION", "CAPNET_NO_AREG"])
 def test_every_trunk_switch_is_a_working_configuration(dev, monkeypatch, switch):
     """Each environment switch the library still reads selects other kernels for part of the trunk (the f32-MFMA
     family for everything / for the stem, the implicit-GEMM kernel for the stride-1 3x3 convolutions, stand-alone
-    bn_add_relu tails). Same weights, same batch of 8: train-mode features, running statistics and inference features
+    bn_add_relu tails, the tiled kernel for the short-K conv3). Same weights, same batch of 8: train-mode features, running statistics and inference features
     must agree with the default plan inside the tolerance the fixture is held to (measured: 6e-4 / 1e-6 / 4e-5 for
     fp32-grade kernels that differ in summation order)."""
     enc0 = EncoderCNN(300)

@@ -513,6 +513,60 @@ def test_conv1x1_f16x3_walks_several_tiles_per_workgroup(dev):
     assert rel_err(outs[0][0], ref) < 3e-6
     assert rel_err(outs[0][1].sum(0), ref.sum(0)) < 1e-5 and rel_err(outs[0][2].sum(0), (ref ** 2).sum(0)) < 1e-5
 
+# ---- conv3 of stages 1-3: short K, the A operand resident in registers (csrc/conv1x1_areg.hip) ----
+@pytest.mark.parametrize("M,Cin,Cout,bn,pre,relu,in_exp", [
+    (4 * 14 * 14, 256, 1024, 128, True, 1, 0),      # stage-3 conv3 at batch 4: 7 workgroups, the last one ragged (784 = 6 x 128 + 16)
+    (2 * 28 * 28, 128, 512, 128, True, 1, 0),       # stage 2
+    (3136, 64, 256, 128, True, 1, 0),               # stage 1, one image
+    (300, 256, 128, 64, True, 1, 0),                # tile width 64, three workgroups, ragged
+    (256, 128, 256, 128, False, 0, 0),              # activated input, no fold, no ReLU
+    (384, 256, 256, 128, True, 1, 5),               # input scaled by 2^5 on its way into the f16 planes: the same result
+    (384, 64, 64, 64, False, 1, -3),
+])
+def test_conv1x1_areg_has_fp32_accuracy(dev, M, Cin, Cout, bn, pre, relu, in_exp):
+    g = torch.Generator().manual_seed(M + Cin + Cout + bn)
+    x = torch.randn(M, Cin, generator=g) * torch.exp(torch.randn(M, Cin, generator=g))
+    w = torch.randn(Cout, Cin, generator=g) * 0.1 * torch.exp(torch.randn(Cout, Cin, generator=g))
+    scale = torch.rand(Cin, generator=g) - 0.3 if pre else None
+    shift = torch.randn(Cin, generator=g) if pre else None
+    xin = x * scale + shift if pre else x            # the fold is an fp32 fma
+    if relu:
+        xin = torch.relu(xin)
+    ref = xin.double() @ w.double().t()
+    L = lib()
+    xd, wd = x.to(dev), w.to(dev)
+    img = torch.empty(L.capnet_conv1x1_f16x3_weight_words(Cin, Cout), dtype=torch.int32, device=dev)
+    check(L.capnet_conv1x1_f16x3_pack(ptr(wd), ptr(img), Cout, Cin, bn, current_stream()))
+    tiles = L.capnet_conv1x1_tiles_m(M)
+    sd, hd = (scale.to(dev), shift.to(dev)) if pre else (None, None)
+
+    def run(stats, e):
+        y = torch.full((M, Cout), float("nan"), device=dev)
+        ps = torch.full((tiles, Cout), float("nan"), device=dev) if stats else None
+        pq = torch.full((tiles, Cout), float("nan"), device=dev) if stats else None
+        check(L.capnet_conv1x1_fwd_areg(ptr(xd), ptr(img), bn, ptr(y), ptr(sd), ptr(hd), relu, ptr(ps), ptr(pq), M, Cin, Cout,
+                                        e, current_stream()), "capnet_conv1x1_fwd_areg")
+        return y, ps, pq
+    y, ps, pq = run(True, in_exp)
+    assert rel_err(y, ref) < 3e-6
+    assert rel_err(ps.sum(0), ref.sum(0)) < 1e-5 and rel_err(pq.sum(0), (ref ** 2).sum(0)) < 1e-5
+    # fp32-grade: rms error against fp64 not above the tiled split-f16 kernel's on the same operands
+    rms = lambda t: (((t.double().cpu() - ref) ** 2).mean().sqrt() / (ref ** 2).mean().sqrt()).item()
+    y2 = torch.empty((M, Cout), device=dev)
+    p1, p2 = torch.empty(tiles, Cout, device=dev), torch.empty(tiles, Cout, device=dev)
+    if Cin % 64 == 0 and relu == (1 if pre else relu):
+        check(L.capnet_conv1x1_fwd_f16x3(ptr(xd), M * Cin, M * Cin, Cin, ptr(img), bn, ptr(y2), ptr(sd), ptr(hd), relu if pre else 0,
+                                         ptr(p1), ptr(p2), 1, 1, M, Cin, Cout, 1, None, None, None, 0, current_stream()))
+        if pre or not relu:
+            print("rms vs fp64: A in registers %.2e, tiled kernel %.2e" % (rms(y), rms(y2)))
+            assert rms(y) < 1.25 * rms(y2) + 2e-8
+    y0, _, _ = run(False, in_exp)                     # without statistics: the same output
+    assert torch.equal(y0, y)
+    if in_exp:
+        y1, _, _ = run(False, 0)                      # a power-of-two prescale changes nothing but the f16 pieces' range
+        assert rel_err(y, y1) < 3e-7
+
+
 # ---- 3x3 convolutions through the split-f16 kernel (implicit GEMM over (tap, channel), csrc/conv_f16x3.hip) ----
 @pytest.mark.parametrize("bn", [64, 128])
 @pytest.mark.parametrize("B,H,W,Cin,Cout,stride,pre,epi", [

@@ -540,7 +540,7 @@ def _trunk_passes_in_flight(enc, dev, B, n=3, seed=70):
         for k, st in enumerate(streams):
             st.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(st):
-                enc(imgs[k], slot=k, defer_stats=True)
+                enc.trunk_features(imgs[k], slot=k, defer_stats=True, balance_tails=False)   # as TrunkPipeline queues them
     return launch
 
 
