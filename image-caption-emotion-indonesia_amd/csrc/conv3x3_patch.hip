@@ -78,11 +78,20 @@ __global__ __launch_bounds__(kThreads, KSPLIT ? 2 : 4) void conv3x3_patch_kernel
   constexpr int NT = BN / 64;
   constexpr int MT = KSPLIT ? 2 : 1;                  // 32-row blocks of a wave
   constexpr int kSubB = BN * 2 * 16, kImgB = 4 * kSubB;
-  constexpr int NBR = kImgB / 16 / kThreads;          // 16-B weight cells per thread and step (2 / 1)
+  // The packed weights of a k-step (kImgB bytes, copied verbatim) go global -> LDS by LDS-DMA into a ring of kRing
+  // buffers, kRing - 1 steps ahead of the MFMAs that read them: a step lasts ~400-500 cycles, a weight fetch from L2
+  // ~2 000 under load, and with the weights passing through registers one step ahead (round 2) every step waited for
+  // its fetch (1 970 cycles per step measured on the 14 x 14 maps). The DMA needs no registers for data in flight.
+  constexpr int kRing = 3;                            // (divides the 9 taps of a chunk: buffer = tap % 3, a constant)
+  constexpr int NDMA = kImgB / 1024 / 8;              // 1-KB DMA instructions per wave and step (2 / 1)
+  static_assert(NDMA * 8 * 1024 == kImgB, "weight image per wave");
   constexpr int kXch = KSPLIT ? 8 * NT * 16 * 64 * 4 : 0;       // the pairs' exchange at the end of a tile reuses the buffers
-  constexpr int kLds = kPatch + 2 * kImgB > kXch ? kPatch + 2 * kImgB : kXch;
+  constexpr int kLds = kPatch + kRing * kImgB > kXch ? kPatch + kRing * kImgB : kXch;
   __shared__ __attribute__((aligned(16))) unsigned char lds[kLds];
-  __shared__ float scratch[2][4][BN];
+  // (the column statistics' scratch lies over the patch, which is free by then: with it apart two workgroups would
+  //  no longer fit a CU's 160 KB)
+  float (*const scratch)[4][BN] = reinterpret_cast<float (*)[4][BN]>(lds);
+  static_assert(2 * 4 * BN * 4 <= kPatch, "statistics scratch inside the patch");
   unsigned char* const patch = lds;
   unsigned char* const bbuf = lds + kPatch;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -98,6 +107,8 @@ __global__ __launch_bounds__(kThreads, KSPLIT ? 2 : 4) void conv3x3_patch_kernel
   const int pq = tid & 7;                             // this thread's 4 channels of a chunk: 4 pq .. 4 pq + 3
   const unsigned char* const a_rd = patch + (kq2 * 2 + lh) * kPatchSub + (rows0 + li) * 16;      // + plane, k16, mt, tap offsets
   const unsigned char* const b_rd = bbuf + p_cell(wn * (BN / 2) + li, lh);
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const unsigned lds_b0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)bbuf);
 
   for (int wk = (int)blockIdx.x; wk < total; wk += G) {
     const int id = xcd_remap(wk, total);
@@ -124,7 +135,6 @@ __global__ __launch_bounds__(kThreads, KSPLIT ? 2 : 4) void conv3x3_patch_kernel
     const float* wsrc = reinterpret_cast<const float*>(g.wimg + kHdrWords) + (long)tn * nk * (kImgB / 4);
 
     f32x4 pre[kPL], fs, ft;
-    u4 bre[NBR];
     auto fetch_patch = [&](int c) {
 #pragma unroll
       for (int u = 0; u < kPL; ++u) {
@@ -161,14 +171,12 @@ __global__ __launch_bounds__(kThreads, KSPLIT ? 2 : 4) void conv3x3_patch_kernel
         }
       }
     };
-    auto fetch_b = [&](int kt) {
-      const u4* src = reinterpret_cast<const u4*>(wsrc + (long)kt * (kImgB / 4));
+    // weights of k-step kt -> ring buffer `buf`: wave w moves bytes [w, w + 1) * NDMA KB of the image
+    auto dma_b = [&](int kt, int buf) {
+      const float* src = wsrc + (long)kt * (kImgB / 4);
 #pragma unroll
-      for (int q = 0; q < NBR; ++q) bre[q] = src[tid + kThreads * q];
-    };
-    auto stage_b = [&](int buf) {
-#pragma unroll
-      for (int q = 0; q < NBR; ++q) *reinterpret_cast<u4*>(bbuf + buf * kImgB + (tid + kThreads * q) * 16) = bre[q];
+      for (int q = 0; q < NDMA; ++q)
+        glds16(src, (wave_u * NDMA + q) * 1024 + lane * 16, lds_b0 + (unsigned)(buf * kImgB + (wave_u * NDMA + q) * 1024));
     };
 
     f32x16 acc[MT][NT];
@@ -179,15 +187,14 @@ __global__ __launch_bounds__(kThreads, KSPLIT ? 2 : 4) void conv3x3_patch_kernel
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
-    // k-step s = 9 c + t uses weight buffer s & 1. The weights of step s + 1 are written to the other buffer right BEHIND
-    // the barrier that opens step s (every wave is then through with step s - 1, which read it), from registers loaded a
-    // whole step earlier, and the loads of step s + 2 follow: a barrier never waits for an LDS write issued just before it.
+    // k-step s = 9 c + t reads weight buffer s % kRing; behind the barrier that opens step s (every wave is then through
+    // with step s - 1) the DMA of step s + kRing - 1 is issued into the buffer step s - 1 read.
     auto kt_of = [&](int s2) { const int c2 = s2 / 9; return (s2 - 9 * c2) * nkc + c2; };       // kt = tap * nkc + chunk
     fetch_patch(0);
-    fetch_b(0);
     __syncthreads();                                   // every wave is through with the previous tile's buffers
-    stage_b(0);
-    if (nk > 1) fetch_b(kt_of(1));
+#pragma unroll
+    for (int r = 0; r < kRing - 1; ++r)
+      if (r < nk) dma_b(kt_of(r), r);
     int step = 0;
     for (int c = 0; c < nkc; ++c) {
       if (c > 0) __syncthreads();                      // every wave is through with the previous chunk's patch
@@ -195,10 +202,18 @@ __global__ __launch_bounds__(kThreads, KSPLIT ? 2 : 4) void conv3x3_patch_kernel
       if (c + 1 < nkc) fetch_patch(c + 1);
 #pragma unroll
       for (int t = 0; t < 9; ++t, ++step) {
-        const int buf = step & 1;
+        constexpr int kR = kRing;
+        const int buf = t % kR;                                       // = step % kRing: 9 % kRing == 0
+        // this wave's share of step `step` has landed once at most the DMAs of the kRing - 2 steps behind it are in
+        // flight (vmcnt retires in issue order; anything else the wave has in flight only makes the wait longer)
+        if (step + kRing - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kRing - 2) * NDMA) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (step + 1 < nk) stage_b(buf ^ 1);
-        if (step + 2 < nk) fetch_b((t + 2 < 9) ? (t + 2) * nkc + c : (t + 2 - 9) * nkc + c + 1);
+        // the buffer of step - 1 is free now: the weights of step + kRing - 1 go there
+        if (step + kRing - 1 < nk) {
+          const int s2 = step + kRing - 1, c2 = s2 / 9;
+          dma_b((s2 - 9 * c2) * nkc + c2, (t + kR - 1) % kR);
+        }
         const int toff = ((t / 3) * W + t % 3) * 16;                 // patch position of row 0 under this tap
 #pragma unroll
         for (int gi = 0; gi < (KSPLIT ? 1 : 2); ++gi) {              // k16 groups of this wave: its own one / both
@@ -262,6 +277,7 @@ __global__ __launch_bounds__(kThreads, KSPLIT ? 2 : 4) void conv3x3_patch_kernel
       }
     }
     if (g.part_sum) {
+      __syncthreads();                                 // the patch / the pairs' exchange (under the scratch) have been read for the last time
       const int rb = KSPLIT ? wm * 2 + kq2 : wm;       // the tile's four 32-row blocks
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
