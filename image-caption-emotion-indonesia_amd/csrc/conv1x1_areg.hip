@@ -58,12 +58,12 @@ __device__ __forceinline__ unsigned r_cell(int row, int c) {
 }
 
 template <int KG, bool PRE>
-__global__ __launch_bounds__(256, 2) void conv1x1_areg_kernel(const RArgs g) {
+__global__ __launch_bounds__(256) void conv1x1_areg_kernel(const RArgs g) {
   constexpr int K = 32 * KG, NK16 = 2 * KG;
   constexpr int kGran = KG * 4096;                  // bytes of a granule: KG k-steps x (2 planes x 2 k16 groups) x 1 KB
-  constexpr int NLD = KG;                           // 16-B cells per thread and granule
-  constexpr int NH = NLD > 1 ? NLD / 2 : 1;         // ... fetched in two halves (registers)
-  __shared__ __attribute__((aligned(16))) unsigned char bbuf[2 * kGran];
+  constexpr int kRing = 3;                          // weight granules in LDS: one being multiplied, two on their way
+  constexpr int NDMA = KG;                          // 1-KB LDS-DMA instructions per wave and granule
+  __shared__ __attribute__((aligned(16))) unsigned char bbuf[kRing * kGran];
   __shared__ __attribute__((aligned(16))) float fold[PRE ? 2 * K : 4];
   __shared__ float scratch[2][2][4][RNB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -76,22 +76,23 @@ __global__ __launch_bounds__(256, 2) void conv1x1_areg_kernel(const RArgs g) {
   const unsigned char* const wbase = reinterpret_cast<const unsigned char*>(g.wimg + kHdrWords);
   const long sub_bytes = (long)g.bn * 32;            // one (plane, k16 group) sub-image of a (tn, kt) step
 
-  // ---- weights: thread t moves cell t of piece (t >> 6) of every k-step u: LDS image = [u][piece][1 KB], linear in t
-  u4 bre[NLD];
-  auto b_src = [&](int nb, int u) {
+  // ---- weights: a granule = KG k-steps x 4 pieces (plane, k16 group) of 1 KB, LDS image [k-step][piece][1 KB]. Wave w
+  // moves pieces w KG .. w KG + KG - 1 by LDS-DMA (no registers for data in flight), two granules ahead of the MFMAs:
+  // a granule lasts ~1 500 cycles, a fetch from L2 ~2 000 under load -- through registers, half a granule ahead, every
+  // granule waited twice for its weights (61 us on the 14 x 14 maps; tools/areg_bench.py).
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const unsigned lds_b0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)bbuf);
+  auto dma_b = [&](int nb, int buf) {
     const int tn = nb / gran_per_tn, sub = nb - tn * gran_per_tn;
-    return reinterpret_cast<const u4*>(wbase + (((long)tn * nk + u) * 4 + (tid >> 6)) * sub_bytes + sub * 1024 + (tid & 63) * 16);
-  };
-  auto fetch_b = [&](int nb, int half) {
 #pragma unroll
-    for (int u = half * NH; u < (NLD > 1 ? (half + 1) * NH : 1); ++u) bre[u] = *b_src(nb, u);
+    for (int i = 0; i < NDMA; ++i) {
+      const int pc = wave_u * NDMA + i;             // = k-step * 4 + piece
+      const unsigned char* src = wbase + ((long)tn * nk * 4 + pc) * sub_bytes + sub * 1024;
+      glds16(reinterpret_cast<const float*>(src), lane * 16, lds_b0 + (unsigned)(buf * kGran + pc * 1024));
+    }
   };
-  auto stage_b = [&](int buf, int half) {
-#pragma unroll
-    for (int u = half * NH; u < (NLD > 1 ? (half + 1) * NH : 1); ++u)
-      *reinterpret_cast<u4*>(bbuf + buf * kGran + u * 4096 + tid * 16) = bre[u];
-  };
-  fetch_b(0, 0);       // (the second half follows the A prologue: 128 + 32 + the prologue's own registers do not fit)
+  dma_b(0, 0);
+  if (n_gran > 1) dma_b(1, 1);
 
   // ---- A: this lane's row, k = 16 kk + 8 lh .. + 7 of every k16 group kk, folded and split once
   if (PRE) {
@@ -101,6 +102,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_areg_kernel(const RArgs g) {
       fold[K + i] = g.in_shift[i] * es;
     }
   }
+  const bool full = m0 + RBM <= M;                  // (uniform) every row of this workgroup exists
   const int row = m0 + wave * 32 + li;
   const float* xr = g.x + (long)(row < M ? row : M - 1) * K + 8 * lh;     // rows past M: a valid row, never stored
   h8 ah[NK16], al[NK16];
@@ -144,20 +146,23 @@ __global__ __launch_bounds__(256, 2) void conv1x1_areg_kernel(const RArgs g) {
     }
     __builtin_amdgcn_sched_barrier(0);              // one batch of loads in flight at a time
   }
-  stage_b(0, 0);
-  if (NLD > 1) {
-    fetch_b(0, 1);
-    stage_b(0, 1);
-  }
-  if (n_gran > 1) fetch_b(1, 0);
 
   const unsigned char* const b_rd = bbuf + r_cell(li, lh);
-  const bool full = m0 + RBM <= M;                  // (uniform) every row of this workgroup exists
-  // ---- the column sweep: granule nb is in buffer nb & 1; granule nb + 1 is fetched and written to the other buffer
-  // (nobody reads it between two barriers) while this one is multiplied
+  // ---- the column sweep: granule nb is in ring buffer nb % 3. Behind the barrier that opens it (every wave is then
+  // through with granule nb - 1) the DMA of granule nb + 2 goes into the buffer granule nb - 1 occupied.
+  // Waits are counted: what this wave issued after the DMA of granule nb is, at the top of iteration nb, the 16 stores of
+  // granule nb - 2's epilogue, the NDMA instructions of granule nb + 1 and the 16 stores of granule nb - 1 (full tiles:
+  // every store unconditional; otherwise only the DMAs are counted on -- a smaller count only waits longer).
+  int buf = 0;
   for (int nb = 0; nb < n_gran; ++nb) {
-    const int buf = nb & 1;
+    if (nb + 1 < n_gran) {
+      if (full && nb >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA + 32) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __syncthreads();                                // granule nb is in LDS; every wave is through with granule nb - 1
+    if (nb + 2 < n_gran) dma_b(nb + 2, buf == 0 ? 2 : buf - 1);
     if (nb > 0 && g.part_sum && tid < RNB) {
       // column statistics of the previous granule: the four waves' partial sums
       const float (*sc)[4][RNB] = scratch[(nb - 1) & 1];
@@ -165,37 +170,35 @@ __global__ __launch_bounds__(256, 2) void conv1x1_areg_kernel(const RArgs g) {
       g.part_sum[o] = (sc[0][0][tid] + sc[0][1][tid]) + (sc[0][2][tid] + sc[0][3][tid]);
       g.part_sq[o] = (sc[1][0][tid] + sc[1][1][tid]) + (sc[1][2][tid] + sc[1][3][tid]);
     }
-    f32x16 acc;
+    // Three accumulators, one per product term: an MFMA that accumulates into the result of the one just issued waits
+    // for it (~3 issue slots of this shape, measured: one chain of 48 ran at a third of the rate), three chains do not.
+    f32x16 acc, acc1, acc2;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    h8 bh[2], bl[2];
+    for (int r = 0; r < 16; ++r) acc[r] = acc1[r] = acc2[r] = 0.f;
+    // B fragments run kAhead k16 groups ahead of the MFMAs that use them: with one wave per SIMD nothing else hides the
+    // LDS latency (~250 cycles beside three other waves' reads against 96 cycles of MFMAs per group: one group ahead the
+    // sweep ran at 4 000 cycles per granule, LDS-latency-bound, whatever else was switched off)
+    constexpr int kAhead = NK16 < 4 ? NK16 - 1 : 3, kSets = kAhead + 1;
+    h8 bh[kSets], bl[kSets];
     auto read_b = [&](int kk, int set) {
       const int pc = (kk >> 1) * 4 + (kk & 1);      // piece of plane h; plane l is two pieces on
       bh[set] = *reinterpret_cast<const h8*>(b_rd + buf * kGran + pc * 1024);
       bl[set] = *reinterpret_cast<const h8*>(b_rd + buf * kGran + (pc + 2) * 1024);
     };
-    read_b(0, 0);
+#pragma unroll
+    for (int kk = 0; kk < kAhead; ++kk) read_b(kk, kk % kSets);
 #pragma unroll
     for (int kk = 0; kk < NK16; ++kk) {
-      const int set = kk & 1;
-      if (kk + 1 < NK16) read_b(kk + 1, set ^ 1);
-      if (kk == NK16 / 2) {
-        // the other buffer is free: first half of the next granule's weights to LDS, second half requested
-        if (nb + 1 < n_gran) {
-          stage_b(buf ^ 1, 0);
-          if (NLD > 1) fetch_b(nb + 1, 1);
-        }
-      }
+      const int set = kk % kSets;
+      if (kk + kAhead < NK16) read_b(kk + kAhead, (kk + kAhead) % kSets);
       __builtin_amdgcn_sched_barrier(0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[kk], bh[set], acc, 0, 0, 0);    // l h'
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kk], bl[set], acc, 0, 0, 0);    // h l'
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kk], bh[set], acc, 0, 0, 0);    // h h'
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[kk], bh[set], acc1, 0, 0, 0);    // l h'
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kk], bl[set], acc2, 0, 0, 0);    // h l'
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kk], bh[set], acc, 0, 0, 0);      // h h'
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (nb + 1 < n_gran) {
-      if (NLD > 1) stage_b(buf ^ 1, 1);
-      if (nb + 2 < n_gran) fetch_b(nb + 2, 0);
-    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] += acc1[r] + acc2[r];      // the two small terms first
     // ---- epilogue of the granule: 2^-(ew + ea), store, column statistics of the rows below M
     float cs = 0.f, cq = 0.f;
     {
@@ -224,10 +227,11 @@ __global__ __launch_bounds__(256, 2) void conv1x1_areg_kernel(const RArgs g) {
       cs += __shfl_xor(cs, 32);
       cq += __shfl_xor(cq, 32);
       if (lh == 0) {
-        scratch[buf][0][wave][li] = cs;
-        scratch[buf][1][wave][li] = cq;
+        scratch[nb & 1][0][wave][li] = cs;
+        scratch[nb & 1][1][wave][li] = cq;
       }
     }
+    buf = buf == 2 ? 0 : buf + 1;
   }
   if (g.part_sum) {
     __syncthreads();

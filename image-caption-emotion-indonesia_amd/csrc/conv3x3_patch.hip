@@ -309,10 +309,11 @@ template <int BN>
 __global__ __launch_bounds__(kThreads, 4) void conv1x1_tail_kernel(const PArgs g) {
   constexpr int NT = BN / 64;
   constexpr int kSubB = BN * 2 * 16, kImgB = 4 * kSubB;
-  constexpr int NBR = kImgB / 16 / kThreads;
+  constexpr int kRing = 3;                            // weight buffers: LDS-DMA, two steps ahead (as conv3x3_patch_kernel)
+  constexpr int NDMA = kImgB / 1024 / 8;              // 1-KB DMA instructions per wave and step
   constexpr int kSubA = PBM * 16, kImgA = 8 * kSubA;            // [plane 2][group 4][pixel 128][8 halfs]
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kImgA + 2 * kImgB];
-  __shared__ float scratch[2][4][BN];
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kImgA + kRing * kImgB];
+  static_assert(2 * 4 * BN * 4 <= kImgA, "the statistics' scratch lies over an A buffer (see the end of a tile)");
   unsigned char* const abuf = lds;
   unsigned char* const bbuf = lds + 2 * kImgA;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -326,15 +327,21 @@ __global__ __launch_bounds__(kThreads, 4) void conv1x1_tail_kernel(const PArgs g
   const int pq = tid & 7, ppx = tid >> 3;              // this thread's 4 channels of a chunk and its pixel (and pixel + 64)
   const unsigned char* const a_rd = abuf + lh * kSubA + (wm * 32 + li) * 16;
   const unsigned char* const b_rd = bbuf + p_cell(wn * (BN / 2) + li, lh);
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const unsigned lds_b0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)bbuf);
 
-  f32x4 pre[2], rsd[2], fs, ft, gs, gt;
-  u4 bre[NBR];
+  // Activations run TWO steps ahead in two register sets (a step of this kernel is ~450 cycles of MFMAs; one step ahead,
+  // every step waited ~2 us for its rows of y3 and of the identity: 63 us per launch on the 14 x 14 maps, 32 steps of
+  // 2 us); the BatchNorms' scale / shift of the chunk one step ahead (they come from L2).
+  // (two NAMED register sets and a step body instantiated per set: a run-time index into a register array makes hipcc
+  //  load into a temporary, wait vmcnt(0) and select -- every load completed where it was issued)
+  f32x4 preA[2], rsdA[2], preB[2], rsdB[2], fs, ft, gs, gt;
   auto tile_of = [&](int s, int& tm, int& tn) {
     const int id = xcd_remap((int)blockIdx.x + (s >> kc_sh) * G, total);
     tm = (int)fast_div((unsigned)id, g.tn_mul, g.tn_sh);
     tn = id - tm * g.tiles_n;
   };
-  auto fetch = [&](int s) {
+  auto fetch = [&](int s, f32x4 (&pre)[2], f32x4 (&rsd)[2]) {
     int tm, tn;
     tile_of(s, tm, tn);
     const int c = s & (nkc - 1);
@@ -345,19 +352,28 @@ __global__ __launch_bounds__(kThreads, 4) void conv1x1_tail_kernel(const PArgs g
       pre[u] = *reinterpret_cast<const f32x4*>(g.x + e);
       rsd[u] = *reinterpret_cast<const f32x4*>(g.res + e);
     }
+  };
+  auto fetch_par = [&](int s) {
+    const int c = s & (nkc - 1);
     fs = *reinterpret_cast<const f32x4*>(g.in_scale + c * 32 + 4 * pq);
     ft = *reinterpret_cast<const f32x4*>(g.in_shift + c * 32 + 4 * pq);
     if (g.res_scale) {
       gs = *reinterpret_cast<const f32x4*>(g.res_scale + c * 32 + 4 * pq);
       gt = *reinterpret_cast<const f32x4*>(g.res_shift + c * 32 + 4 * pq);
     }
-    const u4* src = reinterpret_cast<const u4*>(reinterpret_cast<const float*>(g.wimg + kHdrWords) + ((long)tn * nkc + c) * (kImgB / 4));
-#pragma unroll
-    for (int q = 0; q < NBR; ++q) bre[q] = src[tid + kThreads * q];
   };
-  // (the registers hold step s)
-  auto stage = [&](int s) {
-    const int buf = s & 1;
+  // weights of step s -> ring buffer s % 3: wave w moves bytes [w, w + 1) * NDMA KB of the (tn, chunk) image
+  auto dma_b = [&](int s, int buf) {
+    int tm, tn;
+    tile_of(s, tm, tn);
+    const int c = s & (nkc - 1);
+    const float* src = reinterpret_cast<const float*>(g.wimg + kHdrWords) + ((long)tn * nkc + c) * (kImgB / 4);
+#pragma unroll
+    for (int q = 0; q < NDMA; ++q)
+      glds16(src, (wave_u * NDMA + q) * 1024 + lane * 16, lds_b0 + (unsigned)(buf * kImgB + (wave_u * NDMA + q) * 1024));
+  };
+  // (the register set and the parameter registers hold step s)
+  auto stage = [&](int s, const f32x4 (&pre)[2], const f32x4 (&rsd)[2], bool real, int buf) {
     int tm, tn;
     tile_of(s, tm, tn);
     const int c = s & (nkc - 1);
@@ -375,14 +391,12 @@ __global__ __launch_bounds__(kThreads, 4) void conv1x1_tail_kernel(const PArgs g
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e] + rr[e], 0.f);
       const int m = tm * PBM + ppx + 64 * u;
-      if (tn == 0 && m < g.M) *reinterpret_cast<f32x4*>(g.tail_out + (long)m * Cin + c * 32 + 4 * pq) = v;
+      if (real && tn == 0 && m < g.M) *reinterpret_cast<f32x4*>(g.tail_out + (long)m * Cin + c * 32 + 4 * pq) = v;
       h4 h, l;
       p_split4(v, h, l);
       *reinterpret_cast<h4*>(d + (ppx + 64 * u) * 16) = h;
       *reinterpret_cast<h4*>(d + 4 * kSubA + (ppx + 64 * u) * 16) = l;
     }
-#pragma unroll
-    for (int q = 0; q < NBR; ++q) *reinterpret_cast<u4*>(bbuf + buf * kImgB + (tid + kThreads * q) * 16) = bre[q];
   };
 
   f32x16 acc[NT];
@@ -390,14 +404,38 @@ __global__ __launch_bounds__(kThreads, 4) void conv1x1_tail_kernel(const PArgs g
   for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
-  fetch(0);
-  stage(0);
-  if (n_steps > 1) fetch(1);
-  for (int s = 0; s < n_steps; ++s) {
+  dma_b(0, 0);
+  if (n_steps > 1) dma_b(1, 1);
+  fetch(0, preA, rsdA);
+  fetch_par(0);
+  fetch(n_steps > 1 ? 1 : 0, preB, rsdB);
+  stage(0, preA, rsdA, true, 0);
+  fetch_par(n_steps > 1 ? 1 : 0);
+  asm volatile("" ::: "memory");
+  fetch(n_steps > 2 ? 2 : n_steps - 1, preA, rsdA);
+  int rbuf = 0;                                        // s % kRing
+  // one step; (pre, rsd) = the register set that holds step s + 1 and then receives step s + 3
+  auto body = [&](int s, f32x4 (&pre)[2], f32x4 (&rsd)[2]) {
     const int buf = s & 1;
+    // This wave's share of the weights of step s has landed once nothing older than what it issued AFTER that DMA is in
+    // flight (vmcnt retires in issue order). Issued after the DMA of step s, at the least: the parameters of step s and
+    // the rows of step s + 1 (2 + 4 loads, behind the DMA in step s - 2), the DMA of step s + 1, the parameters of step
+    // s + 1 and the rows of step s + 2 (step s - 1). More than that (a second BatchNorm's parameters, the tail's stores,
+    // a tile's epilogue) only makes the wait longer, never shorter. (The loads are issued unconditionally, to the very end.)
+    if (s + 1 < n_steps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(12 + NDMA) : "memory");
+    else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     __syncthreads();                                   // step s is in LDS; every wave is through with step s - 1
-    if (s + 1 < n_steps) stage(s + 1);
-    if (s + 2 < n_steps) fetch(s + 2);
+    // staging first: its waits (the compiler's, for the rows requested two steps ago) then see only the compiler's own
+    // younger loads; a DMA issued ahead of it would be counted as one of them and complete rows too early
+    // (no branches around the loads: past the end they repeat the last step's -- with loads under conditions hipcc's
+    //  wait-count pass merges the paths and falls back to vmcnt(0) in front of every use)
+    const int last = n_steps - 1;
+    stage(s + 1 < last ? s + 1 : last, pre, rsd, s + 1 <= last, buf ^ 1);      // (past the end: into the buffer nobody reads)
+    if (s + 2 <= last) dma_b(s + 2, rbuf == 0 ? kRing - 1 : rbuf - 1);
+    fetch_par(s + 2 < last ? s + 2 : last);
+    asm volatile("" ::: "memory");                   // parameters BEFORE rows in issue order: waiting for them (next step) must not drain the rows
+    fetch(s + 3 < last ? s + 3 : last, pre, rsd);
+    const unsigned char* const b_cur = b_rd + rbuf * kImgB;
 #pragma unroll
     for (int gq = 0; gq < 2; ++gq) {
       h8 af[2], bf[NT][2];
@@ -407,7 +445,7 @@ __global__ __launch_bounds__(kThreads, 4) void conv1x1_tail_kernel(const PArgs g
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int p = 0; p < 2; ++p)
-          bf[nt][p] = *reinterpret_cast<const h8*>(b_rd + buf * kImgB + (p * 2 + gq) * kSubB + nt * 1024);
+          bf[nt][p] = *reinterpret_cast<const h8*>(b_cur + (p * 2 + gq) * kSubB + nt * 1024);
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1], bf[nt][0], acc[nt], 0, 0, 0);    // l h'
@@ -415,6 +453,7 @@ __global__ __launch_bounds__(kThreads, 4) void conv1x1_tail_kernel(const PArgs g
         acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0], bf[nt][0], acc[nt], 0, 0, 0);    // h h'
       }
     }
+    rbuf = rbuf + 1 == kRing ? 0 : rbuf + 1;
     if ((s & (nkc - 1)) == nkc - 1) {
       // ---- end of a tile: 2^-ew, store, column statistics of the rows below M
       int tm, tn;
@@ -438,6 +477,10 @@ __global__ __launch_bounds__(kThreads, 4) void conv1x1_tail_kernel(const PArgs g
         }
       }
       if (g.part_sum) {
+        // scratch = the A buffer this step read: free once every wave is through with the step's MFMAs (the barrier), and
+        // staged into again only behind the next step's barrier
+        __syncthreads();
+        float (*const scratch)[4][BN] = reinterpret_cast<float (*)[4][BN]>(abuf + buf * kImgA);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           cs[nt] += __shfl_xor(cs[nt], 32);
@@ -454,6 +497,10 @@ __global__ __launch_bounds__(kThreads, 4) void conv1x1_tail_kernel(const PArgs g
         }
       }
     }
+  };
+  for (int s = 0; s < n_steps; s += 2) {
+    body(s, preB, rsdB);                               // step s + 1 (odd) lives in set B
+    if (s + 1 < n_steps) body(s + 1, preA, rsdA);
   }
 }
 

@@ -54,8 +54,9 @@ struct Trunk {
   // A/B and fallback switches, read from the environment when the plan is made (tests/test_encoder_gpu.py runs a
   // trunk under each): CAPNET_NO_P3=1 the stride-1 3x3 convolutions on the implicit-GEMM kernel instead of the patch
   // kernel; CAPNET_NO_TAIL_FUSION=1 every block tail as its own bn_add_relu launch
-  // CAPNET_NO_AREG=1 conv3 of stages 1-3 on the tiled split-f16 kernel instead of the A-in-registers one
-  bool use_patch = true, fuse_tails = true, use_areg = true;
+  // CAPNET_AREG=1 conv3 of stages 1-3 on the A-in-registers kernel (conv1x1_areg.hip) instead of the tiled one: built for
+  // VERDICT r2 #4, measured slower in the pipelined step, kept as an option
+  bool use_patch = true, fuse_tails = true, use_areg = false;
   bool timing = false;
   int timing_every = 1;   // ... on every N-th pass (an event pair is a bubble in the stream: 310 per pass cost 2.5 % images/s)
   long pass_no = 0;
@@ -80,7 +81,7 @@ int trunk_create(int B, int H, int W, Trunk** out) {
   const bool use_h3 = !env_on("CAPNET_NO_H3");
   t->use_patch = !env_on("CAPNET_NO_P3");
   t->fuse_tails = !env_on("CAPNET_NO_TAIL_FUSION");
-  t->use_areg = !env_on("CAPNET_NO_AREG");
+  t->use_areg = env_on("CAPNET_AREG");
   auto add = [&](int cin, int cout, int k, int stride, int pad, int h, int w, bool activated_input = false) {
     TrunkConv c;
     c.Cin = cin; c.Cout = cout; c.k = k; c.stride = stride; c.pad = pad; c.H = h; c.W = w;

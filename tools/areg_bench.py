@@ -21,7 +21,7 @@ def competitor(n):
     for _ in range(n):
         check(L.capnet_conv3x3_fwd_patch(ptr(cx), ptr(cimg), 128, ptr(cy), ptr(csc), ptr(csh), 1, ptr(cps), ptr(cpq), B, cside, cside, cch, cch, 1,
                                          C.c_void_p(other.cuda_stream)))
-for side, cin, cout in ((56, 64, 256), (28, 128, 512), (14, 256, 1024)):
+for side, cin, cout in [tuple(int(v) for v in t.split("x")) for t in os.environ.get("AREG_SHAPES", "56x64x256,28x128x512,14x256x1024").split(",")]:
     M = B * side * side
     bn = 128
     x = torch.randn(M, cin, device=dev); w = torch.randn(cout, cin, device=dev) * 0.05
