@@ -41,7 +41,7 @@ SIGNATURES = {
     "capnet_trunk_conv_shape": (_i, [_vp, _i, _ip, _ip, _ip, _ip, _ip]),
     "capnet_trunk_forward": (_i, [_vp, _vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp),
                                   C.POINTER(_vp), C.POINTER(_vp), _i, C.c_float, C.c_float, _vp,
-                                  _vp, _vp, _vp]),
+                                  _vp, _vp, _ip, _vp, _vp]),
     "capnet_trunk_set_tail_balance": (_i, [_vp, _i]),
     "capnet_trunk_update_running": (_i, [_vp, _vp, C.POINTER(_vp), C.POINTER(_vp), C.c_float, _vp]),
     "capnet_pack_conv_weight": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
@@ -65,6 +65,10 @@ SIGNATURES = {
                                       _i, _vp, _vp, _vp, _i, _vp]),
     "capnet_conv3x3_fwd_patch": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "capnet_conv1x1_fwd_tail": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _l, _i, _i, _vp]),
+    "capnet_conv2d_fwd_f16x3_scaled": (_i, [_vp, _l, _l, _l, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i,
+                                            _i, _i, _i, _i, _vp]),
+    "capnet_conv3x3_fwd_patch_scaled": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "capnet_conv1x1_fwd_tail_scaled": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _l, _i, _i, _i, _vp]),
     "capnet_conv_stem_f16x3_weight_words": (_sz, []),
     "capnet_conv_stem_f16x3_part_rows": (_i, [_i, _i, _i]),
     "capnet_conv_stem_f16x3_pack": (_i, [_vp, _vp, _vp]),

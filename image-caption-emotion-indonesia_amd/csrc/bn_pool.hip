@@ -35,7 +35,7 @@ __global__ __launch_bounds__(kFinCh* ROWS) void bn_finalize_kernel(
     double inv_count, double unbias, const float* __restrict__ gamma,
     const float* __restrict__ beta, float* __restrict__ running_mean,
     float* __restrict__ running_var, float momentum, float eps, float* __restrict__ scale,
-    float* __restrict__ shift, float* __restrict__ batch_mean, float* __restrict__ batch_var) {
+    float* __restrict__ shift, float* __restrict__ batch_mean, float* __restrict__ batch_var, int* __restrict__ err) {
   __shared__ double s_sum[ROWS][kFinCh + 1];
   __shared__ double s_sq[ROWS][kFinCh + 1];
   const int cx = threadIdx.x % kFinCh, ry = threadIdx.x / kFinCh;
@@ -68,6 +68,9 @@ __global__ __launch_bounds__(kFinCh* ROWS) void bn_finalize_kernel(
       s += s_sum[r][cx];
       q += s_sq[r][cx];
     }
+    // a non-finite sum of squares = a non-finite output of the convolution: an activation beyond the f16 range of the
+    // split operands (65 504 after the layer's power-of-two prescale), or a genuine fp32 overflow
+    if (err && !(q < __builtin_inf())) atomicOr(err, 8);
     const double mean = s * inv_count;
     double var = q * inv_count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -91,7 +94,7 @@ __global__ __launch_bounds__(kFinCh* ROWS) void bn_finalize_kernel(
 int bn_finalize(const float* part_sum, const float* part_sq, int tiles, int C, long count,
                 const float* gamma, const float* beta, float* running_mean, float* running_var,
                 float momentum, float eps, float* scale, float* shift, hipStream_t stream,
-                float* batch_mean, float* batch_var) {
+                float* batch_mean, float* batch_var, int* err) {
   CAPNET_REQUIRE(part_sum && part_sq && scale && shift && tiles > 0 && C > 0 && count > 0,
                  "bn_finalize: bad argument");
   CAPNET_REQUIRE((batch_mean == nullptr) == (batch_var == nullptr), "bn_finalize: batch stat pair");
@@ -100,15 +103,15 @@ int bn_finalize(const float* part_sum, const float* part_sq, int tiles, int C, l
   if (tiles <= kFinSmallMaxTiles)
     hipLaunchKernelGGL(bn_finalize_kernel<kFinRowsSmall>, dim3(cdiv(C, kFinCh)), dim3(kFinCh * kFinRowsSmall), 0,
                        stream, part_sum, part_sq, tiles, C, inv, unbias, gamma, beta, running_mean,
-                       running_var, momentum, eps, scale, shift, batch_mean, batch_var);
+                       running_var, momentum, eps, scale, shift, batch_mean, batch_var, err);
   else if (tiles <= 512)
     hipLaunchKernelGGL(bn_finalize_kernel<32>, dim3(cdiv(C, kFinCh)), dim3(kFinCh * 32), 0,
                        stream, part_sum, part_sq, tiles, C, inv, unbias, gamma, beta, running_mean,
-                       running_var, momentum, eps, scale, shift, batch_mean, batch_var);
+                       running_var, momentum, eps, scale, shift, batch_mean, batch_var, err);
   else
     hipLaunchKernelGGL(bn_finalize_kernel<kFinRows>, dim3(cdiv(C, kFinCh)), dim3(kFinCh * kFinRows), 0,
                        stream, part_sum, part_sq, tiles, C, inv, unbias, gamma, beta, running_mean,
-                       running_var, momentum, eps, scale, shift, batch_mean, batch_var);
+                       running_var, momentum, eps, scale, shift, batch_mean, batch_var, err);
   CAPNET_LAUNCH_CHECK();
   return kOk;
 }
@@ -333,7 +336,7 @@ int bn_relu_maxpool(const float* y, const float* scale, const float* shift, floa
 // ---- global average pool: [B][HW][C] -> [B][C] --------------------------------------------
 __global__ __launch_bounds__(256) void avgpool_kernel(const float* __restrict__ x,
                                                       float* __restrict__ out, int Bn, int HW,
-                                                      int C, float inv) {
+                                                      int C, float inv, int* __restrict__ err) {
   const int C4 = C / 4;
   const long total = (long)Bn * C4;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -346,15 +349,16 @@ __global__ __launch_bounds__(256) void avgpool_kernel(const float* __restrict__ 
       s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
     }
     s.x *= inv; s.y *= inv; s.z *= inv; s.w *= inv;
+    if (err && !(fabsf(s.x) + fabsf(s.y) + fabsf(s.z) + fabsf(s.w) < __builtin_inff())) atomicOr(err, 8);
     *reinterpret_cast<float4*>(out + (long)b * C + c) = s;
   }
 }
 
-int global_avgpool(const float* x, float* out, int Bn, int HW, int C, hipStream_t stream) {
+int global_avgpool(const float* x, float* out, int Bn, int HW, int C, hipStream_t stream, int* err) {
   CAPNET_REQUIRE(x && out && C % 4 == 0 && HW > 0, "global_avgpool: bad argument");
   const long total = (long)Bn * (C / 4);
   hipLaunchKernelGGL(avgpool_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, x, out, Bn, HW,
-                     C, 1.f / (float)HW);
+                     C, 1.f / (float)HW, err);
   CAPNET_LAUNCH_CHECK();
   return kOk;
 }

@@ -95,6 +95,28 @@ int capnet_conv1x1_fwd_tail(const float* y3, const float* s1, const float* t1, c
                             float* part_sq, long M, int Cin, int Cout, capnet_stream_t stream) {
   return conv1x1_fwd_tail(y3, s1, t1, res, s2, t2, tail_out, image, bn, y, part_sum, part_sq, M, Cin, Cout, S(stream));
 }
+// the same three with the input's power-of-two prescale (capnet.h)
+int capnet_conv2d_fwd_f16x3_scaled(const float* x, long sxb, long sxh, long sxw, const unsigned* image, int bn, float* y,
+                                   const float* in_scale, const float* in_shift, int relu_in, float* part_sum,
+                                   float* part_sq, int B, int H, int W, int Cin, int Cout, int k, int stride, int pad,
+                                   int in_exp, capnet_stream_t stream) {
+  CAPNET_REQUIRE(conv_f16x3_eligible(x, sxb, sxh, sxw, 1, B, H, W, Cin, Cout, k, stride, pad, in_scale, in_shift),
+                 "capnet_conv2d_fwd_f16x3_scaled: operands not eligible");
+  return conv_fwd_f16x3(x, sxb, sxh, sxw, image, bn, y, in_scale, in_shift, relu_in, part_sum, part_sq, B, H, W,
+                        Cin, Cout, k, stride, pad, S(stream), nullptr, nullptr, nullptr, 0, in_exp);
+}
+int capnet_conv3x3_fwd_patch_scaled(const float* x, const unsigned* image, int bn, float* y, const float* in_scale,
+                                    const float* in_shift, int relu_in, float* part_sum, float* part_sq, int B, int H,
+                                    int W, int Cin, int Cout, int shared_chip, int in_exp, capnet_stream_t stream) {
+  return conv3x3_fwd_patch(x, image, bn, y, in_scale, in_shift, relu_in, part_sum, part_sq, B, H, W, Cin, Cout, S(stream),
+                           shared_chip != 0, in_exp);
+}
+int capnet_conv1x1_fwd_tail_scaled(const float* y3, const float* s1, const float* t1, const float* res, const float* s2,
+                                   const float* t2, float* tail_out, const unsigned* image, int bn, float* y,
+                                   float* part_sum, float* part_sq, long M, int Cin, int Cout, int in_exp,
+                                   capnet_stream_t stream) {
+  return conv1x1_fwd_tail(y3, s1, t1, res, s2, t2, tail_out, image, bn, y, part_sum, part_sq, M, Cin, Cout, S(stream), in_exp);
+}
 size_t capnet_conv_stem_f16x3_weight_words(void) { return conv_stem_f16x3_weight_words(); }
 int capnet_conv_stem_f16x3_part_rows(int B, int H, int W) { return conv_stem_f16x3_part_rows(B, H, W); }
 int capnet_conv_stem_f16x3_pack(const float* w_oihw, unsigned* image, capnet_stream_t stream) {
@@ -150,10 +172,10 @@ int capnet_trunk_forward(const capnet_trunk_t* t, const float* images_nchw,
                          const float* const* bn_bias, float* const* bn_running_mean,
                          float* const* bn_running_var, int train, float momentum, float eps,
                          void* workspace, float* out_pooled, float* out_map,
-                         capnet_stream_t stream) {
+                         const int* input_exponents, int* err_flag, capnet_stream_t stream) {
   return trunk_forward(reinterpret_cast<Trunk*>(const_cast<capnet_trunk_t*>(t)), images_nchw, w_packed, bn_weight,
                        bn_bias, bn_running_mean, bn_running_var, train, momentum, eps,
-                       reinterpret_cast<float*>(workspace), out_pooled, out_map, S(stream));
+                       reinterpret_cast<float*>(workspace), out_pooled, out_map, input_exponents, err_flag, S(stream));
 }
 int capnet_trunk_set_tail_balance(const capnet_trunk_t* t, int on) {
   return trunk_set_tail_balance(reinterpret_cast<Trunk*>(const_cast<capnet_trunk_t*>(t)), on);

@@ -49,6 +49,7 @@ struct PArgs {
   float* part_sum;
   float* part_sq;
   int M, Cin, Cout, relu_in, H, W;
+  int in_exp;                // the input enters the f16 planes multiplied by 2^in_exp (undone in the epilogue)
   int tiles_m, tiles_n;
   unsigned tn_mul, tn_sh, hw_mul, hw_sh, w_mul, w_sh;
   // conv1x1_tail_kernel: the block tail it absorbs -- input = relu(x * in_scale + in_shift + res (* res_scale + res_shift)),
@@ -103,7 +104,8 @@ __global__ __launch_bounds__(kThreads, KSPLIT ? 2 : 4) void conv3x3_patch_kernel
   const int W = g.W, Cin = g.Cin;
   const int nkc = Cin / 32, nk = 9 * nkc;
   const int total = g.tiles_m * g.tiles_n, G = (int)gridDim.x;
-  const float oscale = ldexpf(1.f, -(int)g.wimg[0]);
+  const float oscale = ldexpf(1.f, -((int)g.wimg[0] + g.in_exp));
+  const float iscale = ldexpf(1.f, g.in_exp);
   const int pq = tid & 7;                             // this thread's 4 channels of a chunk: 4 pq .. 4 pq + 3
   const unsigned char* const a_rd = patch + (kq2 * 2 + lh) * kPatchSub + (rows0 + li) * 16;      // + plane, k16, mt, tap offsets
   const unsigned char* const b_rd = bbuf + p_cell(wn * (BN / 2) + li, lh);
@@ -151,6 +153,8 @@ __global__ __launch_bounds__(kThreads, KSPLIT ? 2 : 4) void conv3x3_patch_kernel
     };
     auto stage_patch = [&]() {
       unsigned char* d = patch + (pq >> 1) * kPatchSub + (pq & 1) * 8;
+      // the prescale rides in the fold's scale / shift (8 multiplies per thread and chunk; a power of two: exact)
+      const f32x4 fs2 = fs * iscale, ft2 = ft * iscale;
 #pragma unroll
       for (int u = 0; u < kPL; ++u) {
         const int px = (tid >> 3) + (kThreads / 8) * u;
@@ -158,7 +162,9 @@ __global__ __launch_bounds__(kThreads, KSPLIT ? 2 : 4) void conv3x3_patch_kernel
           f32x4 v = pre[u];
           if (g.in_scale) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], fs[e], ft[e]);
+            for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], fs2[e], ft2[e]);
+          } else {
+            v *= iscale;
           }
           if (g.relu_in) {
 #pragma unroll
@@ -323,7 +329,8 @@ __global__ __launch_bounds__(kThreads, 4) void conv1x1_tail_kernel(const PArgs g
   const int total = g.tiles_m * g.tiles_n, G = (int)gridDim.x;
   const int my_tiles = (total - 1 - (int)blockIdx.x) / G + 1;
   const int n_steps = my_tiles * nkc;
-  const float oscale = ldexpf(1.f, -(int)g.wimg[0]);
+  const float oscale = ldexpf(1.f, -((int)g.wimg[0] + g.in_exp));
+  const float iscale = ldexpf(1.f, g.in_exp);
   const int pq = tid & 7, ppx = tid >> 3;              // this thread's 4 channels of a chunk and its pixel (and pixel + 64)
   const unsigned char* const a_rd = abuf + lh * kSubA + (wm * 32 + li) * 16;
   const unsigned char* const b_rd = bbuf + p_cell(wn * (BN / 2) + li, lh);
@@ -393,7 +400,7 @@ __global__ __launch_bounds__(kThreads, 4) void conv1x1_tail_kernel(const PArgs g
       const int m = tm * PBM + ppx + 64 * u;
       if (real && tn == 0 && m < g.M) *reinterpret_cast<f32x4*>(g.tail_out + (long)m * Cin + c * 32 + 4 * pq) = v;
       h4 h, l;
-      p_split4(v, h, l);
+      p_split4(v * iscale, h, l);                      // (the written tail is unscaled; the A operand carries the prescale)
       *reinterpret_cast<h4*>(d + (ppx + 64 * u) * 16) = h;
       *reinterpret_cast<h4*>(d + 4 * kSubA + (ppx + 64 * u) * 16) = l;
     }
@@ -519,15 +526,16 @@ bool conv3x3_patch_eligible(const float* x, long sxb, long sxh, long sxw, long s
 // shared_chip: other kernels run beside this one (several trunk passes in flight)
 int conv3x3_fwd_patch(const float* x, const unsigned* wimg, int bn, float* y, const float* in_scale, const float* in_shift,
                       int relu_in, float* part_sum, float* part_sq, int Bn, int H, int W, int Cin, int Cout,
-                      hipStream_t stream, bool shared_chip) {
-  CAPNET_REQUIRE(x && wimg && y && aligned16(wimg) && (bn == 64 || bn == 128) && Cout % bn == 0, "conv3x3_fwd_patch: bad argument");
+                      hipStream_t stream, bool shared_chip, int in_exp) {
+  CAPNET_REQUIRE(x && wimg && y && aligned16(wimg) && (bn == 64 || bn == 128) && Cout % bn == 0 && in_exp > -64 && in_exp < 64,
+                 "conv3x3_fwd_patch: bad argument");
   CAPNET_REQUIRE(conv3x3_patch_eligible(x, (long)H * W * Cin, (long)W * Cin, Cin, 1, Bn, H, W, Cin, Cout, 3, 1, 1, in_scale, in_shift),
                  "conv3x3_fwd_patch: operands not eligible");
   CAPNET_REQUIRE((in_scale == nullptr) == (in_shift == nullptr) && (part_sum == nullptr) == (part_sq == nullptr),
                  "conv3x3_fwd_patch: scale / shift and statistics come in pairs");
   PArgs a{};
   a.x = x; a.wimg = wimg; a.y = y; a.in_scale = in_scale; a.in_shift = in_shift; a.part_sum = part_sum; a.part_sq = part_sq;
-  a.M = Bn * H * W; a.Cin = Cin; a.Cout = Cout; a.relu_in = relu_in; a.H = H; a.W = W;
+  a.M = Bn * H * W; a.Cin = Cin; a.Cout = Cout; a.relu_in = relu_in; a.H = H; a.W = W; a.in_exp = in_exp;
   a.tiles_m = cdiv(a.M, PBM); a.tiles_n = Cout / bn;
   magic_div((unsigned)a.tiles_n, &a.tn_mul, &a.tn_sh);
   magic_div((unsigned)(H * W), &a.hw_mul, &a.hw_sh);
@@ -564,7 +572,8 @@ bool conv1x1_tail_eligible(const float* y3, const float* res, long M, int Cin, i
 // statistics rows as conv_fwd_f16x3 with k = 1. s2 / t2 null: the identity is used as it is.
 int conv1x1_fwd_tail(const float* y3, const float* s1, const float* t1, const float* res, const float* s2, const float* t2,
                      float* tail_out, const unsigned* wimg, int bn, float* y, float* part_sum, float* part_sq, long M,
-                     int Cin, int Cout, hipStream_t stream) {
+                     int Cin, int Cout, hipStream_t stream, int in_exp) {
+  CAPNET_REQUIRE(in_exp > -64 && in_exp < 64, "conv1x1_fwd_tail: input exponent %d", in_exp);
   CAPNET_REQUIRE(y3 && s1 && t1 && res && tail_out && wimg && y && aligned16(wimg) && aligned16(tail_out) && aligned16(s1) &&
                      aligned16(t1) && (bn == 64 || bn == 128) && Cout % bn == 0 && conv1x1_tail_eligible(y3, res, M, Cin, Cout),
                  "conv1x1_fwd_tail: bad argument");
@@ -573,7 +582,7 @@ int conv1x1_fwd_tail(const float* y3, const float* s1, const float* t1, const fl
   PArgs a{};
   a.x = y3; a.in_scale = s1; a.in_shift = t1; a.res = res; a.res_scale = s2; a.res_shift = t2; a.tail_out = tail_out;
   a.wimg = wimg; a.y = y; a.part_sum = part_sum; a.part_sq = part_sq;
-  a.M = (int)M; a.Cin = Cin; a.Cout = Cout; a.relu_in = 1; a.W = 1;
+  a.M = (int)M; a.Cin = Cin; a.Cout = Cout; a.relu_in = 1; a.W = 1; a.in_exp = in_exp;
   const int nkc = Cin / 32;
   a.H = 0;
   while ((1 << a.H) < nkc) ++a.H;                     // (H carries log2 of the k-steps per tile)

@@ -75,6 +75,7 @@ struct HArgs {
   const float* res;
   int relu_out;
   int M, Cin, Cout, relu_in;
+  int in_exp;                // the input enters the f16 planes multiplied by 2^in_exp (undone in the epilogue)
   int H, W, pad;             // input map and zero padding (3x3 convolutions)
   int tiles_m, tiles_n;
   unsigned tn_mul, tn_sh;
@@ -141,7 +142,8 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const HArgs g) {
   const int my_tiles = (total - 1 - (int)blockIdx.x) / G + 1;
   const int n_it = my_tiles * nk;
   const float* wimg = reinterpret_cast<const float*>(g.wimg + kHdrWords);
-  const float oscale = ldexpf(1.f, -(int)g.wimg[0]);
+  const float oscale = ldexpf(1.f, -((int)g.wimg[0] + g.in_exp));
+  const float iscale = ldexpf(1.f, g.in_exp);
 
   const int arow = tid >> 1, ag = tid & 1;          // A staging: this thread's row and k16 group
 
@@ -174,8 +176,8 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const HArgs g) {
   if (PRE) {
     float* f = reinterpret_cast<float*>(lds + 2 * kStage + 4 * BN * 4);
     for (int i = tid; i < g.Cin; i += 256) {
-      f[i] = g.in_scale[i];
-      f[kFoldMaxH + i] = g.in_shift[i];
+      f[i] = g.in_scale[i] * iscale;               // (a power of two: exact) -- the prescale costs nothing in the loop
+      f[kFoldMaxH + i] = g.in_shift[i] * iscale;
     }
     __syncthreads();
   }
@@ -218,7 +220,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const HArgs g) {
     }
     if (TAPS > 1) {
       R.lo = i_ok ? lo : 0.f;
-      R.hi = i_ok ? (PRE ? __builtin_inff() : 1.f) : 0.f;
+      R.hi = i_ok ? (PRE ? __builtin_inff() : iscale) : 0.f;
     }
     i_sB += kImgB / 4;
     i_sA += HBK;
@@ -266,8 +268,8 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const HArgs g) {
         x0 = fmaxf(x0, lo);
         x1 = fmaxf(x1, lo);
       }
-    } else if (TAPS > 1) {
-      x0 *= bhi;
+    } else {
+      x0 *= bhi;             // without a fold: the prescale (and the 0 of a padding tap)
       x1 *= bhi;
     }
     split2(x0, x1, h, l);
@@ -301,7 +303,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const HArgs g) {
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
       unsigned h, l;
-      stage_pair(x, fs, ft, p, R.lo, R.hi, h, l);
+      stage_pair(x, fs, ft, p, R.lo, TAPS > 1 ? R.hi : iscale, h, l);
       ph[p >> 2][p & 3] = h; pl[p >> 2][p & 3] = l;
     }
     unsigned char* d = lds + stage * kStage + ag * kSubA;
@@ -371,7 +373,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const HArgs g) {
         const int p = phase & 3;
         const float fs[8] = {fsv[0][0], fsv[0][1], fsv[0][2], fsv[0][3], fsv[1][0], fsv[1][1], fsv[1][2], fsv[1][3]};
         const float ft[8] = {ftv[0][0], ftv[0][1], ftv[0][2], ftv[0][3], ftv[1][0], ftv[1][1], ftv[1][2], ftv[1][3]};
-        stage_pair(x + 8 * (phase >> 2), fs, ft, p, R.lo, R.hi, h, l);
+        stage_pair(x + 8 * (phase >> 2), fs, ft, p, R.lo, TAPS > 1 ? R.hi : iscale, h, l);
       }
       asm volatile("" : "+v"(h), "+v"(l));        // (a volatile use keeps the phase's VALU here: pure IR sinks to its ds_write)
       ph[phase >> 2][phase & 3] = h;
@@ -618,8 +620,8 @@ int conv1x1_f16x3_pack(const float* w, unsigned* img, int Cout, int Cin, int bn,
 int conv_fwd_f16x3(const float* x, long sxb, long sxh, long sxw, const unsigned* wimg, int bn, float* y,
                    const float* in_scale, const float* in_shift, int relu_in, float* part_sum, float* part_sq, int Bn,
                    int H, int W, int Cin, int Cout, int k, int stride, int pad, hipStream_t stream,
-                   const float* out_scale, const float* out_shift, const float* res, int relu_out) {
-  CAPNET_REQUIRE(x && wimg && y && stride >= 1, "conv_fwd_f16x3: bad argument");
+                   const float* out_scale, const float* out_shift, const float* res, int relu_out, int in_exp) {
+  CAPNET_REQUIRE(x && wimg && y && stride >= 1 && in_exp > -64 && in_exp < 64, "conv_fwd_f16x3: bad argument");
   CAPNET_REQUIRE(conv_f16x3_eligible(x, sxb, sxh, sxw, 1, Bn, H, W, Cin, Cout, k, stride, pad, in_scale, in_shift) &&
                      aligned16(wimg) && (bn == 64 || bn == 128) && Cout % bn == 0,
                  "conv_fwd_f16x3: operands not eligible");
@@ -631,7 +633,7 @@ int conv_fwd_f16x3(const float* x, long sxb, long sxh, long sxw, const unsigned*
   a.x = x; a.wimg = wimg; a.y = y; a.in_scale = in_scale; a.in_shift = in_shift;
   a.part_sum = part_sum; a.part_sq = part_sq;
   a.out_scale = out_scale; a.out_shift = out_shift; a.res = res; a.relu_out = relu_out;
-  a.M = Bn * OH * OW; a.Cin = Cin; a.Cout = Cout; a.relu_in = relu_in;
+  a.M = Bn * OH * OW; a.Cin = Cin; a.Cout = Cout; a.relu_in = relu_in; a.in_exp = in_exp;
   a.H = H; a.W = W; a.pad = pad;
   a.tiles_m = cdiv(a.M, HBM); a.tiles_n = Cout / bn;
   magic_div((unsigned)a.tiles_n, &a.tn_mul, &a.tn_sh);

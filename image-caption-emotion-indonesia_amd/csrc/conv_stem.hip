@@ -50,7 +50,7 @@ struct StemArgs {
   float* y;
   float* part_sum;
   float* part_sq;
-  int B, H, W, OH, OW, chunks, tiles;
+  int B, H, W, OH, OW, chunks, tiles, in_exp;
   int sxb, sxc, sxh;                       // floats
   unsigned tile_mul, tile_sh;              // segment -> (b oh), chunk
   unsigned oh_mul, oh_sh;                  // (b oh) -> b, oh
@@ -72,7 +72,8 @@ __global__ __launch_bounds__(256, 2) void conv_stem_f16x3_kernel(const StemArgs 
   unsigned char* const xl = lds + kImgBytes;       // staged rows: plane h | plane l
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
-  const float oscale = ldexpf(1.f, -(int)g.wimg[0]);
+  const float oscale = ldexpf(1.f, -((int)g.wimg[0] + g.in_exp));
+  const float iscale = ldexpf(1.f, g.in_exp);
 
   // ---- once per workgroup: weights into LDS, the zero-weight row to zero (its products must be finite)
   {
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(256, 2) void conv_stem_f16x3_kernel(const StemArgs 
       const int r = i / kGroups, q = i - r * kGroups;
       if (r < 21) {
         h4 h, l;
-        split4(pre[u], h, l);
+        split4(pre[u] * iscale, h, l);            // (the image's power-of-two prescale: exact)
         *reinterpret_cast<h4*>(xl + r * kRowDw * 4 + q * 8) = h;
         *reinterpret_cast<h4*>(xl + kPlane + r * kRowDw * 4 + q * 8) = l;
       }
@@ -260,14 +261,15 @@ int conv_stem_f16x3_pack(const float* w_oihw, unsigned* img, hipStream_t stream)
 
 // y [B][OH][OW][64] = conv7x7/2(x NCHW, strides in floats) ; part_sum / part_sq [conv_stem_f16x3_part_rows][64] or null
 int conv_stem_fwd_f16x3(const float* x, long sxb, long sxc, long sxh, const unsigned* wimg, float* y, float* part_sum,
-                        float* part_sq, int Bn, int H, int W, hipStream_t stream) {
-  CAPNET_REQUIRE(x && wimg && y && aligned16(wimg), "conv_stem_fwd_f16x3: bad argument");
+                        float* part_sq, int Bn, int H, int W, hipStream_t stream, int in_exp) {
+  CAPNET_REQUIRE(x && wimg && y && aligned16(wimg) && in_exp > -64 && in_exp < 64, "conv_stem_fwd_f16x3: bad argument");
   CAPNET_REQUIRE(conv_stem_f16x3_eligible(x, sxb, sxc, sxh, 1, Bn, H, W, 3, 64, 7, 2, 3),
                  "conv_stem_fwd_f16x3: operands not eligible (B=%d %dx%d)", Bn, H, W);
   CAPNET_REQUIRE((part_sum == nullptr) == (part_sq == nullptr), "conv_stem_fwd_f16x3: stats pair");
   StemArgs a{};
   a.x = x; a.wimg = wimg; a.y = y; a.part_sum = part_sum; a.part_sq = part_sq;
   a.B = Bn; a.H = H; a.W = W; a.OH = (H - 1) / 2 + 1; a.OW = (W - 1) / 2 + 1;
+  a.in_exp = in_exp;
   a.chunks = cdiv(a.OW, kSeg);
   a.tiles = Bn * a.OH * a.chunks;
   a.sxb = (int)sxb; a.sxc = (int)sxc; a.sxh = (int)sxh;

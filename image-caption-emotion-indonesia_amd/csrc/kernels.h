@@ -66,7 +66,10 @@ int conv_fwd_f16x3(const float* x, long sxb, long sxh, long sxw, const unsigned*
                    const float* in_scale, const float* in_shift, int relu_in, float* part_sum, float* part_sq, int Bn,
                    int H, int W, int Cin, int Cout, int k, int stride, int pad, hipStream_t stream,
                    const float* out_scale = nullptr, const float* out_shift = nullptr, const float* res = nullptr,
-                   int relu_out = 0);
+                   int relu_out = 0, int in_exp = 0);
+// (in_exp, here and below: the input is multiplied by 2^in_exp on its way into the f16 planes -- folded into the
+//  BatchNorm's scale / shift where there is one -- and the accumulators by 2^-in_exp: exact, and what keeps the split
+//  operands inside f16's range whatever the scale of the tensor; chosen per tensor by the trunk)
 // The stem (7x7 stride 2 pad 3, 3 -> 64 channels, NCHW image in, NHWC out) on the same split-f16 arithmetic
 // (conv_stem.hip); statistics partials: one row per workgroup
 bool conv_stem_f16x3_eligible(const float* x, long sxb, long sxc, long sxh, long sxw, int Bn, int H, int W, int Cin,
@@ -75,14 +78,14 @@ size_t conv_stem_f16x3_weight_words();
 int conv_stem_f16x3_part_rows(int Bn, int H, int W);
 int conv_stem_f16x3_pack(const float* w_oihw, unsigned* img, hipStream_t stream);
 int conv_stem_fwd_f16x3(const float* x, long sxb, long sxc, long sxh, const unsigned* wimg, float* y, float* part_sum,
-                        float* part_sq, int Bn, int H, int W, hipStream_t stream);
+                        float* part_sq, int Bn, int H, int W, hipStream_t stream, int in_exp = 0);
 // ... and the stride-1 3x3 ones with the tile's input patch resident in LDS (conv3x3_patch.hip): same weight image,
 // tile width and statistics rows as conv_fwd_f16x3; dense NHWC input
 bool conv3x3_patch_eligible(const float* x, long sxb, long sxh, long sxw, long sxc, int Bn, int H, int W, int Cin,
                             int Cout, int k, int stride, int pad, const float* in_scale, const float* in_shift);
 int conv3x3_fwd_patch(const float* x, const unsigned* wimg, int bn, float* y, const float* in_scale, const float* in_shift,
                       int relu_in, float* part_sum, float* part_sq, int Bn, int H, int W, int Cin, int Cout,
-                      hipStream_t stream, bool shared_chip = false);
+                      hipStream_t stream, bool shared_chip = false, int in_exp = 0);
 // Stride-1 1x1 convolutions with Cin = 64 / 128 / 256 (conv3 of stages 1-3) with the A operand resident in registers
 // (conv1x1_areg.hip): dense [M][Cin] input, same weight image, tile width and statistics rows as conv_fwd_f16x3
 bool conv1x1_areg_eligible(const float* x, long M, int Cin, int Cout, int bn, const float* in_scale, const float* in_shift);
@@ -92,7 +95,7 @@ int conv1x1_fwd_areg(const float* x, const unsigned* wimg, int bn, float* y, con
 bool conv1x1_tail_eligible(const float* y3, const float* res, long M, int Cin, int Cout);
 int conv1x1_fwd_tail(const float* y3, const float* s1, const float* t1, const float* res, const float* s2, const float* t2,
                      float* tail_out, const unsigned* wimg, int bn, float* y, float* part_sum, float* part_sq, long M,
-                     int Cin, int Cout, hipStream_t stream);
+                     int Cin, int Cout, hipStream_t stream, int in_exp = 0);
 size_t conv1x1_f16x3_weight_words(int Cin, int Cout);
 int conv1x1_f16x3_pack(const float* w, unsigned* img, int Cout, int Cin, int bn, hipStream_t stream);
 int conv1x1_fwd_f16x3(const float* x, long sxb, long sxh, long sxw, const unsigned* wimg, int bn, float* y,
@@ -105,7 +108,7 @@ int conv1x1_fwd_f16x3(const float* x, long sxb, long sxh, long sxw, const unsign
 int bn_finalize(const float* part_sum, const float* part_sq, int tiles, int C, long count,
                 const float* gamma, const float* beta, float* running_mean, float* running_var,
                 float momentum, float eps, float* scale, float* shift, hipStream_t stream,
-                float* batch_mean = nullptr, float* batch_var = nullptr);
+                float* batch_mean = nullptr, float* batch_var = nullptr, int* err = nullptr);
 int bn_eval_scale_shift(const float* gamma, const float* beta, const float* rm, const float* rv,
                         float eps, int C, float* scale, float* shift, hipStream_t stream);
 int bn_running_update_multi(int n, const float* const* mean, const float* const* var, float* const* rm,
@@ -118,7 +121,7 @@ int bn_add_relu(const float* y, const float* s1, const float* t1, const float* r
                 hipStream_t stream);
 int bn_relu_maxpool(const float* y, const float* scale, const float* shift, float* out, int Bn,
                     int H, int W, int C, hipStream_t stream);
-int global_avgpool(const float* x, float* out, int Bn, int HW, int C, hipStream_t stream);
+int global_avgpool(const float* x, float* out, int Bn, int HW, int C, hipStream_t stream, int* err = nullptr);
 int adaptive_pool_replicate(const float* x, float* out, int Bn, int S, int OUT, int C,
                             hipStream_t stream);
 int pack_conv_weight_kmajor(const float* w_oihw, float* out, int Cout, int Cin, int KH, int KW,
@@ -147,7 +150,7 @@ int trunk_forward(Trunk* t, const float* images_nchw, const float* const* w_pack
                   const float* const* bn_gamma, const float* const* bn_beta,
                   float* const* bn_rmean, float* const* bn_rvar, int train, float momentum,
                   float eps, float* workspace, float* out_pooled, float* out_map,
-                  hipStream_t stream);
+                  const int* in_exps, int* err_flag, hipStream_t stream);
 
 // seq_kernels.hip
 constexpr int kMaxSteps = 128;

@@ -303,6 +303,9 @@ struct Ctx {
   float* ws;
   hipStream_t s;
   bool eval_ready = false;   // inference: every BatchNorm's (scale, shift) already sits in the workspace (bn_eval_multi)
+  const int* in_exps = nullptr;   // per convolution: power-of-two prescale of its INPUT on the split-f16 kernels (null: none)
+  int* err = nullptr;             // device error word: bit 3 = a non-finite value in the trunk
+  int in_exp(int i) const { return in_exps ? in_exps[i] : 0; }
   float* scale(int i) const { return ws + t->ss_off[i]; }
   float* shift(int i) const { return ws + t->ss_off[i] + t->convs[i].Cout; }
   float* bmean(int i) const { return ws + t->bs_off[i]; }
@@ -356,29 +359,29 @@ int conv_bn(const Ctx& c, int i, const float* x, long sxb, long sxh, long sxw, l
   if (fuse_tail) {
     rc = conv1x1_fwd_tail(tail->y3, tail->s1, tail->t1, tail->res, tail->s2, tail->t2, tail->out,
                           reinterpret_cast<const unsigned*>(c.w[i]), d.tile_n, y, c.train ? psum : nullptr,
-                          c.train ? psq : nullptr, M, d.Cin, d.Cout, c.s);
+                          c.train ? psq : nullptr, M, d.Cin, d.Cout, c.s, c.in_exp(i));
   } else if (d.stem_h3) {
     CAPNET_REQUIRE(!in_scale && conv_stem_f16x3_eligible(x, sxb, sxc, sxh, sxw, c.t->B, d.H, d.W, d.Cin, d.Cout, d.k, d.stride, d.pad),
                    "trunk: the stem is planned for the split-f16 kernel but its operands are not eligible");
     rc = conv_stem_fwd_f16x3(x, sxb, sxc, sxh, reinterpret_cast<const unsigned*>(c.w[i]), y, c.train ? psum : nullptr,
-                             c.train ? psq : nullptr, c.t->B, d.H, d.W, c.s);
+                             c.train ? psq : nullptr, c.t->B, d.H, d.W, c.s, c.in_exp(i));
   } else if (d.h3 && d.k == 3 && c.t->use_patch &&
              conv3x3_patch_eligible(x, sxb, sxh, sxw, sxc, c.t->B, d.H, d.W, d.Cin, d.Cout, d.k, d.stride, d.pad, in_scale, in_shift)) {
     // stride-1 3x3: the tile's input patch staged once instead of once per tap (conv3x3_patch.hip), same weight image
     rc = conv3x3_fwd_patch(x, reinterpret_cast<const unsigned*>(c.w[i]), d.tile_n, y, in_scale, in_shift, relu_in,
                            c.train ? psum : nullptr, c.train ? psq : nullptr, c.t->B, d.H, d.W, d.Cin, d.Cout, c.s,
-                           !c.t->tail_balance);
+                           !c.t->tail_balance, c.in_exp(i));
   } else if (d.h3 && d.k == 1 && d.stride == 1 && c.t->use_areg && sxc == 1 && sxw == d.Cin && sxh == (long)d.W * d.Cin &&
              sxb == (long)d.H * d.W * d.Cin && conv1x1_areg_eligible(x, M, d.Cin, d.Cout, d.tile_n, in_scale, in_shift)) {
     // short K (conv3 of stages 1-3): the A operand folded and split once per 128 rows, resident in registers
     rc = conv1x1_fwd_areg(x, reinterpret_cast<const unsigned*>(c.w[i]), d.tile_n, y, in_scale, in_shift, relu_in,
-                          c.train ? psum : nullptr, c.train ? psq : nullptr, M, d.Cin, d.Cout, 0, c.s);
+                          c.train ? psum : nullptr, c.train ? psq : nullptr, M, d.Cin, d.Cout, c.in_exp(i), c.s);
   } else if (d.h3) {
     CAPNET_REQUIRE(conv_f16x3_eligible(x, sxb, sxh, sxw, sxc, c.t->B, d.H, d.W, d.Cin, d.Cout, d.k, d.stride, d.pad, in_scale, in_shift),
                    "trunk: conv %d planned for the split-f16 kernel but its operands are not eligible", i);
     rc = conv_fwd_f16x3(x, sxb, sxh, sxw, reinterpret_cast<const unsigned*>(c.w[i]), d.tile_n, y, in_scale,
                         in_shift, relu_in, c.train ? psum : nullptr, c.train ? psq : nullptr, c.t->B, d.H,
-                        d.W, d.Cin, d.Cout, d.k, d.stride, d.pad, c.s);
+                        d.W, d.Cin, d.Cout, d.k, d.stride, d.pad, c.s, nullptr, nullptr, nullptr, 0, c.in_exp(i));
   } else if (d.kmajor) {
     CAPNET_REQUIRE(conv_v2_eligible(x, sxb, sxh, sxw, sxc, c.t->B, d.Cin, d.Cout, in_scale, in_shift),
                    "trunk: conv %d planned for the K-major kernel but its operands are not eligible", i);
@@ -402,10 +405,10 @@ int conv_bn(const Ctx& c, int i, const float* x, long sxb, long sxh, long sxw, l
   if (c.train == 2)   // running statistics deferred to trunk_update_running
     return bn_finalize(psum, psq, prows, d.Cout, M, c.gamma[i], c.beta[i],
                        nullptr, nullptr, c.momentum, c.eps, c.scale(i), c.shift(i), c.s, c.bmean(i),
-                       c.bvar(i));
+                       c.bvar(i), c.err);
   if (c.train)
     return bn_finalize(psum, psq, prows, d.Cout, M, c.gamma[i], c.beta[i],
-                       c.rmean[i], c.rvar[i], c.momentum, c.eps, c.scale(i), c.shift(i), c.s);
+                       c.rmean[i], c.rvar[i], c.momentum, c.eps, c.scale(i), c.shift(i), c.s, nullptr, nullptr, c.err);
   if (c.eval_ready) return kOk;
   return bn_eval_scale_shift(c.gamma[i], c.beta[i], c.rmean[i], c.rvar[i], c.eps, d.Cout,
                              c.scale(i), c.shift(i), c.s);
@@ -427,7 +430,7 @@ int conv_folded(const Ctx& c, int i, const float* x, const float* res, int relu,
   if (d.h3) {
     rc = conv_fwd_f16x3(x, sb, sh, sw, reinterpret_cast<const unsigned*>(c.w[i]), d.tile_n, y, nullptr, nullptr,
                         0, nullptr, nullptr, c.t->B, d.H, d.W, d.Cin, d.Cout, d.k, d.stride, d.pad, c.s, c.scale(i),
-                        c.shift(i), res, relu);
+                        c.shift(i), res, relu, c.in_exp(i));
   } else {
     rc = conv2d_fwd_v2(x, sb, sh, sw, c.w[i], d.Kw, y, nullptr, nullptr, 0, nullptr, nullptr,
                        c.t->B, d.H, d.W, d.Cin, d.Cout, d.k, d.k, d.stride, d.pad, 0,
@@ -477,7 +480,7 @@ int trunk_forward_eval(const Ctx& c, const float* images_nchw, float* out_pooled
     const long M = (long)B * d.OH * d.OW;
     if (d.stem_h3)
       rc = conv_stem_fwd_f16x3(images_nchw, (long)3 * d.H * d.W, (long)d.H * d.W, d.W, reinterpret_cast<const unsigned*>(c.w[0]),
-                               Y3, nullptr, nullptr, B, d.H, d.W, c.s);
+                               Y3, nullptr, nullptr, B, d.H, d.W, c.s, c.in_exp(0));
     else
       rc = conv2d_fwd(images_nchw, (long)3 * d.H * d.W, d.W, 1, (long)d.H * d.W, c.w[0], d.Kw, Y3, nullptr,
                       nullptr, 0, nullptr, nullptr, B, d.H, d.W, d.Cin, d.Cout, d.k, d.k, d.stride, d.pad,
@@ -512,7 +515,7 @@ int trunk_forward_eval(const Ctx& c, const float* images_nchw, float* out_pooled
   }
   const int side = t->final_side;
   if (out_pooled) {
-    rc = global_avgpool(X[cur], out_pooled, B, side * side, 2048, c.s);
+    rc = global_avgpool(X[cur], out_pooled, B, side * side, 2048, c.s, c.err);
     if (rc) return rc;
   }
   if (out_map)
@@ -540,13 +543,15 @@ int trunk_forward(Trunk* t, const float* images_nchw, const float* const* w_pack
                   const float* const* bn_gamma, const float* const* bn_beta,
                   float* const* bn_rmean, float* const* bn_rvar, int train, float momentum,
                   float eps, float* workspace, float* out_pooled, float* out_map,
-                  hipStream_t stream) {
+                  const int* in_exps, int* err_flag, hipStream_t stream) {
   CAPNET_REQUIRE(t && images_nchw && w_packed && bn_gamma && bn_beta && bn_rmean && bn_rvar &&
                      workspace,
                  "trunk_forward: null argument");
   CAPNET_REQUIRE(out_pooled || out_map, "trunk_forward: no output requested");
   CAPNET_REQUIRE(aligned16(workspace), "trunk_forward: workspace must be 16-B aligned");
   Ctx c{t, w_packed, bn_gamma, bn_beta, bn_rmean, bn_rvar, train, momentum, eps, workspace, stream};
+  c.in_exps = in_exps;
+  c.err = err_flag;
   t->timing_now = t->timing && (t->pass_no++ % t->timing_every == 0);
   const int B = t->B;
   float* X[2] = {workspace + t->off_x[0], workspace + t->off_x[1]};
@@ -633,7 +638,7 @@ int trunk_forward(Trunk* t, const float* images_nchw, const float* const* w_pack
   }
   const int side = t->final_side;
   if (out_pooled) {
-    rc = global_avgpool(X[cur], out_pooled, B, side * side, 2048, stream);
+    rc = global_avgpool(X[cur], out_pooled, B, side * side, 2048, stream, c.err);
     if (rc) return rc;
   }
   if (out_map) {

@@ -199,6 +199,62 @@ class _TrunkRunner:
                 self.pack_waited.add(st.cuda_stream)
         return self.packed
 
+    def _input_exponents(self, plan, b, h, w):
+        """Per convolution: the power of two its INPUT tensor is multiplied by on its way into the f16 planes of the
+        split-f16 kernels (capnet_trunk_forward's input_exponents), chosen so that the tensor's largest possible
+        value lands in [2^14, 2^15) -- below f16's 65 504 whatever the scale of the BatchNorm parameters, with the
+        typical values far enough above f16's subnormals for their residuals to keep 22 bits.
+
+        The bounds are rigorous in train mode and use nothing but the parameters: a batch-normalised value is at most
+        sqrt(M - 1) standard deviations from its mean (M = B OH OW values per channel), so |bn(y)| <= sqrt(M - 1)
+        max|gamma| + max|beta|; a block's output is bounded by its two summands' bounds. Inference (running
+        statistics) has no such bound: it uses the same exponents and relies on the error word (bit 3) to say so
+        if an activation ever exceeds them. Images are taken as they come (exponent 0): normalised pixels."""
+        key = (b, h, w) + tuple((bn.weight._version, bn.bias._version, bn.weight.data_ptr())
+                                for bn in (self.bns[0], self.bns[len(self.bns) // 2], self.bns[-1]))
+        hit = plan.get("exps")
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        with torch.no_grad():
+            gb = torch.stack([bn.weight.detach().abs().max() for bn in self.bns] +
+                             [bn.bias.detach().abs().max() for bn in self.bns]).cpu().tolist()
+        n = len(self.bns)
+        g, bt = gb[:n], gb[n:]
+
+        def post(i, m):
+            return math.sqrt(max(m - 1, 1)) * g[i] + bt[i]
+
+        def ea(bound):
+            if not (bound > 0.0 and math.isfinite(bound)):
+                return 0
+            return max(-40, min(40, 15 - math.frexp(bound)[1]))      # bound < 2^e  ->  bound 2^(15 - e) in [2^14, 2^15)
+
+        exps = [0] * n
+        oh, ow = (h - 1) // 2 + 1, (w - 1) // 2 + 1                  # stem 7x7 / 2, pad 3
+        a_in = post(0, b * oh * ow)                                  # max-pool of relu(bn(stem))
+        hh, ww = (oh - 1) // 2 + 1, (ow - 1) // 2 + 1                # max-pool 3x3 / 2, pad 1
+        ci = 1
+        for li, blocks in enumerate((3, 8, 36, 3)):
+            for blk in range(blocks):
+                stride = 2 if (blk == 0 and li > 0) else 1
+                i1, i2, i3 = ci, ci + 1, ci + 2
+                idn = ci + 3 if blk == 0 else -1
+                ci += 4 if blk == 0 else 3
+                m_in = b * hh * ww
+                hh, ww = (hh - 1) // stride + 1, (ww - 1) // stride + 1
+                m_out = b * hh * ww
+                exps[i1] = ea(a_in)
+                exps[i2] = ea(post(i1, m_in))
+                exps[i3] = ea(post(i2, m_out))
+                if idn >= 0:
+                    exps[idn] = ea(a_in)
+                    a_in = post(i3, m_out) + post(idn, m_out)
+                else:
+                    a_in = post(i3, m_out) + a_in
+        arr = (C.c_int * n)(*exps)
+        plan["exps"] = (key, arr, exps)
+        return arr
+
     def _tables(self, packed):
         """ctypes pointer tables of the C call (packed weights, BN weight / bias / running mean /
         running var), rebuilt only when a tensor moved: building them is ~1 ms of host time per
@@ -235,13 +291,15 @@ class _TrunkRunner:
             plan["balance_tails"] = bool(balance_tails)
         bn0 = self.bns[0]
         tables = self._tables(packed)
+        exps = self._input_exponents(plan, b, h, w)
+        err = ops.err_flag(dev)
         L = _lib.lib()
 
         def launch(img, pooled, fmap):
             check(L.capnet_trunk_forward(
                 plan["handle"], ptr(img), tables[0], tables[1], tables[2], tables[3], tables[4],
                 (2 if defer_stats else 1) if train else 0, bn0.momentum, bn0.eps,
-                ptr(ws), ptr(pooled), ptr(fmap), current_stream()), "capnet_trunk_forward")
+                ptr(ws), ptr(pooled), ptr(fmap), exps, ptr(err), current_stream()), "capnet_trunk_forward")
 
         def new_outputs():
             p = torch.empty((b, 2048), dtype=torch.float32, device=dev) if want_pooled else None

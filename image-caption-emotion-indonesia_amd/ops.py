@@ -44,6 +44,9 @@ def err_flag(device):
 
 
 _ERR_BITS = {1: "token id out of range", 2: "target out of range",
+             8: "a non-finite value in the ResNet-152 trunk (an activation beyond the range its layer's power-of-two prescale "
+                "allows for the split-f16 operands -- possible only in inference, with running statistics far from the data "
+                "-- or a genuine fp32 overflow)",
              4: "a bounded wait of the persistent LSTM kernel expired (its 256 workgroups were not co-resident in time); "
                 "the process now runs one launch per LSTM step, as CAPNET_NO_PERSISTENT_LSTM=1 does from the start"}
 

@@ -91,13 +91,21 @@ double capnet_trunk_conv_flops(const capnet_trunk_t* t, int i); /* 2*MACs of con
 int capnet_trunk_conv_shape(const capnet_trunk_t* t, int i, int* cout, int* cin, int* ksize,
                             int* stride, int* row_stride);
 /* w_packed / bn_* : HOST arrays of num_convs DEVICE pointers. out_pooled and/or out_map may
- * be NULL (at least one must be given). */
+ * be NULL (at least one must be given).
+ * input_exponents: NULL, or a HOST array of num_convs ints e[i]: convolution i's input tensor is multiplied by 2^e[i] on
+ * its way into the f16 planes of the split-f16 kernels (folded into the preceding BatchNorm's scale / shift where there
+ * is one; exact; undone in the epilogue). What gives the split operands the domain of fp32: the caller derives e[i] from
+ * the BatchNorm parameters so that the tensor's largest possible value sits just below f16's 65 504
+ * (capnet.model._TrunkRunner._input_exponents).
+ * err_flag: NULL, or the device error word: bit 3 (value 8) is set when a convolution's output statistics (train mode)
+ * or the pooled features (inference) are not finite -- an activation beyond the range the exponents allow for, or a
+ * genuine fp32 overflow; never silently inf. */
 int capnet_trunk_forward(const capnet_trunk_t* t, const float* images_nchw,
                          const float* const* w_packed, const float* const* bn_weight,
                          const float* const* bn_bias, float* const* bn_running_mean,
                          float* const* bn_running_var, int train, float momentum, float eps,
                          void* workspace, float* out_pooled, float* out_map,
-                         capnet_stream_t stream);
+                         const int* input_exponents, int* err_flag, capnet_stream_t stream);
 
 /* train == 2 in capnet_trunk_forward: batch statistics as for train == 1, but the running
  * statistics are NOT touched; the pass leaves every BatchNorm's batch mean / unbiased variance in
@@ -219,6 +227,23 @@ int capnet_conv3x3_fwd_patch(const float* x, const unsigned* image, int bn, floa
 int capnet_conv1x1_fwd_tail(const float* y3, const float* s1, const float* t1, const float* res, const float* s2,
                             const float* t2, float* tail_out, const unsigned* image, int bn, float* y, float* part_sum,
                             float* part_sq, long M, int Cin, int Cout, capnet_stream_t stream);
+/* The three entry points above with the input's power-of-two prescale: the input tensor is multiplied by 2^in_exp on its
+ * way into the f16 planes (folded into in_scale / in_shift where given; the tail written by capnet_conv1x1_fwd_tail
+ * stays unscaled) and the accumulators by 2^-in_exp -- exact. With in_exp chosen so that max |input| 2^in_exp lies in
+ * [2^14, 2^15) the result has fp32-grade RELATIVE accuracy whatever the scale of the tensor; without it (in_exp = 0)
+ * inputs beyond 65 504 overflow the f16 pieces and inputs far below 1 lose their residuals to f16's subnormals.
+ * capnet_trunk_forward applies it per tensor (input_exponents). */
+int capnet_conv2d_fwd_f16x3_scaled(const float* x, long sxb, long sxh, long sxw, const unsigned* image, int bn, float* y,
+                                   const float* in_scale, const float* in_shift, int relu_in, float* part_sum,
+                                   float* part_sq, int B, int H, int W, int Cin, int Cout, int k, int stride, int pad,
+                                   int in_exp, capnet_stream_t stream);
+int capnet_conv3x3_fwd_patch_scaled(const float* x, const unsigned* image, int bn, float* y, const float* in_scale,
+                                    const float* in_shift, int relu_in, float* part_sum, float* part_sq, int B, int H,
+                                    int W, int Cin, int Cout, int shared_chip, int in_exp, capnet_stream_t stream);
+int capnet_conv1x1_fwd_tail_scaled(const float* y3, const float* s1, const float* t1, const float* res, const float* s2,
+                                   const float* t2, float* tail_out, const unsigned* image, int bn, float* y,
+                                   float* part_sum, float* part_sq, long M, int Cin, int Cout, int in_exp,
+                                   capnet_stream_t stream);
 
 /* The stem on the same arithmetic (csrc/conv_stem.hip): 7x7, stride 2, pad 3, 3 -> 64 channels; x is the NCHW image
  * (strides in floats, unit stride along W, W % 4 == 0, 16-B aligned rows), y is NHWC [B][OH][OW][64]. Replaces
