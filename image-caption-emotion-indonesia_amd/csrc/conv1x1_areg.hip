@@ -41,6 +41,7 @@ struct RArgs {
   float* part_sum;           // [ceil(M / 128)][Cout]
   float* part_sq;
   int M, Cout, bn, relu_in, in_exp;
+  int* err;                  // error word (launches without statistics check their outputs for non-finite values)
 };
 
 __device__ __forceinline__ void r_split4(const f32x4 v, h4& h, h4& l) {
@@ -223,6 +224,7 @@ __global__ __launch_bounds__(256) void conv1x1_areg_kernel(const RArgs g) {
         }
       }
     }
+    if (!g.part_sum && g.err) flag_nonfinite(cq, g.err);
     if (g.part_sum) {
       cs += __shfl_xor(cs, 32);
       cq += __shfl_xor(cq, 32);
@@ -256,7 +258,8 @@ bool conv1x1_areg_eligible(const float* x, long M, int Cin, int Cout, int bn, co
 // weight image, tile width and statistics rows (conv1x1_tiles_m(M) = ceil(M / 128)) as conv_fwd_f16x3 with k = 1.
 // in_exp: the input is multiplied by 2^in_exp on its way into the f16 planes (exact; undone in the epilogue).
 int conv1x1_fwd_areg(const float* x, const unsigned* wimg, int bn, float* y, const float* in_scale, const float* in_shift,
-                     int relu_in, float* part_sum, float* part_sq, long M, int Cin, int Cout, int in_exp, hipStream_t stream) {
+                     int relu_in, float* part_sum, float* part_sq, long M, int Cin, int Cout, int in_exp, hipStream_t stream,
+                     int* err) {
   CAPNET_REQUIRE(x && wimg && y && aligned16(wimg) && conv1x1_areg_eligible(x, M, Cin, Cout, bn, in_scale, in_shift),
                  "conv1x1_fwd_areg: operands not eligible (Cin=%d Cout=%d bn=%d)", Cin, Cout, bn);
   CAPNET_REQUIRE((in_scale == nullptr) == (in_shift == nullptr) && (part_sum == nullptr) == (part_sq == nullptr),
@@ -264,7 +267,7 @@ int conv1x1_fwd_areg(const float* x, const unsigned* wimg, int bn, float* y, con
   CAPNET_REQUIRE(in_exp > -64 && in_exp < 64, "conv1x1_fwd_areg: input exponent %d", in_exp);
   RArgs a{};
   a.x = x; a.wimg = wimg; a.y = y; a.in_scale = in_scale; a.in_shift = in_shift; a.part_sum = part_sum; a.part_sq = part_sq;
-  a.M = (int)M; a.Cout = Cout; a.bn = bn; a.relu_in = relu_in; a.in_exp = in_exp;
+  a.M = (int)M; a.Cout = Cout; a.bn = bn; a.relu_in = relu_in; a.in_exp = in_exp; a.err = err;
   const dim3 grid(cdiv((int)M, RBM)), block(256);
 #define CAPNET_AREG_LAUNCH(KG_)                                                                        \
   do {                                                                                                \

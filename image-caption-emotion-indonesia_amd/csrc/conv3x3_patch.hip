@@ -50,6 +50,7 @@ struct PArgs {
   float* part_sq;
   int M, Cin, Cout, relu_in, H, W;
   int in_exp;                // the input enters the f16 planes multiplied by 2^in_exp (undone in the epilogue)
+  int* err;                  // error word (launches without statistics check their outputs for non-finite values)
   int tiles_m, tiles_n;
   unsigned tn_mul, tn_sh, hw_mul, hw_sh, w_mul, w_sh;
   // conv1x1_tail_kernel: the block tail it absorbs -- input = relu(x * in_scale + in_shift + res (* res_scale + res_shift)),
@@ -282,6 +283,12 @@ __global__ __launch_bounds__(kThreads, KSPLIT ? 2 : 4) void conv3x3_patch_kernel
         }
       }
     }
+    if (!g.part_sum && g.err) {
+      float t = 0.f;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) t += cq[nt];     // sums of squares of what this thread stored
+      flag_nonfinite(t, g.err);
+    }
     if (g.part_sum) {
       __syncthreads();                                 // the patch / the pairs' exchange (under the scratch) have been read for the last time
       const int rb = KSPLIT ? wm * 2 + kq2 : wm;       // the tile's four 32-row blocks
@@ -483,6 +490,12 @@ __global__ __launch_bounds__(kThreads, 4) void conv1x1_tail_kernel(const PArgs g
           }
         }
       }
+      if (!g.part_sum && g.err) {
+        float t = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) t += cq[nt];
+        flag_nonfinite(t, g.err);
+      }
       if (g.part_sum) {
         // scratch = the A buffer this step read: free once every wave is through with the step's MFMAs (the barrier), and
         // staged into again only behind the next step's barrier
@@ -526,7 +539,7 @@ bool conv3x3_patch_eligible(const float* x, long sxb, long sxh, long sxw, long s
 // shared_chip: other kernels run beside this one (several trunk passes in flight)
 int conv3x3_fwd_patch(const float* x, const unsigned* wimg, int bn, float* y, const float* in_scale, const float* in_shift,
                       int relu_in, float* part_sum, float* part_sq, int Bn, int H, int W, int Cin, int Cout,
-                      hipStream_t stream, bool shared_chip, int in_exp) {
+                      hipStream_t stream, bool shared_chip, int in_exp, int* err) {
   CAPNET_REQUIRE(x && wimg && y && aligned16(wimg) && (bn == 64 || bn == 128) && Cout % bn == 0 && in_exp > -64 && in_exp < 64,
                  "conv3x3_fwd_patch: bad argument");
   CAPNET_REQUIRE(conv3x3_patch_eligible(x, (long)H * W * Cin, (long)W * Cin, Cin, 1, Bn, H, W, Cin, Cout, 3, 1, 1, in_scale, in_shift),
@@ -535,7 +548,7 @@ int conv3x3_fwd_patch(const float* x, const unsigned* wimg, int bn, float* y, co
                  "conv3x3_fwd_patch: scale / shift and statistics come in pairs");
   PArgs a{};
   a.x = x; a.wimg = wimg; a.y = y; a.in_scale = in_scale; a.in_shift = in_shift; a.part_sum = part_sum; a.part_sq = part_sq;
-  a.M = Bn * H * W; a.Cin = Cin; a.Cout = Cout; a.relu_in = relu_in; a.H = H; a.W = W; a.in_exp = in_exp;
+  a.M = Bn * H * W; a.Cin = Cin; a.Cout = Cout; a.relu_in = relu_in; a.H = H; a.W = W; a.in_exp = in_exp; a.err = err;
   a.tiles_m = cdiv(a.M, PBM); a.tiles_n = Cout / bn;
   magic_div((unsigned)a.tiles_n, &a.tn_mul, &a.tn_sh);
   magic_div((unsigned)(H * W), &a.hw_mul, &a.hw_sh);
@@ -572,7 +585,7 @@ bool conv1x1_tail_eligible(const float* y3, const float* res, long M, int Cin, i
 // statistics rows as conv_fwd_f16x3 with k = 1. s2 / t2 null: the identity is used as it is.
 int conv1x1_fwd_tail(const float* y3, const float* s1, const float* t1, const float* res, const float* s2, const float* t2,
                      float* tail_out, const unsigned* wimg, int bn, float* y, float* part_sum, float* part_sq, long M,
-                     int Cin, int Cout, hipStream_t stream, int in_exp) {
+                     int Cin, int Cout, hipStream_t stream, int in_exp, int* err) {
   CAPNET_REQUIRE(in_exp > -64 && in_exp < 64, "conv1x1_fwd_tail: input exponent %d", in_exp);
   CAPNET_REQUIRE(y3 && s1 && t1 && res && tail_out && wimg && y && aligned16(wimg) && aligned16(tail_out) && aligned16(s1) &&
                      aligned16(t1) && (bn == 64 || bn == 128) && Cout % bn == 0 && conv1x1_tail_eligible(y3, res, M, Cin, Cout),
@@ -582,7 +595,7 @@ int conv1x1_fwd_tail(const float* y3, const float* s1, const float* t1, const fl
   PArgs a{};
   a.x = y3; a.in_scale = s1; a.in_shift = t1; a.res = res; a.res_scale = s2; a.res_shift = t2; a.tail_out = tail_out;
   a.wimg = wimg; a.y = y; a.part_sum = part_sum; a.part_sq = part_sq;
-  a.M = (int)M; a.Cin = Cin; a.Cout = Cout; a.relu_in = 1; a.W = 1; a.in_exp = in_exp;
+  a.M = (int)M; a.Cin = Cin; a.Cout = Cout; a.relu_in = 1; a.W = 1; a.in_exp = in_exp; a.err = err;
   const int nkc = Cin / 32;
   a.H = 0;
   while ((1 << a.H) < nkc) ++a.H;                     // (H carries log2 of the k-steps per tile)

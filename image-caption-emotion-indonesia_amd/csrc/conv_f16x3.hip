@@ -76,6 +76,7 @@ struct HArgs {
   int relu_out;
   int M, Cin, Cout, relu_in;
   int in_exp;                // the input enters the f16 planes multiplied by 2^in_exp (undone in the epilogue)
+  int* err;                  // error word (launches without statistics check their outputs for non-finite values)
   int H, W, pad;             // input map and zero padding (3x3 convolutions)
   int tiles_m, tiles_n;
   unsigned tn_mul, tn_sh;
@@ -416,6 +417,16 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const HArgs g) {
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mt][nt][r] *= oscale;          // 2^-ew: exact
+    if (g.err && !g.part_sum) {
+      float t = 0.f;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) t += fabsf(acc[mt][nt][r]);
+      flag_nonfinite(t, g.err);
+    }
     if (ragged) {
       // rows past M were computed from a clamped row: keep them out of the statistics
 #pragma unroll
@@ -620,7 +631,7 @@ int conv1x1_f16x3_pack(const float* w, unsigned* img, int Cout, int Cin, int bn,
 int conv_fwd_f16x3(const float* x, long sxb, long sxh, long sxw, const unsigned* wimg, int bn, float* y,
                    const float* in_scale, const float* in_shift, int relu_in, float* part_sum, float* part_sq, int Bn,
                    int H, int W, int Cin, int Cout, int k, int stride, int pad, hipStream_t stream,
-                   const float* out_scale, const float* out_shift, const float* res, int relu_out, int in_exp) {
+                   const float* out_scale, const float* out_shift, const float* res, int relu_out, int in_exp, int* err) {
   CAPNET_REQUIRE(x && wimg && y && stride >= 1 && in_exp > -64 && in_exp < 64, "conv_fwd_f16x3: bad argument");
   CAPNET_REQUIRE(conv_f16x3_eligible(x, sxb, sxh, sxw, 1, Bn, H, W, Cin, Cout, k, stride, pad, in_scale, in_shift) &&
                      aligned16(wimg) && (bn == 64 || bn == 128) && Cout % bn == 0,
@@ -633,7 +644,7 @@ int conv_fwd_f16x3(const float* x, long sxb, long sxh, long sxw, const unsigned*
   a.x = x; a.wimg = wimg; a.y = y; a.in_scale = in_scale; a.in_shift = in_shift;
   a.part_sum = part_sum; a.part_sq = part_sq;
   a.out_scale = out_scale; a.out_shift = out_shift; a.res = res; a.relu_out = relu_out;
-  a.M = Bn * OH * OW; a.Cin = Cin; a.Cout = Cout; a.relu_in = relu_in; a.in_exp = in_exp;
+  a.M = Bn * OH * OW; a.Cin = Cin; a.Cout = Cout; a.relu_in = relu_in; a.in_exp = in_exp; a.err = err;
   a.H = H; a.W = W; a.pad = pad;
   a.tiles_m = cdiv(a.M, HBM); a.tiles_n = Cout / bn;
   magic_div((unsigned)a.tiles_n, &a.tn_mul, &a.tn_sh);

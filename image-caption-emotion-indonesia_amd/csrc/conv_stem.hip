@@ -51,6 +51,7 @@ struct StemArgs {
   float* part_sum;
   float* part_sq;
   int B, H, W, OH, OW, chunks, tiles, in_exp;
+  int* err;                                // error word (launches without statistics check their outputs)
   int sxb, sxc, sxh;                       // floats
   unsigned tile_mul, tile_sh;              // segment -> (b oh), chunk
   unsigned oh_mul, oh_sh;                  // (b oh) -> b, oh
@@ -172,6 +173,7 @@ __global__ __launch_bounds__(256, 2) void conv_stem_f16x3_kernel(const StemArgs 
     }
     __syncthreads();       // every wave is through with the staged rows
   }
+  if (!g.part_sum && g.err) flag_nonfinite(csq[0] + csq[1], g.err);
   // ---- the workgroup's statistics: the two half-waves, then the four waves
   if (g.part_sum) {
 #pragma unroll
@@ -261,7 +263,7 @@ int conv_stem_f16x3_pack(const float* w_oihw, unsigned* img, hipStream_t stream)
 
 // y [B][OH][OW][64] = conv7x7/2(x NCHW, strides in floats) ; part_sum / part_sq [conv_stem_f16x3_part_rows][64] or null
 int conv_stem_fwd_f16x3(const float* x, long sxb, long sxc, long sxh, const unsigned* wimg, float* y, float* part_sum,
-                        float* part_sq, int Bn, int H, int W, hipStream_t stream, int in_exp) {
+                        float* part_sq, int Bn, int H, int W, hipStream_t stream, int in_exp, int* err) {
   CAPNET_REQUIRE(x && wimg && y && aligned16(wimg) && in_exp > -64 && in_exp < 64, "conv_stem_fwd_f16x3: bad argument");
   CAPNET_REQUIRE(conv_stem_f16x3_eligible(x, sxb, sxc, sxh, 1, Bn, H, W, 3, 64, 7, 2, 3),
                  "conv_stem_fwd_f16x3: operands not eligible (B=%d %dx%d)", Bn, H, W);
@@ -269,7 +271,7 @@ int conv_stem_fwd_f16x3(const float* x, long sxb, long sxc, long sxh, const unsi
   StemArgs a{};
   a.x = x; a.wimg = wimg; a.y = y; a.part_sum = part_sum; a.part_sq = part_sq;
   a.B = Bn; a.H = H; a.W = W; a.OH = (H - 1) / 2 + 1; a.OW = (W - 1) / 2 + 1;
-  a.in_exp = in_exp;
+  a.in_exp = in_exp; a.err = err;
   a.chunks = cdiv(a.OW, kSeg);
   a.tiles = Bn * a.OH * a.chunks;
   a.sxb = (int)sxb; a.sxc = (int)sxc; a.sxh = (int)sxh;

@@ -66,7 +66,7 @@ int conv_fwd_f16x3(const float* x, long sxb, long sxh, long sxw, const unsigned*
                    const float* in_scale, const float* in_shift, int relu_in, float* part_sum, float* part_sq, int Bn,
                    int H, int W, int Cin, int Cout, int k, int stride, int pad, hipStream_t stream,
                    const float* out_scale = nullptr, const float* out_shift = nullptr, const float* res = nullptr,
-                   int relu_out = 0, int in_exp = 0);
+                   int relu_out = 0, int in_exp = 0, int* err = nullptr);
 // (in_exp, here and below: the input is multiplied by 2^in_exp on its way into the f16 planes -- folded into the
 //  BatchNorm's scale / shift where there is one -- and the accumulators by 2^-in_exp: exact, and what keeps the split
 //  operands inside f16's range whatever the scale of the tensor; chosen per tensor by the trunk)
@@ -78,24 +78,25 @@ size_t conv_stem_f16x3_weight_words();
 int conv_stem_f16x3_part_rows(int Bn, int H, int W);
 int conv_stem_f16x3_pack(const float* w_oihw, unsigned* img, hipStream_t stream);
 int conv_stem_fwd_f16x3(const float* x, long sxb, long sxc, long sxh, const unsigned* wimg, float* y, float* part_sum,
-                        float* part_sq, int Bn, int H, int W, hipStream_t stream, int in_exp = 0);
+                        float* part_sq, int Bn, int H, int W, hipStream_t stream, int in_exp = 0, int* err = nullptr);
 // ... and the stride-1 3x3 ones with the tile's input patch resident in LDS (conv3x3_patch.hip): same weight image,
 // tile width and statistics rows as conv_fwd_f16x3; dense NHWC input
 bool conv3x3_patch_eligible(const float* x, long sxb, long sxh, long sxw, long sxc, int Bn, int H, int W, int Cin,
                             int Cout, int k, int stride, int pad, const float* in_scale, const float* in_shift);
 int conv3x3_fwd_patch(const float* x, const unsigned* wimg, int bn, float* y, const float* in_scale, const float* in_shift,
                       int relu_in, float* part_sum, float* part_sq, int Bn, int H, int W, int Cin, int Cout,
-                      hipStream_t stream, bool shared_chip = false, int in_exp = 0);
+                      hipStream_t stream, bool shared_chip = false, int in_exp = 0, int* err = nullptr);
 // Stride-1 1x1 convolutions with Cin = 64 / 128 / 256 (conv3 of stages 1-3) with the A operand resident in registers
 // (conv1x1_areg.hip): dense [M][Cin] input, same weight image, tile width and statistics rows as conv_fwd_f16x3
 bool conv1x1_areg_eligible(const float* x, long M, int Cin, int Cout, int bn, const float* in_scale, const float* in_shift);
 int conv1x1_fwd_areg(const float* x, const unsigned* wimg, int bn, float* y, const float* in_scale, const float* in_shift,
-                     int relu_in, float* part_sum, float* part_sq, long M, int Cin, int Cout, int in_exp, hipStream_t stream);
+                     int relu_in, float* part_sum, float* part_sq, long M, int Cin, int Cout, int in_exp, hipStream_t stream,
+                     int* err = nullptr);
 // A bottleneck block's tail (bn_add_relu) fused into the next block's stride-1 1x1 conv1 (conv3x3_patch.hip)
 bool conv1x1_tail_eligible(const float* y3, const float* res, long M, int Cin, int Cout);
 int conv1x1_fwd_tail(const float* y3, const float* s1, const float* t1, const float* res, const float* s2, const float* t2,
                      float* tail_out, const unsigned* wimg, int bn, float* y, float* part_sum, float* part_sq, long M,
-                     int Cin, int Cout, hipStream_t stream, int in_exp = 0);
+                     int Cin, int Cout, hipStream_t stream, int in_exp = 0, int* err = nullptr);
 size_t conv1x1_f16x3_weight_words(int Cin, int Cout);
 int conv1x1_f16x3_pack(const float* w, unsigned* img, int Cout, int Cin, int bn, hipStream_t stream);
 int conv1x1_fwd_f16x3(const float* x, long sxb, long sxh, long sxw, const unsigned* wimg, int bn, float* y,

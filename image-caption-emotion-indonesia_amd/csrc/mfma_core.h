@@ -275,6 +275,13 @@ __device__ __forceinline__ void block_col_stats(const f32x16 (&acc)[T::MT][T::NT
   }
 }
 
+// Launches WITHOUT BatchNorm statistics (inference) have nothing that carries a non-finite output to bn_finalize's
+// check, and a ReLU behind it would turn a NaN into 0: such launches look at their own outputs. t = sum of |outputs| of
+// this thread; bit 3 of the error word = a non-finite value in the trunk.
+__device__ __forceinline__ void flag_nonfinite(float t, int* err) {
+  if (!(t < __builtin_inff())) atomicOr(err, 8);
+}
+
 // ---- helpers shared by the hand-scheduled conv kernels (conv_f32_v2.hip, conv_wino.hip) ----
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 

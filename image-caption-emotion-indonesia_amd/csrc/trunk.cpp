@@ -359,29 +359,29 @@ int conv_bn(const Ctx& c, int i, const float* x, long sxb, long sxh, long sxw, l
   if (fuse_tail) {
     rc = conv1x1_fwd_tail(tail->y3, tail->s1, tail->t1, tail->res, tail->s2, tail->t2, tail->out,
                           reinterpret_cast<const unsigned*>(c.w[i]), d.tile_n, y, c.train ? psum : nullptr,
-                          c.train ? psq : nullptr, M, d.Cin, d.Cout, c.s, c.in_exp(i));
+                          c.train ? psq : nullptr, M, d.Cin, d.Cout, c.s, c.in_exp(i), c.err);
   } else if (d.stem_h3) {
     CAPNET_REQUIRE(!in_scale && conv_stem_f16x3_eligible(x, sxb, sxc, sxh, sxw, c.t->B, d.H, d.W, d.Cin, d.Cout, d.k, d.stride, d.pad),
                    "trunk: the stem is planned for the split-f16 kernel but its operands are not eligible");
     rc = conv_stem_fwd_f16x3(x, sxb, sxc, sxh, reinterpret_cast<const unsigned*>(c.w[i]), y, c.train ? psum : nullptr,
-                             c.train ? psq : nullptr, c.t->B, d.H, d.W, c.s, c.in_exp(i));
+                             c.train ? psq : nullptr, c.t->B, d.H, d.W, c.s, c.in_exp(i), c.err);
   } else if (d.h3 && d.k == 3 && c.t->use_patch &&
              conv3x3_patch_eligible(x, sxb, sxh, sxw, sxc, c.t->B, d.H, d.W, d.Cin, d.Cout, d.k, d.stride, d.pad, in_scale, in_shift)) {
     // stride-1 3x3: the tile's input patch staged once instead of once per tap (conv3x3_patch.hip), same weight image
     rc = conv3x3_fwd_patch(x, reinterpret_cast<const unsigned*>(c.w[i]), d.tile_n, y, in_scale, in_shift, relu_in,
                            c.train ? psum : nullptr, c.train ? psq : nullptr, c.t->B, d.H, d.W, d.Cin, d.Cout, c.s,
-                           !c.t->tail_balance, c.in_exp(i));
+                           !c.t->tail_balance, c.in_exp(i), c.err);
   } else if (d.h3 && d.k == 1 && d.stride == 1 && c.t->use_areg && sxc == 1 && sxw == d.Cin && sxh == (long)d.W * d.Cin &&
              sxb == (long)d.H * d.W * d.Cin && conv1x1_areg_eligible(x, M, d.Cin, d.Cout, d.tile_n, in_scale, in_shift)) {
     // short K (conv3 of stages 1-3): the A operand folded and split once per 128 rows, resident in registers
     rc = conv1x1_fwd_areg(x, reinterpret_cast<const unsigned*>(c.w[i]), d.tile_n, y, in_scale, in_shift, relu_in,
-                          c.train ? psum : nullptr, c.train ? psq : nullptr, M, d.Cin, d.Cout, c.in_exp(i), c.s);
+                          c.train ? psum : nullptr, c.train ? psq : nullptr, M, d.Cin, d.Cout, c.in_exp(i), c.s, c.err);
   } else if (d.h3) {
     CAPNET_REQUIRE(conv_f16x3_eligible(x, sxb, sxh, sxw, sxc, c.t->B, d.H, d.W, d.Cin, d.Cout, d.k, d.stride, d.pad, in_scale, in_shift),
                    "trunk: conv %d planned for the split-f16 kernel but its operands are not eligible", i);
     rc = conv_fwd_f16x3(x, sxb, sxh, sxw, reinterpret_cast<const unsigned*>(c.w[i]), d.tile_n, y, in_scale,
                         in_shift, relu_in, c.train ? psum : nullptr, c.train ? psq : nullptr, c.t->B, d.H,
-                        d.W, d.Cin, d.Cout, d.k, d.stride, d.pad, c.s, nullptr, nullptr, nullptr, 0, c.in_exp(i));
+                        d.W, d.Cin, d.Cout, d.k, d.stride, d.pad, c.s, nullptr, nullptr, nullptr, 0, c.in_exp(i), c.err);
   } else if (d.kmajor) {
     CAPNET_REQUIRE(conv_v2_eligible(x, sxb, sxh, sxw, sxc, c.t->B, d.Cin, d.Cout, in_scale, in_shift),
                    "trunk: conv %d planned for the K-major kernel but its operands are not eligible", i);
@@ -430,7 +430,7 @@ int conv_folded(const Ctx& c, int i, const float* x, const float* res, int relu,
   if (d.h3) {
     rc = conv_fwd_f16x3(x, sb, sh, sw, reinterpret_cast<const unsigned*>(c.w[i]), d.tile_n, y, nullptr, nullptr,
                         0, nullptr, nullptr, c.t->B, d.H, d.W, d.Cin, d.Cout, d.k, d.stride, d.pad, c.s, c.scale(i),
-                        c.shift(i), res, relu, c.in_exp(i));
+                        c.shift(i), res, relu, c.in_exp(i), c.err);
   } else {
     rc = conv2d_fwd_v2(x, sb, sh, sw, c.w[i], d.Kw, y, nullptr, nullptr, 0, nullptr, nullptr,
                        c.t->B, d.H, d.W, d.Cin, d.Cout, d.k, d.k, d.stride, d.pad, 0,
@@ -480,7 +480,7 @@ int trunk_forward_eval(const Ctx& c, const float* images_nchw, float* out_pooled
     const long M = (long)B * d.OH * d.OW;
     if (d.stem_h3)
       rc = conv_stem_fwd_f16x3(images_nchw, (long)3 * d.H * d.W, (long)d.H * d.W, d.W, reinterpret_cast<const unsigned*>(c.w[0]),
-                               Y3, nullptr, nullptr, B, d.H, d.W, c.s, c.in_exp(0));
+                               Y3, nullptr, nullptr, B, d.H, d.W, c.s, c.in_exp(0), c.err);
     else
       rc = conv2d_fwd(images_nchw, (long)3 * d.H * d.W, d.W, 1, (long)d.H * d.W, c.w[0], d.Kw, Y3, nullptr,
                       nullptr, 0, nullptr, nullptr, B, d.H, d.W, d.Cin, d.Cout, d.k, d.k, d.stride, d.pad,

@@ -207,14 +207,19 @@ class _TrunkRunner:
 
         The bounds are rigorous in train mode and use nothing but the parameters: a batch-normalised value is at most
         sqrt(M - 1) standard deviations from its mean (M = B OH OW values per channel), so |bn(y)| <= sqrt(M - 1)
-        max|gamma| + max|beta|; a block's output is bounded by its two summands' bounds. Inference (running
-        statistics) has no such bound: it uses the same exponents and relies on the error word (bit 3) to say so
-        if an activation ever exceeds them. Images are taken as they come (exponent 0): normalised pixels."""
+        max|gamma| + max|beta|; a block's output is bounded by its two summands' bounds. The exponents are computed
+        for 4 096 standard deviations (>= sqrt(M - 1) for every M the kernels take, 2^24): still 2^3 for a typical
+        value of one standard deviation, whose low piece is then a normal f16 number.
+        Inference (running statistics) has no such bound -- the running statistics need not fit the data --, so it
+        only ever scales DOWN (min(e, 0): the range never shrinks below the unscaled 65 504) and relies on the
+        error word (bit 3: the launches without statistics look at their own outputs) to say so if an activation
+        exceeds it. Images are taken as they come (exponent 0): normalised pixels.
+        -> (train exponents, inference exponents) as ctypes int arrays."""
         key = (b, h, w) + tuple((bn.weight._version, bn.bias._version, bn.weight.data_ptr())
                                 for bn in (self.bns[0], self.bns[len(self.bns) // 2], self.bns[-1]))
         hit = plan.get("exps")
         if hit is not None and hit[0] == key:
-            return hit[1]
+            return hit[1], hit[3]
         with torch.no_grad():
             gb = torch.stack([bn.weight.detach().abs().max() for bn in self.bns] +
                              [bn.bias.detach().abs().max() for bn in self.bns]).cpu().tolist()
@@ -222,7 +227,8 @@ class _TrunkRunner:
         g, bt = gb[:n], gb[n:]
 
         def post(i, m):
-            return math.sqrt(max(m - 1, 1)) * g[i] + bt[i]
+            assert m < (1 << 24)
+            return 4096.0 * g[i] + bt[i]
 
         def ea(bound):
             if not (bound > 0.0 and math.isfinite(bound)):
@@ -252,8 +258,9 @@ class _TrunkRunner:
                 else:
                     a_in = post(i3, m_out) + a_in
         arr = (C.c_int * n)(*exps)
-        plan["exps"] = (key, arr, exps)
-        return arr
+        arr_eval = (C.c_int * n)(*[min(e, 0) for e in exps])
+        plan["exps"] = (key, arr, exps, arr_eval)
+        return arr, arr_eval
 
     def _tables(self, packed):
         """ctypes pointer tables of the C call (packed weights, BN weight / bias / running mean /
@@ -291,7 +298,7 @@ class _TrunkRunner:
             plan["balance_tails"] = bool(balance_tails)
         bn0 = self.bns[0]
         tables = self._tables(packed)
-        exps = self._input_exponents(plan, b, h, w)
+        exps = self._input_exponents(plan, b, h, w)[0 if train else 1]
         err = ops.err_flag(dev)
         L = _lib.lib()
 

@@ -130,40 +130,52 @@ def test_conv1x1_tail_relative_accuracy_at_every_input_scale(dev, lg):
     assert rel_err(y, ref) < 3e-6 and _rms(y, ref) < 6e-7
 
 
-def test_trunk_exponents_follow_the_batchnorm_parameters_and_overflow_is_flagged(dev):
-    """The whole trunk with BatchNorm parameters scaled by 2^12 and by 2^-12: the exponents move with them, the features
-    keep their relative accuracy against the same network on the f32-MFMA kernels scaled the same way. Then an
-    inference pass whose running statistics are absurd (variance 1e-30): activations beyond any bound -- the error word
-    says so."""
+def test_trunk_exponents_follow_the_batchnorm_parameters_and_overflow_is_flagged(dev, monkeypatch):
+    """The whole trunk with the BatchNorm weights in front of conv2 / conv3 scaled by 2^12 and by 2^-12: the exponents
+    move with them, and the features stay as close to the same network on the f32-MFMA kernels (CAPNET_NO_H3=1, which
+    have fp32's range by construction) as they are at scale 1. Then an inference pass whose running statistics are
+    absurd (a running mean of -1e8): activations beyond any bound -- the error word says so."""
     from capnet.model import EncoderCNN
     from test_encoder_gpu import _encoder_state
     imgs = synthetic.make_batch(4, 100, seed=5)[0].to(dev)
 
-    def features(k):
+    def features(k, f32):
+        if f32:
+            monkeypatch.setenv("CAPNET_NO_H3", "1")
+        else:
+            monkeypatch.delenv("CAPNET_NO_H3", raising=False)
         enc = EncoderCNN(300)
         st = _encoder_state(enc)
         for name in list(st):
             if name.startswith("resnet.") and (name.endswith("bn1.weight") or name.endswith("bn2.weight")):
-                st[name] = st[name] * 2.0 ** k             # conv2 / conv3 inputs at scale 2^k; the next BatchNorm undoes it
+                st[name] = st[name] * 2.0 ** k             # conv2 / conv3 inputs at scale 2^k
         enc.load_state_dict(st)
         enc.to(dev).train()
         runner = enc._trunk()
         pooled, _ = runner.forward(imgs, True, True, False)
         plan = runner._plan(4, 224, 224, dev)
         return pooled, plan["exps"][2]
-    p0, e0 = features(0)
-    for k in (12, -12):
-        pk, ek = features(k)
-        moved = [b - a for a, b in zip(e0, ek)]
-        assert set(moved) <= {0, -k} and moved.count(-k) == 100      # the 50 conv2 and 50 conv3 inputs
-        # train-mode BatchNorm is invariant under the scale of its input: the same features (to rounding)
-        assert rel_err(pk, p0) < 2e-3, k
-        print("gamma x 2^%d: features vs unscaled %.2e" % (k, rel_err(pk, p0)))
+    errs = {}
+    e0 = None
+    for k in (0, 12, -12):
+        ph, eh = features(k, False)
+        pf, _ = features(k, True)
+        errs[k] = rel_err(ph, pf)
+        if k == 0:
+            e0 = eh
+        else:
+            moved = [b - a for a, b in zip(e0, eh)]
+            assert set(moved) <= {0, -k} and moved.count(-k) == 100      # the 50 conv2 and 50 conv3 inputs
+    print("split-f16 trunk vs f32-MFMA trunk, BatchNorm weights x 2^k:", errs)
+    # (train-mode BatchNorm over 4 images amplifies rounding differences: 1e-3 at scale 1, tests/test_encoder_gpu.py)
+    assert errs[0] < 3e-3 and errs[12] < 3e-3 and errs[-12] < 3e-3
+    assert max(errs[12], errs[-12]) < 3 * errs[0] + 1e-4
     ops.check_device_errors()
-    # inference with absurd running statistics: post-BN values ~1e15 x the bound
+    # inference with absurd running statistics: post-BN values of 1e8, far beyond the bound the exponents allow for
+    monkeypatch.delenv("CAPNET_NO_H3", raising=False)
     enc = EncoderCNN(300)
     st = _encoder_state(enc)
-    st["resnet.4.0.bn1.running_var"] = torch.full_like(st["resnet.4.0.bn1.running_var"], 1e-30)
+    st["resnet.4.0.bn1.running_mean"] = torch.full_like(st["resnet.4.0.bn1.running_mean"], -1e8)
     enc.load_state_dict(st)
     enc.to(dev).eval()
     with torch.no_grad():
