@@ -35,6 +35,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="images per GPU")
     ap.add_argument("--vocab", type=int, default=8192)
+    ap.add_argument("--layers", type=int, default=1,
+                    help="stacked FactoredLSTM layers (configs[3] / [4]: 2 / 3). PERF-ONLY, PARITY UNPINNED: the reference "
+                         "ignores num_layers; capnet.stacked defines the stacking (SURVEY App. A-1)")
+    ap.add_argument("--factored", type=int, default=512, help="factored size (configs[4]: 1024)")
     ap.add_argument("--decoder", default="factored", choices=["factored", "nic", "att"],
                     help="factored = BASELINE configs[1] (the headline); nic = config 0's decoder; "
                          "att = config 3's attention decoder (secondary workloads)")
@@ -240,8 +244,11 @@ def main():
     B, V = args.batch, args.vocab
     torch.manual_seed(1234)
     encoder = EncoderCNN(300) if args.decoder != "att" else model_att.EncoderCNN(14)
-    if args.decoder == "factored":
-        decoder = DecoderFactoredLSTM(300, 512, 512, V, 1, dropout=args.dropout)
+    if args.decoder == "factored" and args.layers > 1:
+        from capnet.stacked import StackedFactoredLSTM
+        decoder = StackedFactoredLSTM(300, 512, args.factored, V, args.layers, dropout=args.dropout)
+    elif args.decoder == "factored":
+        decoder = DecoderFactoredLSTM(300, 512, args.factored, V, 1, dropout=args.dropout)
     elif args.decoder == "att":
         decoder = model_att.DecoderFactoredLSTMAtt(512, 300, 512, 512, V, 1, dropout=args.dropout)
     else:
@@ -351,36 +358,37 @@ def main():
                 elif kind == 6:      # the stem: K = 147 issued as 22 rows x 8 taps = 176
                     f16x += 3.0 * fi * 176.0 / 147.0
                     algo_f16 += fi
-                elif kind == 4:
-                    bf16x += 6.0 * fi
                 else:
-                    f32x += fi / (2.25 if kind == 2 else 1.0)
+                    f32x += fi
             t_peak = f32x / MFMA_F32_PEAK_TFLOPS + (bf16x + f16x) / MFMA_BF16_PEAK_TFLOPS     # per pass, in 1e-12 s
             peak_equiv = algo / t_peak
             per_s = achieved / algo          # TFLOP/s per algorithmic flop of a pass
             roofline = {"bound": "mfma",
                         "kernel": "the trunk's 155 conv launches, all on three v_mfma_f32_32x32x16_f16 products of 2-way "
-                                  "split fp32 operands per multiply (fp32-grade results): conv_f16x3_kernel (55 of the 104 1x1 "
-                                  "convs and the 3 strided 3x3 ones, implicit GEMM over (tap, channel)), conv1x1_tail_kernel "
+                                  "split fp32 operands per multiply (fp32-grade results): conv_f16x3_kernel (the 50 conv3, the 4 "
+                                  "downsample convs, the first conv1 and the 3 strided 3x3 ones, implicit GEMM over (tap, "
+                                  "channel)), conv1x1_tail_kernel "
                                   "(the 49 conv1 that absorb the previous block's bn_add_relu tail: its three passes over the "
                                   "block output are inside these launches' time; CAPNET_NO_TAIL_FUSION=1 separates them), "
                                   "conv3x3_patch_kernel (the 47 stride-1 3x3 convs, input patch resident in LDS; "
                                   "CAPNET_NO_P3=1 puts them back on conv_f16x3_kernel) and "
                                   "conv_stem_f16x3_kernel (K = 147 issued as 176) for the 7x7 stem; "
-                                  "CAPNET_H3_3X3=none puts the stride-1 3x3 convs back on conv_wino_kernel (Winograd "
-                                  "F(2x2,3x3), f32 MFMA), CAPNET_NO_STEM_H3=1 the stem on conv_f32_kernel",
+                                  "CAPNET_NO_STEM_H3=1 puts the stem, CAPNET_NO_H3=1 everything on the f32-MFMA kernels",
                         "flops": "ALGORITHMIC: 2*M*Cout*KH*KW*Cin of the direct sum (SURVEY 8d: 23.02 GFLOP per image)",
                         "peak_is": "algorithmic flops / (time the f32 matrix pipe needs for what is issued on it at "
                                    "157.3 TFLOP/s + time the 16-bit matrix pipe needs for its share at 2500 TFLOP/s): "
                                    "a split-f16 conv issues 3 f16 products per multiply (the stem x 176/147 for its padded K), "
-                                   "Winograd (when selected) 16/36 of its direct-sum flops on the f32 pipe, the rest f32 as "
-                                   "counted (breakdown in `executed`)",
+                                   "anything planned for the f32-MFMA kernels as counted (breakdown in `executed`); "
+                                   "`frac_algorithmic_vs_f16_dense` prices the ALGORITHMIC flops against the 2 500 TFLOP/s "
+                                   "dense f16 peak instead (SURVEY 8d's reading: the three products count as overhead)",
                         "how": "HIP events around every conv launch of every %d-th trunk pass of the timed region, on its "
                                "launch stream; " % args.conv_event_every +
                                "duration = time with at least one conv launch running (union of the "
-                               "intervals: two trunk passes are in flight, their launches overlap)",
+                               "intervals: three trunk passes are in flight, their launches overlap)",
                         "achieved": round(achieved, 2), "peak": round(peak_equiv, 2), "unit": "TFLOP/s",
-                        "frac": round(achieved / peak_equiv, 4), "traffic": pmc_traffic()[0],
+                        "frac": round(achieved / peak_equiv, 4),
+                        "frac_algorithmic_vs_f16_dense": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4),
+                        "traffic": pmc_traffic()[0],
                         "traffic_source": pmc_traffic()[1],
                         "launches": n.value, "avg_launch_us": round(ms.value * 1e3 / n.value, 2),
                         "flops_per_launch": fl.value / n.value,
@@ -562,7 +570,7 @@ def main():
         us_a -= us_clone
         by = bb * (P * A * 4 + P * Cf * 4)
         extra = {
-            "vocab_projection": {"bound": "mfma", "kernel": "gemm_f32_kernel<128,128> (logits = hiddens . C^T, "
+            "vocab_projection": {"bound": "mfma", "kernel": "nt_dma_kernel<128,32> (f32 MFMA, both operands by LDS-DMA; logits = hiddens . C^T, "
                                  "%d x %d x %d)" % (Nt, V, Hh), "achieved": round(fl / us_v / 1e6, 2),
                                  "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                  "frac": round(fl / us_v / 1e6 / MFMA_F32_PEAK_TFLOPS, 4), "us": round(us_v, 1)},
@@ -585,7 +593,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32 (trunk: operands as 2 f16 pieces each, 3 MFMA products per multiply, f32 accumulate; decoder: f32 MFMA)",
             "data": "synthetic",
             "config": {"workload": "configs[1]: StyleNet FactoredLSTM (factored 512, hidden 512, 1 layer, "
                                    "emb 300, V=%d) + ResNet-152 train-mode trunk, batch %d/GPU, 224x224, "
@@ -602,7 +610,12 @@ def main():
         if args.decoder != "factored":
             out["config"]["workload"] = out["config"]["workload"].replace(
                 "configs[1]: StyleNet FactoredLSTM", "secondary (--decoder %s): " % args.decoder)
-        if world == 1 and not args.no_cpu_baseline and args.decoder == "factored":
+        if args.layers > 1 or args.factored != 512:
+            out["config"]["workload"] = out["config"]["workload"].replace(
+                "configs[1]: StyleNet FactoredLSTM (factored 512, hidden 512, 1 layer,",
+                "secondary (PERF-ONLY, PARITY UNPINNED: the reference ignores num_layers, capnet.stacked defines the "
+                "stacking): FactoredLSTM (factored %d, hidden 512, %d layers," % (args.factored, args.layers))
+        if world == 1 and not args.no_cpu_baseline and args.decoder == "factored" and args.layers == 1 and args.factored == 512:
             out["cpu_baseline"] = cpu_baseline(args, args.cpu_steps)
         else:
             out["cpu_baseline"] = None

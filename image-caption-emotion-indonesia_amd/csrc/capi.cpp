@@ -284,6 +284,15 @@ int capnet_lstm_pointwise_fwd(float* pre, const float* c_prev, float* c_out, flo
   return lstm_pointwise_fwd(pre, 4L * H, c_prev, c_out, h_out, b, H, 0, 1, 3, 2, 1, S(stream));
 }
 
+int capnet_lstm_pointwise_bwd(const float* gates, const float* c, const float* c_prev, const float* dh, float* dc_io,
+                              float* dpre, int b, int H, int cell, capnet_stream_t stream) {
+  CAPNET_REQUIRE(gates && c && dh && dc_io && dpre && b >= 0 && H > 0, "lstm_pointwise_bwd: bad argument");
+  CAPNET_REQUIRE(cell == kCellFactored || cell == kCellLSTM, "lstm_pointwise_bwd: unknown cell %d", cell);
+  const bool f = cell == kCellFactored;
+  // (no separate recurrent dh: the caller's dh is the whole gradient of h; dc_io: in dL/dc, out dL/dc_prev)
+  return lstm_pointwise_bwd(gates, 4L * H, c, c_prev, dh, nullptr, dc_io, dpre, 4L * H, b, b, H, 0, 1, f ? 2 : 3, f ? 3 : 2,
+                            f ? 0 : 1, S(stream), 0, 0);
+}
 size_t capnet_lstm_wfrag_floats(int H) { return lstm_wfrag_floats(H); }
 int capnet_lstm_pack_wfrag(const float* w_cat, float* w_frag, int H, int cell, capnet_stream_t stream) {
   CAPNET_REQUIRE(cell == kCellFactored || cell == kCellLSTM, "lstm_pack_wfrag: unknown cell %d", cell);

@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256) void lstm_pointwise_bwd_kernel(
       }
       for (; k < dh_slabs; ++k) s += sp[(long)k * dh_slab_stride];
       dh += s;
-    } else {
+    } else if (dh_rec) {
       dh += dh_rec[(long)row * H + j];
     }
     dc = dc_io[(long)row * H + j];

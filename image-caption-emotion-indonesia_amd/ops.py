@@ -208,6 +208,43 @@ def lstm_pointwise(pre, c_prev, cell):
     return h, c
 
 
+class LstmCellFn(torch.autograd.Function):
+    """(h, c) = cell(pre-activations [b, 4H], c_prev [b, H]) with autograd: capnet_lstm_pointwise_fwd / _bwd.
+    cell 0: gates i,f,o,c~ and h = o*c (stylenet/model.py:147-153); cell 1: i,f,g,o and h = o*tanh(c)."""
+
+    @staticmethod
+    def forward(ctx, pre, c_prev, cell):
+        _need_cuda(pre, c_prev)
+        gates = pre.detach().clone().contiguous()          # the kernel leaves the activated gates here
+        cp = _c(c_prev.detach())
+        b, h4 = gates.shape
+        H = h4 // 4
+        c = torch.empty((b, H), dtype=torch.float32, device=gates.device)
+        h = torch.empty((b, H), dtype=torch.float32, device=gates.device)
+        check(_lib.lib().capnet_lstm_pointwise_fwd(ptr(gates), ptr(cp), ptr(c), ptr(h), b, H, cell, current_stream()),
+              "capnet_lstm_pointwise_fwd")
+        ctx.save_for_backward(gates, c, cp)
+        ctx.cell = cell
+        ctx.mark_non_differentiable()
+        return h, c
+
+    @staticmethod
+    def backward(ctx, dh, dc):
+        gates, c, cp = ctx.saved_tensors
+        b, h4 = gates.shape
+        H = h4 // 4
+        dh = _c(dh) if dh is not None else torch.zeros_like(c)
+        dc_io = dc.clone().contiguous() if dc is not None else torch.zeros_like(c)
+        dpre = torch.empty_like(gates)
+        check(_lib.lib().capnet_lstm_pointwise_bwd(ptr(gates), ptr(c), ptr(cp), ptr(dh), ptr(dc_io), ptr(dpre), b, H,
+                                                   ctx.cell, current_stream()), "capnet_lstm_pointwise_bwd")
+        return dpre, dc_io, None
+
+
+def lstm_cell(pre, c_prev, cell=0):
+    return LstmCellFn.apply(pre, c_prev, cell)
+
+
 def packed_targets(captions, lengths):
     """pack_padded_sequence(captions, lengths, batch_first=True)[0] for int64 captions."""
     _need_cuda(captions)

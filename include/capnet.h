@@ -390,6 +390,11 @@ int capnet_embedding_fwd(const long long* idx, int n, const float* emb, int E, i
                          int* err_flag, capnet_stream_t stream);
 int capnet_lstm_pointwise_fwd(float* pre, const float* c_prev, float* c_out, float* h_out, int b,
                               int H, int cell, capnet_stream_t stream);
+/* ... and its backward (the cell of capnet.stacked's layers): gates = the ACTIVATED gates the forward left in `pre`,
+ * c / c_prev the new / previous cell state (c_prev NULL = zeros), dh = dL/dh; dc_io: in dL/dc, out dL/dc_prev;
+ * dpre [b][4H] = dL/d pre-activations. */
+int capnet_lstm_pointwise_bwd(const float* gates, const float* c, const float* c_prev, const float* dh, float* dc_io,
+                              float* dpre, int b, int H, int cell, capnet_stream_t stream);
 
 /* One recurrent step in one launch (used inside capnet_seq_forward for t > 0):
  *   gates[b][4H] (in: U(S(V x)) + biases, ld ldg) += h_prev[b][H] . W[4H][H]^T (W given as the

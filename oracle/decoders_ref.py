@@ -94,6 +94,41 @@ def factored_lstm_forward(p, captions, lengths, features, tf_mask, mode="factual
                 p["C.bias"], captions, lengths, features, tf_mask, H, drop_mask)[0]
 
 
+def stacked_factored_lstm_forward(p, captions, lengths, features, tf_mask, mode="factual", num_layers=2):
+    """capnet.stacked.StackedFactoredLSTM.forward restated on the CPU. PARITY UNPINNED: the reference ignores num_layers
+    (stylenet/model.py:37); this is SURVEY App. A-1's definition -- layer l > 0 is the factored cell of model.py:115-155
+    on the hidden state of the layer below at the same step (parameters `V1_i`, `S1_fi`, ...), the top layer feeds C,
+    the loop is model.py:157-196 -- and what it pins is the GPU engine to an independent statement of that definition."""
+    H = p["W_i.weight"].shape[0]
+    B = captions.size(0)
+    emb_w = p["B.weight"]
+    embeddings = emb_w[captions]
+    if features is not None:
+        embeddings = torch.cat((features.unsqueeze(1), embeddings), 1)
+    bs = batch_sizes(lengths)
+    hs = [torch.zeros(B, H, dtype=emb_w.dtype) for _ in range(num_layers)]
+    cs = [torch.zeros(B, H, dtype=emb_w.dtype) for _ in range(num_layers)]
+    sfx = {"factual": "f", "happy": "happy_", "sad": "sad_", "angry": "angry_"}[mode]
+    hiddens = []
+    predicted = captions[:, 0:1]
+    for i, b in enumerate(bs):
+        x = embeddings[:b, i, :] if tf_mask[i] else emb_w[predicted][:b, 0, :]
+        for l in range(num_layers):
+            tag = "" if l == 0 else str(l)
+            pre = []
+            for g in "ifoc":
+                v = _lin(p, "V%s_%s" % (tag, g), x)
+                v = _lin(p, "S%s_%s%s" % (tag, sfx, g), v)
+                pre.append(_lin(p, "U%s_%s" % (tag, g), v) + _lin(p, "W%s_%s" % (tag, g), hs[l][:b]))
+            i_t, f_t, o_t = torch.sigmoid(pre[0]), torch.sigmoid(pre[1]), torch.sigmoid(pre[2])
+            cs[l] = f_t * cs[l][:b] + i_t * torch.tanh(pre[3])
+            hs[l] = o_t * cs[l]
+            x = hs[l]
+        hiddens.append(x)
+        predicted = Fn.linear(x, p["C.weight"], p["C.bias"]).max(1)[1].unsqueeze(1)
+    return Fn.linear(torch.cat(hiddens, 0), p["C.weight"], p["C.bias"])
+
+
 def lstm_forward(p, captions, lengths, features, tf_mask, drop_mask=None):
     H = p["lstm.weight_hh"].shape[1]
     return _run(lambda x, h, c: lstmcell_step(p, x, h, c), p["embed.weight"], p["linear.weight"],

@@ -1,0 +1,106 @@
+"""capnet.stacked.StackedFactoredLSTM (BASELINE configs[3] / [4]: "2-layer", "3-layer"). PARITY UNPINNED: the reference
+ignores num_layers (stylenet/model.py:37); the semantics are SURVEY App. A-1's. Checked: against the CPU restatement of
+that definition (oracle/decoders_ref.py: logits, loss and every gradient, scheduled sampling included), and with one
+layer against DecoderFactoredLSTM itself (which IS pinned to the reference)."""
+import random
+
+import pytest
+import torch
+import torch.nn.functional as Fn
+
+import capnet
+from capnet import ops, synthetic
+from capnet.model import DecoderFactoredLSTM
+from capnet.stacked import StackedFactoredLSTM
+from oracle import decoders_ref as D
+from helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _state(dec, seed):
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for k, v in dec.state_dict().items():
+        lim = 0.3 if v.dim() > 1 else 0.05
+        sd[k] = (torch.rand(v.shape, generator=g) * 2 - 1) * lim
+    return sd
+
+
+@pytest.mark.parametrize("layers,mode", [(2, "factual"), (3, "happy"), (2, "sad")])
+def test_stacked_decoder_matches_its_cpu_restatement(dev, layers, mode):
+    E, H, F, V, B = 20, 24, 16, 61, 5
+    dec = StackedFactoredLSTM(E, H, F, V, layers, dropout=0.0)
+    p = _state(dec, 7 + layers)
+    dec.load_state_dict(p)
+    dec.to(dev).train()
+    _, caps, lens = synthetic.make_batch(B, V, seed=3, min_len=4, max_len=8)
+    feats = torch.randn(B, E, generator=torch.Generator().manual_seed(1))
+    random.seed(11)
+    tf = [random.random() < 0.6 for _ in range(max(lens))]
+    tf[0] = True
+    assert not all(tf)
+    out = dec(caps.to(dev), lens, feats.to(dev), mode=mode, tf_mask=tf)
+    loss = ops.cross_entropy(out, ops.packed_targets(caps.to(dev), lens))
+    loss.backward()
+    leaves = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    ref = D.stacked_factored_lstm_forward(leaves, caps, lens, feats, tf, mode, layers)
+    ref_loss = Fn.cross_entropy(ref, D.packed_targets(caps, lens))
+    ref_loss.backward()
+    assert rel_err(out, ref.detach()) < 2e-5
+    assert abs(loss.item() - ref_loss.item()) / ref_loss.item() < 1e-5
+    got = dict(dec.named_parameters())
+    n_checked = 0
+    for k, leaf in leaves.items():
+        if leaf.grad is None or float(leaf.grad.abs().max()) == 0.0:
+            assert got[k].grad is None or float(got[k].grad.abs().max()) == 0.0, k     # the other modes' S
+            continue
+        assert rel_err(got[k].grad, leaf.grad) < 2e-4, k
+        n_checked += 1
+    assert n_checked >= 1 + layers * 16 + 2
+
+
+def test_one_layer_is_the_reference_decoder(dev):
+    E, H, F, V, B = 300, 512, 512, 1000, 6
+    ref = DecoderFactoredLSTM(E, H, F, V, 1, dropout=0.0)
+    p = synthetic.decoder_state(ref.state_dict(), seed=5)
+    ref.load_state_dict(p)
+    dec = StackedFactoredLSTM(E, H, F, V, 1, dropout=0.0)
+    assert list(dec.state_dict().keys()) == list(ref.state_dict().keys())
+    dec.load_state_dict(p)
+    ref.to(dev).train()
+    dec.to(dev).train()
+    _, caps, lens = synthetic.make_batch(B, V, seed=9)
+    feats = torch.randn(B, E, generator=torch.Generator().manual_seed(2)).to(dev)
+    random.seed(4)
+    tf = [random.random() < 0.8 for _ in range(max(lens))]
+    a = ref(caps.to(dev), lens, feats, tf_mask=tf)
+    b = dec(caps.to(dev), lens, feats, tf_mask=tf)
+    assert rel_err(b, a) < 1e-5
+    la = ops.cross_entropy(a, ops.packed_targets(caps.to(dev), lens)); la.backward()
+    lb = ops.cross_entropy(b, ops.packed_targets(caps.to(dev), lens)); lb.backward()
+    assert rel_err(dec.W_i.weight.grad, ref.W_i.weight.grad) < 1e-4
+    assert rel_err(dec.B.weight.grad, ref.B.weight.grad) < 1e-4
+
+
+def test_stacked_train_step_runs_and_learns(dev):
+    """configs[4]'s decoder shape (3 layers, factored 1024) through capnet.train.train_step with capnet.optim.Adam."""
+    from capnet.optim import Adam
+    from capnet.train import CrossEntropyLoss, train_step
+
+    class Enc(torch.nn.Module):                       # a stand-in encoder head: features are given
+        def __init__(self, f):
+            super().__init__()
+            self.f = f
+
+        def forward(self, images):
+            return self.f
+    B, V = 8, 500
+    dec = StackedFactoredLSTM(300, 512, 1024, V, 3, dropout=0.3).to(dev).train()
+    feats = torch.randn(B, 300, device=dev)
+    enc = Enc(feats)
+    _, caps, lens = synthetic.make_batch(B, V, seed=1)
+    opt = Adam(dec.parameters(), lr=1e-3)
+    losses = [train_step(enc, dec, opt, CrossEntropyLoss(), None, caps.to(dev), lens, 0.5).item() for _ in range(8)]
+    ops.check_device_errors()
+    assert all(torch.isfinite(torch.tensor(losses))) and losses[-1] < losses[0]
