@@ -3,7 +3,7 @@ tools/pmc_traffic.sh. Corrections per /opt/skills/guides/MI355X_MICROARCH.md (HB
 FETCH_SIZE is reported in KB and counts 64 B per 128-B request on gfx950 for wide coalesced
 reads -> doubled; WRITE_SIZE (KB) is exact for 16-B-per-lane stores.
 
-usage: python tools/pmc_summarize.py gpurun_out/pmc > profiles/round2_pmc_traffic.json
+usage: python tools/pmc_summarize.py gpurun_out/pmc > profiles/roundN_pmc_traffic.json
 """
 import csv
 import glob
@@ -32,7 +32,7 @@ def main():
     fetch = collect(os.path.join(root, "fetch"), "FETCH_SIZE")
     write = collect(os.path.join(root, "write"), "WRITE_SIZE")
     if len(sys.argv) > 2 and sys.argv[2] == "--per-kernel":
-        # raw per-kernel sums (profiles/round2_pmc_per_kernel.csv)
+        # raw per-kernel sums (profiles/roundN_pmc_per_kernel.csv)
         print("# rocprofv3 --kernel-trace --pmc FETCH_SIZE (pass 1) / WRITE_SIZE (pass 2) -- python3 bench.py "
               "--steps 2 --warmup 1 --no-cpu-baseline --no-conv-events --no-lstm-roofline")
         print("# raw counter sums in KB over the run (pipelined: 3 + 3 trunk passes, 3 decoder steps); FETCH_SIZE "
@@ -41,16 +41,11 @@ def main():
         for k, v in sorted(fetch.items(), key=lambda kv: -(2 * kv[1][1] + write.get(kv[0], [0, 0])[1]))[:14]:
             print("%s,%d,%.0f,%.0f" % (k.replace(",", ";"), v[0], v[1], write.get(k, [0, 0])[1]))
         return
-    convk = ("conv_f32", "conv_wino", "conv1x1_bf16x6", "conv_f16x3_kernel", "conv3x3_patch_kernel", "conv_stem_f16x3_kernel", "conv1x1_tail_kernel")
+    convk = ("conv_f32", "conv_f16x3_kernel", "conv3x3_patch_kernel", "conv_stem_f16x3_kernel", "conv1x1_tail_kernel", "conv1x1_areg_kernel")
     conv = lambda n: any(k in n for k in convk) or "conv_tail_fixup" in n
     launches = sum(v[0] for k, v in fetch.items() if any(c in k for c in convk))   # fix-ups belong to a conv
-    wino = lambda n: "conv_wino" in n
-    wino_n = sum(v[0] for k, v in fetch.items() if wino(k))
-    wino_bytes = (2.0 * sum(v[1] for k, v in fetch.items() if wino(k)) +
-                  sum(v[1] for k, v in write.items() if wino(k))) * 1024.0
     fetch_kb = sum(v[1] for k, v in fetch.items() if conv(k))
     write_kb = sum(v[1] for k, v in write.items() if conv(k))
-    x6 = lambda n: "conv1x1_bf16x6" in n
     h3 = lambda n: "conv_f16x3_kernel" in n
     h3_n = sum(v[0] for k, v in fetch.items() if h3(k))
     h3_bytes = (2.0 * sum(v[1] for k, v in fetch.items() if h3(k)) + sum(v[1] for k, v in write.items() if h3(k))) * 1024.0
@@ -63,8 +58,6 @@ def main():
     st = lambda n: "conv_stem_f16x3_kernel" in n
     st_n = sum(v[0] for k, v in fetch.items() if st(k))
     st_bytes = (2.0 * sum(v[1] for k, v in fetch.items() if st(k)) + sum(v[1] for k, v in write.items() if st(k))) * 1024.0
-    x6_n = sum(v[0] for k, v in fetch.items() if x6(k))
-    x6_bytes = (2.0 * sum(v[1] for k, v in fetch.items() if x6(k)) + sum(v[1] for k, v in write.items() if x6(k))) * 1024.0
     lp = lambda n: "lstm_persist_kernel" in n
     lp_n = sum(v[0] for k, v in fetch.items() if lp(k))
     lp_bytes = (2.0 * sum(v[1] for k, v in fetch.items() if lp(k)) + sum(v[1] for k, v in write.items() if lp(k))) * 1024.0
@@ -83,8 +76,6 @@ def main():
         # with the 49 fused block tails: + 3 passes over each block output (3 365 MB per pass of the trunk at B = 64:
         # read y3, read the identity, write the block output) - the conv1 read of that output the fusion removes
         "algorithmic_bytes_per_launch_with_tails": round((232e6 + 2 * 90e6 * 64 + 3 * 3288e6 - 3288e6) / 155),
-        "winograd_launches": wino_n,
-        "winograd_bytes_per_launch": round(wino_bytes / max(wino_n, 1)),
         "f16x3_launches": h3_n,
         "f16x3_bytes_per_launch": round(h3_bytes / max(h3_n, 1)),
         "patch3x3_launches": p3_n,
@@ -93,8 +84,6 @@ def main():
         "tail_conv1_bytes_per_launch": round(tl_bytes / max(tl_n, 1)),
         "stem_launches": st_n,
         "stem_bytes_per_launch": round(st_bytes / max(st_n, 1)),
-        "bf16x6_launches": x6_n,
-        "bf16x6_bytes_per_launch": round(x6_bytes / max(x6_n, 1)),
         "lstm_persist_launches": lp_n,
         "lstm_persist_bytes_per_launch": round(lp_bytes / max(lp_n, 1)),
         "lstm_step_launches": ls_n,
