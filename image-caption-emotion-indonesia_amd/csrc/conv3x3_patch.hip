@@ -318,19 +318,26 @@ __global__ __launch_bounds__(kThreads, KSPLIT ? 2 : 4) void conv3x3_patch_kernel
 // into the f16 planes of the A operand. Eight waves at <= 128 VGPRs, both operands double-buffered in LDS, the (tile,
 // chunk) steps of a workgroup one stream: operands of step s + 1 are written behind the barrier that opens step s,
 // those of step s + 2 fetched then -- also across the end of a tile.
+// Two wave arrangements: BN = 64 / 128: 4 x 2 waves of 32 rows x BN / 2 columns (<= 128 VGPRs, two workgroups per CU);
+// BN = 256 (conv1 of stage 3, Cout = 256): 2 x 4 waves of 64 x 64 -- ONE column tile, so y3 and the identity are read and
+// the tail is formed once per row tile instead of once per column tile (two workgroups read the same 1 MB before), and a
+// wave reads 0.67 LDS fragments per MFMA instead of 1 (the eight-wave kernels are LDS-bandwidth-bound); 98
+// workgroups of ~150 VGPRs on the 14 x 14 maps: they take 98 CUs for themselves and leave the rest to the other passes.
 template <int BN>
-__global__ __launch_bounds__(kThreads, 4) void conv1x1_tail_kernel(const PArgs g) {
-  constexpr int NT = BN / 64;
+__global__ __launch_bounds__(kThreads, BN == 256 ? 2 : 4) void conv1x1_tail_kernel(const PArgs g) {
+  constexpr int MT = BN == 256 ? 2 : 1;               // 32-row blocks of a wave
+  constexpr int WN = BN == 256 ? 4 : 2;               // waves along the columns
+  constexpr int NT = BN / (32 * WN);                  // 32-column blocks of a wave (1 / 2 / 2)
   constexpr int kSubB = BN * 2 * 16, kImgB = 4 * kSubB;
   constexpr int kRing = 3;                            // weight buffers: LDS-DMA, two steps ahead (as conv3x3_patch_kernel)
   constexpr int NDMA = kImgB / 1024 / 8;              // 1-KB DMA instructions per wave and step
   constexpr int kSubA = PBM * 16, kImgA = 8 * kSubA;            // [plane 2][group 4][pixel 128][8 halfs]
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kImgA + kRing * kImgB];
-  static_assert(2 * 4 * BN * 4 <= kImgA, "the statistics' scratch lies over an A buffer (see the end of a tile)");
+  static_assert(2 * (8 / WN) * BN * 4 <= kImgA, "the statistics' scratch lies over an A buffer (see the end of a tile)");
   unsigned char* const abuf = lds;
   unsigned char* const bbuf = lds + 2 * kImgA;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = BN == 256 ? wave >> 2 : wave >> 1, wn = BN == 256 ? (wave & 3) : (wave & 1);
   const int li = lane & 31, lh = lane >> 5;
   const int Cin = g.Cin, nkc = Cin / 32, kc_sh = g.H;           // nkc = 1 << kc_sh
   const int total = g.tiles_m * g.tiles_n, G = (int)gridDim.x;
@@ -339,8 +346,8 @@ __global__ __launch_bounds__(kThreads, 4) void conv1x1_tail_kernel(const PArgs g
   const float oscale = ldexpf(1.f, -((int)g.wimg[0] + g.in_exp));
   const float iscale = ldexpf(1.f, g.in_exp);
   const int pq = tid & 7, ppx = tid >> 3;              // this thread's 4 channels of a chunk and its pixel (and pixel + 64)
-  const unsigned char* const a_rd = abuf + lh * kSubA + (wm * 32 + li) * 16;
-  const unsigned char* const b_rd = bbuf + p_cell(wn * (BN / 2) + li, lh);
+  const unsigned char* const a_rd = abuf + lh * kSubA + (wm * 32 * MT + li) * 16;
+  const unsigned char* const b_rd = bbuf + p_cell(wn * (BN / WN) + li, lh);
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const unsigned lds_b0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)bbuf);
 
@@ -413,11 +420,13 @@ __global__ __launch_bounds__(kThreads, 4) void conv1x1_tail_kernel(const PArgs g
     }
   };
 
-  f32x16 acc[NT];
+  f32x16 acc[MT][NT];
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt)
+  for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
   dma_b(0, 0);
   if (n_steps > 1) dma_b(1, 1);
   fetch(0, preA, rsdA);
@@ -452,20 +461,24 @@ __global__ __launch_bounds__(kThreads, 4) void conv1x1_tail_kernel(const PArgs g
     const unsigned char* const b_cur = b_rd + rbuf * kImgB;
 #pragma unroll
     for (int gq = 0; gq < 2; ++gq) {
-      h8 af[2], bf[NT][2];
+      h8 af[MT][2], bf[NT][2];
 #pragma unroll
-      for (int p = 0; p < 2; ++p) af[p] = *reinterpret_cast<const h8*>(a_rd + buf * kImgA + (p * 4 + gq * 2) * kSubA);
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) af[mt][p] = *reinterpret_cast<const h8*>(a_rd + buf * kImgA + (p * 4 + gq * 2) * kSubA + mt * 512);
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int p = 0; p < 2; ++p)
           bf[nt][p] = *reinterpret_cast<const h8*>(b_cur + (p * 2 + gq) * kSubB + nt * 1024);
+      // term by term over the wave's MT x NT blocks: consecutive MFMAs go to different accumulators
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1], bf[nt][0], acc[nt], 0, 0, 0);    // l h'
-        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0], bf[nt][1], acc[nt], 0, 0, 0);    // h l'
-        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0], bf[nt][0], acc[nt], 0, 0, 0);    // h h'
-      }
+      for (int term = 0; term < 3; ++term)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mt][term == 0 ? 1 : 0], bf[nt][term == 1 ? 1 : 0], acc[mt][nt], 0, 0, 0);   // l h', h l', h h'
     }
     rbuf = rbuf + 1 == kRing ? 0 : rbuf + 1;
     if ((s & (nkc - 1)) == nkc - 1) {
@@ -479,16 +492,18 @@ __global__ __launch_bounds__(kThreads, 4) void conv1x1_tail_kernel(const PArgs g
         cs[nt] = 0.f;
         cq[nt] = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = m0 + wm * 32 + 4 * lh + (r & 3) + 8 * (r >> 2);
-          const float v = acc[nt][r] * oscale;
-          acc[nt][r] = 0.f;
-          if (row < g.M) {
-            g.y[(long)row * g.Cout + n0 + wn * (BN / 2) + nt * 32 + li] = v;
-            cs[nt] += v;
-            cq[nt] = fmaf(v, v, cq[nt]);
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = m0 + (wm * MT + mt) * 32 + 4 * lh + (r & 3) + 8 * (r >> 2);
+            const float v = acc[mt][nt][r] * oscale;
+            acc[mt][nt][r] = 0.f;
+            if (row < g.M) {
+              g.y[(long)row * g.Cout + n0 + wn * (BN / WN) + nt * 32 + li] = v;
+              cs[nt] += v;
+              cq[nt] = fmaf(v, v, cq[nt]);
+            }
           }
-        }
       }
       if (!g.part_sum && g.err) {
         float t = 0.f;
@@ -500,20 +515,26 @@ __global__ __launch_bounds__(kThreads, 4) void conv1x1_tail_kernel(const PArgs g
         // scratch = the A buffer this step read: free once every wave is through with the step's MFMAs (the barrier), and
         // staged into again only behind the next step's barrier
         __syncthreads();
-        float (*const scratch)[4][BN] = reinterpret_cast<float (*)[4][BN]>(abuf + buf * kImgA);
+        constexpr int WM = 8 / WN;                     // waves along the rows (4 / 2): partial sums per column
+        float (*const scratch)[WM][BN] = reinterpret_cast<float (*)[WM][BN]>(abuf + buf * kImgA);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           cs[nt] += __shfl_xor(cs[nt], 32);
           cq[nt] += __shfl_xor(cq[nt], 32);
           if (lh == 0) {
-            scratch[0][wm][wn * (BN / 2) + nt * 32 + li] = cs[nt];
-            scratch[1][wm][wn * (BN / 2) + nt * 32 + li] = cq[nt];
+            scratch[0][wm][wn * (BN / WN) + nt * 32 + li] = cs[nt];
+            scratch[1][wm][wn * (BN / WN) + nt * 32 + li] = cq[nt];
           }
         }
         __syncthreads();
         if (tid < BN) {
-          g.part_sum[(long)tm * g.Cout + n0 + tid] = (scratch[0][0][tid] + scratch[0][1][tid]) + (scratch[0][2][tid] + scratch[0][3][tid]);
-          g.part_sq[(long)tm * g.Cout + n0 + tid] = (scratch[1][0][tid] + scratch[1][1][tid]) + (scratch[1][2][tid] + scratch[1][3][tid]);
+          if (WM == 4) {
+            g.part_sum[(long)tm * g.Cout + n0 + tid] = (scratch[0][0][tid] + scratch[0][1][tid]) + (scratch[0][2][tid] + scratch[0][3][tid]);
+            g.part_sq[(long)tm * g.Cout + n0 + tid] = (scratch[1][0][tid] + scratch[1][1][tid]) + (scratch[1][2][tid] + scratch[1][3][tid]);
+          } else {
+            g.part_sum[(long)tm * g.Cout + n0 + tid] = scratch[0][0][tid] + scratch[0][1][tid];
+            g.part_sq[(long)tm * g.Cout + n0 + tid] = scratch[1][0][tid] + scratch[1][1][tid];
+          }
         }
       }
     }
@@ -588,7 +609,7 @@ int conv1x1_fwd_tail(const float* y3, const float* s1, const float* t1, const fl
                      int Cin, int Cout, hipStream_t stream, int in_exp, int* err) {
   CAPNET_REQUIRE(in_exp > -64 && in_exp < 64, "conv1x1_fwd_tail: input exponent %d", in_exp);
   CAPNET_REQUIRE(y3 && s1 && t1 && res && tail_out && wimg && y && aligned16(wimg) && aligned16(tail_out) && aligned16(s1) &&
-                     aligned16(t1) && (bn == 64 || bn == 128) && Cout % bn == 0 && conv1x1_tail_eligible(y3, res, M, Cin, Cout),
+                     aligned16(t1) && (bn == 64 || bn == 128 || bn == 256) && Cout % bn == 0 && conv1x1_tail_eligible(y3, res, M, Cin, Cout),
                  "conv1x1_fwd_tail: bad argument");
   CAPNET_REQUIRE((s2 == nullptr) == (t2 == nullptr) && (!s2 || (aligned16(s2) && aligned16(t2))) &&
                      (part_sum == nullptr) == (part_sq == nullptr), "conv1x1_fwd_tail: scale / shift and statistics come in pairs");
@@ -604,7 +625,8 @@ int conv1x1_fwd_tail(const float* y3, const float* s1, const float* t1, const fl
   const int cap = 512;
   const int total = a.tiles_m * a.tiles_n;
   const dim3 grid(total <= cap ? total : cap), block(kThreads);
-  if (bn == 128) CAPNET_LAUNCH_TIMED((conv1x1_tail_kernel<128>), grid, block, stream, a);
+  if (bn == 256) CAPNET_LAUNCH_TIMED((conv1x1_tail_kernel<256>), grid, block, stream, a);
+  else if (bn == 128) CAPNET_LAUNCH_TIMED((conv1x1_tail_kernel<128>), grid, block, stream, a);
   else CAPNET_LAUNCH_TIMED((conv1x1_tail_kernel<64>), grid, block, stream, a);
   CAPNET_LAUNCH_CHECK();
   return kOk;

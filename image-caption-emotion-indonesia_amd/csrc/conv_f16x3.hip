@@ -610,7 +610,7 @@ size_t conv1x1_f16x3_weight_words(int Cin, int Cout) { return conv_f16x3_weight_
 
 // w OIHW fp32 ([Cout][Cin][k][k]) -> header + the split f16 image for tile width bn
 int conv_f16x3_pack(const float* w, unsigned* img, int Cout, int Cin, int k, int bn, hipStream_t stream) {
-  CAPNET_REQUIRE(w && img && Cin % HBK == 0 && (k == 1 || k == 3) && (bn == 64 || bn == 128) && Cout % bn == 0 && aligned16(img),
+  CAPNET_REQUIRE(w && img && Cin % HBK == 0 && (k == 1 || k == 3) && (bn == 64 || bn == 128 || bn == 256) && Cout % bn == 0 && aligned16(img),
                  "conv_f16x3_pack: bad argument (Cin=%d Cout=%d k=%d bn=%d)", Cin, Cout, k, bn);
   CAPNET_HIP_CHECK(hipMemsetAsync(img, 0, kHdrWords * 4, stream));
   const long n = (long)Cout * Cin * k * k;
@@ -619,7 +619,8 @@ int conv_f16x3_pack(const float* w, unsigned* img, int Cout, int Cin, int k, int
   CAPNET_LAUNCH_CHECK();
   const long cells = n / 2;
   const int grid = (int)(cdiv(cells, 256) > 4096 ? 4096 : cdiv(cells, 256));
-  if (bn == 128) hipLaunchKernelGGL(conv_f16x3_pack_kernel<128>, dim3(grid), dim3(256), 0, stream, w, img, Cout, Cin, k * k);
+  if (bn == 256) hipLaunchKernelGGL(conv_f16x3_pack_kernel<256>, dim3(grid), dim3(256), 0, stream, w, img, Cout, Cin, k * k);   // (conv1x1_tail_kernel<256> only)
+  else if (bn == 128) hipLaunchKernelGGL(conv_f16x3_pack_kernel<128>, dim3(grid), dim3(256), 0, stream, w, img, Cout, Cin, k * k);
   else hipLaunchKernelGGL(conv_f16x3_pack_kernel<64>, dim3(grid), dim3(256), 0, stream, w, img, Cout, Cin, k * k);
   CAPNET_LAUNCH_CHECK();
   return kOk;

@@ -82,7 +82,13 @@ int trunk_create(int B, int H, int W, Trunk** out) {
   t->use_patch = !env_on("CAPNET_NO_P3");
   t->fuse_tails = !env_on("CAPNET_NO_TAIL_FUSION");
   t->use_areg = env_on("CAPNET_AREG");
-  auto add = [&](int cin, int cout, int k, int stride, int pad, int h, int w, bool activated_input = false) {
+  // conv1 of every block but the first rides with the previous block's tail (conv1x1_tail_kernel); where Cout is a
+  // multiple of 256 (stages 3 and 4) that kernel takes a 256-wide tile -- its own weight image, which the other kernels
+  // do not read: planned only while every such conv1 is certain to run fused (not with CAPNET_NO_TAIL_FUSION=1 or the
+  // folded inference trunk, CAPNET_EVAL_FOLDED=1)
+  const bool wide_tails = t->fuse_tails && !env_on("CAPNET_EVAL_FOLDED") && !env_on("CAPNET_NO_WIDE_TAIL");
+  auto add = [&](int cin, int cout, int k, int stride, int pad, int h, int w, bool activated_input = false,
+                 bool tail_conv1 = false) {
     TrunkConv c;
     c.Cin = cin; c.Cout = cout; c.k = k; c.stride = stride; c.pad = pad; c.H = h; c.W = w;
     c.OH = (h + 2 * pad - k) / stride + 1;
@@ -100,6 +106,10 @@ int trunk_create(int B, int H, int W, Trunk** out) {
                                  activated_input ? nullptr : aligned, activated_input ? nullptr : aligned);
     }
     c.tile_n = c.h3 ? conv1x1_f16x3_bn((long)B * c.OH * c.OW, cout) : 0;
+    if (c.h3 && tail_conv1 && wide_tails && cout % 256 == 0 &&
+        conv1x1_tail_eligible(reinterpret_cast<const float*>(uintptr_t(256)), reinterpret_cast<const float*>(uintptr_t(256)),
+                              (long)B * h * w, cin, cout))
+      c.tile_n = 256;
     t->convs.push_back(c);
     return c;
   };
@@ -117,7 +127,7 @@ int trunk_create(int B, int H, int W, Trunk** out) {
     for (int b = 0; b < blocks[L]; ++b) {
       const int stride = (b == 0 && L > 0) ? 2 : 1;
       const int p = planes[L];
-      TrunkConv c1 = add(inplanes, p, 1, 1, 0, h, w, true);
+      TrunkConv c1 = add(inplanes, p, 1, 1, 0, h, w, true, !(L == 0 && b == 0));
       TrunkConv c2 = add(p, p, 3, stride, 1, h, w);
       TrunkConv c3 = add(p, p * 4, 1, 1, 0, c2.OH, c2.OW);
       max_y1 = std::max(max_y1, (size_t)c1.OH * c1.OW * c1.Cout);
@@ -331,6 +341,7 @@ int conv_bn(const Ctx& c, int i, const float* x, long sxb, long sxh, long sxw, l
             const float* in_scale, const float* in_shift, int relu_in, float* y, const BlockTail* tail = nullptr) {
   const TrunkConv& d = c.t->convs[i];
   const long M = (long)c.t->B * d.OH * d.OW;
+  CAPNET_REQUIRE(d.tile_n != 256 || (tail && (c.train || c.eval_ready)), "trunk: conv %d was planned for the wide tail kernel", i);
   const bool fuse_tail = tail && (c.train || c.eval_ready) && c.t->fuse_tails && d.h3 && d.k == 1 && d.stride == 1 && !in_scale &&
                          x == tail->out && tail->C == d.Cin && tail->rows == M && sxc == 1 && sxw == d.Cin &&
                          sxh == (long)d.W * d.Cin && sxb == (long)d.H * d.W * d.Cin &&
@@ -418,6 +429,7 @@ int conv_folded(const Ctx& c, int i, const float* x, const float* res, int relu,
   const TrunkConv& d = c.t->convs[i];
   const long M = (long)c.t->B * d.OH * d.OW;
   const long sw = d.Cin, sh = (long)d.W * d.Cin, sb = (long)d.H * d.W * d.Cin;
+  CAPNET_REQUIRE(d.tile_n != 256, "trunk: conv %d was planned for the wide tail kernel; CAPNET_EVAL_FOLDED=1 must be set before the plan is made", i);
   CAPNET_REQUIRE(d.h3 || (d.kmajor && conv_v2_eligible(x, sb, sh, sw, 1, c.t->B, d.Cin, d.Cout, nullptr, nullptr)),
                  "trunk: conv %d is not eligible for the folded-BN kernel", i);
   hipEvent_t e0 = nullptr, e1 = nullptr;

@@ -691,7 +691,9 @@ def test_conv3x3_patch_matches_fp64(dev, B, H, W, Cin, Cout, bn, pre, shared):
 
 
 @pytest.mark.parametrize("M,Cin,Cout,bn,ds", [(12544, 1024, 256, 128, False), (300, 256, 64, 64, True),
-                                              (3136, 2048, 512, 128, False), (1000, 64, 128, 64, True)])
+                                              (3136, 2048, 512, 128, False), (1000, 64, 128, 64, True),
+                                              (12544, 1024, 256, 256, False),     # stage 3 on the 128 x 256 tile (64 x 64 wave tiles)
+                                              (3136, 2048, 512, 256, True), (300, 512, 256, 256, True)])
 def test_conv1x1_tail_fusion_matches_its_two_kernels(dev, M, Cin, Cout, bn, ds):
     """A block's tail + the next block's conv1 in one launch: the tail it writes is bit-for-bit bn_add_relu's, the
     convolution is fp32-grade against fp64 (ragged tiles, 2 to 64 k-steps per tile, with and without a BatchNorm on
@@ -722,7 +724,9 @@ def test_conv1x1_tail_fusion_matches_its_two_kernels(dev, M, Cin, Cout, bn, ds):
     assert rel_err(psum.sum(0), ref.sum(0)) < 1e-5
     assert rel_err(psq.sum(0), (ref ** 2).sum(0)) < 1e-5
     y2 = torch.full_like(y, float("nan"))
-    check(L.capnet_conv2d_fwd_f16x3(ptr(want_tail), Cin, Cin, Cin, ptr(img), bn, ptr(y2), None, None, 0, None, None,
+    bn2 = min(bn, 128)                              # (the 256-wide image is the tail kernel's own)
+    img2 = img if bn2 == bn else ops.pack_conv_weight_f16x3(w.to(dev), bn2)
+    check(L.capnet_conv2d_fwd_f16x3(ptr(want_tail), Cin, Cin, Cin, ptr(img2), bn2, ptr(y2), None, None, 0, None, None,
                                     1, M, 1, Cin, Cout, 1, 1, 0, None, None, None, 0, current_stream()))
     assert rel_err(y, y2) < 4e-6
 
