@@ -75,10 +75,16 @@ __device__ __forceinline__ unsigned p_cell(int row, int c) {
   return (unsigned)((row * 2 + (c ^ ((r >> 3) & 1))) * 16);
 }
 
-template <int BN, bool KSPLIT>
-__global__ __launch_bounds__(kThreads, KSPLIT ? 2 : 4) void conv3x3_patch_kernel(const PArgs g) {
-  constexpr int NT = BN / 64;
-  constexpr int MT = KSPLIT ? 2 : 1;                  // 32-row blocks of a wave
+// MODE 0: 4 x 2 waves of 32 rows x BN / 2 columns (<= 128 VGPRs); 1 (KSPLIT): four pairs of waves on 64 x BN / 2 blocks, the
+// two waves of a pair split K; 2 (BN = 256 only): 2 x 4 waves of 64 x 64 -- one 128 x 256 tile per row tile (the patch is
+// staged once instead of once per column tile, 0.67 LDS fragments per MFMA instead of 1; as conv1x1_tail_kernel<256>)
+template <int BN, int MODE>
+__global__ __launch_bounds__(kThreads, MODE == 0 ? 4 : 2) void conv3x3_patch_kernel(const PArgs g) {
+  constexpr bool KSPLIT = MODE == 1, WIDE = MODE == 2;
+  static_assert(!WIDE || BN == 256, "the wide arrangement is the 256-column tile's");
+  constexpr int WN = WIDE ? 4 : 2;                    // waves (pairs of waves) along the columns
+  constexpr int NT = BN / (32 * WN);
+  constexpr int MT = MODE == 0 ? 1 : 2;               // 32-row blocks of a wave
   constexpr int kSubB = BN * 2 * 16, kImgB = 4 * kSubB;
   // The packed weights of a k-step (kImgB bytes, copied verbatim) go global -> LDS by LDS-DMA into a ring of kRing
   // buffers, kRing - 1 steps ahead of the MFMAs that read them: a step lasts ~400-500 cycles, a weight fetch from L2
@@ -99,7 +105,7 @@ __global__ __launch_bounds__(kThreads, KSPLIT ? 2 : 4) void conv3x3_patch_kernel
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // KSPLIT: wave = (pair on the 2 x 2 grid of 64-row blocks, k16 group kq2); else 4 x 2 waves of 32 rows, both groups
   const int kq2 = KSPLIT ? (wave & 1) : 0;
-  const int wm = KSPLIT ? (wave >> 2) : (wave >> 1), wn = KSPLIT ? ((wave >> 1) & 1) : (wave & 1);
+  const int wm = MODE == 0 ? (wave >> 1) : (wave >> 2), wn = KSPLIT ? ((wave >> 1) & 1) : WIDE ? (wave & 3) : (wave & 1);
   const int rows0 = wm * (32 * MT);                   // this wave's first row of the tile
   const int li = lane & 31, lh = lane >> 5;
   const int W = g.W, Cin = g.Cin;
@@ -109,7 +115,7 @@ __global__ __launch_bounds__(kThreads, KSPLIT ? 2 : 4) void conv3x3_patch_kernel
   const float iscale = ldexpf(1.f, g.in_exp);
   const int pq = tid & 7;                             // this thread's 4 channels of a chunk: 4 pq .. 4 pq + 3
   const unsigned char* const a_rd = patch + (kq2 * 2 + lh) * kPatchSub + (rows0 + li) * 16;      // + plane, k16, mt, tap offsets
-  const unsigned char* const b_rd = bbuf + p_cell(wn * (BN / 2) + li, lh);
+  const unsigned char* const b_rd = bbuf + p_cell(wn * (BN / WN) + li, lh);
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const unsigned lds_b0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)bbuf);
 
@@ -262,23 +268,29 @@ __global__ __launch_bounds__(kThreads, KSPLIT ? 2 : 4) void conv3x3_patch_kernel
         for (int r = 0; r < 16; ++r) xch[(nt * 16 + r) * 64 + lane] = kq2 ? acc[0][nt][r] : acc[MT - 1][nt][r];
       __syncthreads();
     }
-    float cs[NT], cq[NT];
+    // the 32-row blocks this wave finishes: its only one (MODE 0), the pair's block kq2 (KSPLIT), both of its own (WIDE)
+    constexpr int NFIN = WIDE ? 2 : 1;
+    float cs[NFIN][NT], cq[NFIN][NT];
     {
       const float* xin = reinterpret_cast<const float*>(lds) + (long)(wave ^ 1) * (NT * 16 * 64);
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        cs[nt] = 0.f;
-        cq[nt] = 0.f;
+      for (int f = 0; f < NFIN; ++f) {
+        const int mb = WIDE ? f : kq2;                 // the wave's row block (0 for MODE 0: kq2 = 0)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = m0 + rows0 + kq2 * 32 + 4 * lh + (r & 3) + 8 * (r >> 2);
-          float v = kq2 ? acc[MT - 1][nt][r] : acc[0][nt][r];
-          if (KSPLIT) v += xin[(nt * 16 + r) * 64 + lane];
-          v *= oscale;
-          if (row < g.M) {
-            g.y[(long)row * g.Cout + n0 + wn * (BN / 2) + nt * 32 + li] = v;
-            cs[nt] += v;
-            cq[nt] = fmaf(v, v, cq[nt]);
+        for (int nt = 0; nt < NT; ++nt) {
+          cs[f][nt] = 0.f;
+          cq[f][nt] = 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = m0 + rows0 + mb * 32 + 4 * lh + (r & 3) + 8 * (r >> 2);
+            float v = WIDE ? acc[f][nt][r] : (kq2 ? acc[MT - 1][nt][r] : acc[0][nt][r]);
+            if (KSPLIT) v += xin[(nt * 16 + r) * 64 + lane];
+            v *= oscale;
+            if (row < g.M) {
+              g.y[(long)row * g.Cout + n0 + wn * (BN / WN) + nt * 32 + li] = v;
+              cs[f][nt] += v;
+              cq[f][nt] = fmaf(v, v, cq[f][nt]);
+            }
           }
         }
       }
@@ -286,19 +298,24 @@ __global__ __launch_bounds__(kThreads, KSPLIT ? 2 : 4) void conv3x3_patch_kernel
     if (!g.part_sum && g.err) {
       float t = 0.f;
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) t += cq[nt];     // sums of squares of what this thread stored
+      for (int f = 0; f < NFIN; ++f)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) t += cq[f][nt];     // sums of squares of what this thread stored
       flag_nonfinite(t, g.err);
     }
     if (g.part_sum) {
       __syncthreads();                                 // the patch / the pairs' exchange (under the scratch) have been read for the last time
-      const int rb = KSPLIT ? wm * 2 + kq2 : wm;       // the tile's four 32-row blocks
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        cs[nt] += __shfl_xor(cs[nt], 32);
-        cq[nt] += __shfl_xor(cq[nt], 32);
-        if (lh == 0) {
-          scratch[0][rb][wn * (BN / 2) + nt * 32 + li] = cs[nt];
-          scratch[1][rb][wn * (BN / 2) + nt * 32 + li] = cq[nt];
+      for (int f = 0; f < NFIN; ++f) {
+        const int rb = MODE == 0 ? wm : wm * 2 + (WIDE ? f : kq2);       // the tile's four 32-row blocks
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          cs[f][nt] += __shfl_xor(cs[f][nt], 32);
+          cq[f][nt] += __shfl_xor(cq[f][nt], 32);
+          if (lh == 0) {
+            scratch[0][rb][wn * (BN / WN) + nt * 32 + li] = cs[f][nt];
+            scratch[1][rb][wn * (BN / WN) + nt * 32 + li] = cq[f][nt];
+          }
         }
       }
       __syncthreads();
@@ -561,7 +578,7 @@ bool conv3x3_patch_eligible(const float* x, long sxb, long sxh, long sxw, long s
 int conv3x3_fwd_patch(const float* x, const unsigned* wimg, int bn, float* y, const float* in_scale, const float* in_shift,
                       int relu_in, float* part_sum, float* part_sq, int Bn, int H, int W, int Cin, int Cout,
                       hipStream_t stream, bool shared_chip, int in_exp, int* err) {
-  CAPNET_REQUIRE(x && wimg && y && aligned16(wimg) && (bn == 64 || bn == 128) && Cout % bn == 0 && in_exp > -64 && in_exp < 64,
+  CAPNET_REQUIRE(x && wimg && y && aligned16(wimg) && (bn == 64 || bn == 128 || bn == 256) && Cout % bn == 0 && in_exp > -64 && in_exp < 64,
                  "conv3x3_fwd_patch: bad argument");
   CAPNET_REQUIRE(conv3x3_patch_eligible(x, (long)H * W * Cin, (long)W * Cin, Cin, 1, Bn, H, W, Cin, Cout, 3, 1, 1, in_scale, in_shift),
                  "conv3x3_fwd_patch: operands not eligible");
@@ -584,12 +601,14 @@ int conv3x3_fwd_patch(const float* x, const unsigned* wimg, int bn, float* y, co
   // 8 097 on the implicit-GEMM kernel.
   const int ks_max = shared_chip ? 0 : 256;
   const bool ksplit = total <= ks_max;
-  if (bn == 128) {
-    if (ksplit) CAPNET_LAUNCH_TIMED((conv3x3_patch_kernel<128, true>), grid, block, stream, a);
-    else CAPNET_LAUNCH_TIMED((conv3x3_patch_kernel<128, false>), grid, block, stream, a);
+  if (bn == 256) {
+    CAPNET_LAUNCH_TIMED((conv3x3_patch_kernel<256, 2>), grid, block, stream, a);
+  } else if (bn == 128) {
+    if (ksplit) CAPNET_LAUNCH_TIMED((conv3x3_patch_kernel<128, 1>), grid, block, stream, a);
+    else CAPNET_LAUNCH_TIMED((conv3x3_patch_kernel<128, 0>), grid, block, stream, a);
   } else {
-    if (ksplit) CAPNET_LAUNCH_TIMED((conv3x3_patch_kernel<64, true>), grid, block, stream, a);
-    else CAPNET_LAUNCH_TIMED((conv3x3_patch_kernel<64, false>), grid, block, stream, a);
+    if (ksplit) CAPNET_LAUNCH_TIMED((conv3x3_patch_kernel<64, 1>), grid, block, stream, a);
+    else CAPNET_LAUNCH_TIMED((conv3x3_patch_kernel<64, 0>), grid, block, stream, a);
   }
   CAPNET_LAUNCH_CHECK();
   return kOk;

@@ -82,11 +82,16 @@ int trunk_create(int B, int H, int W, Trunk** out) {
   t->use_patch = !env_on("CAPNET_NO_P3");
   t->fuse_tails = !env_on("CAPNET_NO_TAIL_FUSION");
   t->use_areg = env_on("CAPNET_AREG");
-  // conv1 of every block but the first rides with the previous block's tail (conv1x1_tail_kernel); where Cout is a
-  // multiple of 256 (stages 3 and 4) that kernel takes a 256-wide tile -- its own weight image, which the other kernels
-  // do not read: planned only while every such conv1 is certain to run fused (not with CAPNET_NO_TAIL_FUSION=1 or the
-  // folded inference trunk, CAPNET_EVAL_FOLDED=1)
-  const bool wide_tails = t->fuse_tails && !env_on("CAPNET_EVAL_FOLDED") && !env_on("CAPNET_NO_WIDE_TAIL");
+  // conv1 of every block but the first rides with the previous block's tail (conv1x1_tail_kernel), the stride-1 3x3
+  // convolutions run on the patch kernel; where Cout is a multiple of 256 (stages 3 and 4) both take ONE 128 x 256 tile
+  // per row tile -- their own weight image, which conv_f16x3_kernel does not read: planned only while such a convolution
+  // is certain to run on those kernels (not with CAPNET_NO_TAIL_FUSION=1 / CAPNET_NO_P3=1 or the folded inference trunk,
+  // CAPNET_EVAL_FOLDED=1). The tail kernel's wide tile is the default (+1.5 % images/s although 30 % slower alone:
+  // 98 workgroups leave 158 CUs to the other passes; CAPNET_NO_WIDE_TAIL=1 for the 128-column tiles), the patch
+  // kernel's is not (86 vs 61 us alone, -0.9 % in the step; CAPNET_WIDE_P3=1 turns it on) -- DESIGN 4j
+  const bool no_folded = !env_on("CAPNET_EVAL_FOLDED");
+  const bool wide_tails = t->fuse_tails && no_folded && !env_on("CAPNET_NO_WIDE_TAIL");
+  const bool wide_p3 = t->use_patch && no_folded && env_on("CAPNET_WIDE_P3");
   auto add = [&](int cin, int cout, int k, int stride, int pad, int h, int w, bool activated_input = false,
                  bool tail_conv1 = false) {
     TrunkConv c;
@@ -109,6 +114,11 @@ int trunk_create(int B, int H, int W, Trunk** out) {
     if (c.h3 && tail_conv1 && wide_tails && cout % 256 == 0 &&
         conv1x1_tail_eligible(reinterpret_cast<const float*>(uintptr_t(256)), reinterpret_cast<const float*>(uintptr_t(256)),
                               (long)B * h * w, cin, cout))
+      c.tile_n = 256;
+    if (c.h3 && wide_p3 && k == 3 && stride == 1 && cout % 256 == 0 &&
+        conv3x3_patch_eligible(reinterpret_cast<const float*>(uintptr_t(256)), (long)h * w * cin, (long)w * cin, cin, 1, B, h, w, cin,
+                               cout, k, stride, pad, reinterpret_cast<const float*>(uintptr_t(256)),
+                               reinterpret_cast<const float*>(uintptr_t(256))))
       c.tile_n = 256;
     t->convs.push_back(c);
     return c;
@@ -341,7 +351,7 @@ int conv_bn(const Ctx& c, int i, const float* x, long sxb, long sxh, long sxw, l
             const float* in_scale, const float* in_shift, int relu_in, float* y, const BlockTail* tail = nullptr) {
   const TrunkConv& d = c.t->convs[i];
   const long M = (long)c.t->B * d.OH * d.OW;
-  CAPNET_REQUIRE(d.tile_n != 256 || (tail && (c.train || c.eval_ready)), "trunk: conv %d was planned for the wide tail kernel", i);
+  CAPNET_REQUIRE(d.tile_n != 256 || d.k == 3 || (tail && (c.train || c.eval_ready)), "trunk: conv %d was planned for the wide tail kernel", i);
   const bool fuse_tail = tail && (c.train || c.eval_ready) && c.t->fuse_tails && d.h3 && d.k == 1 && d.stride == 1 && !in_scale &&
                          x == tail->out && tail->C == d.Cin && tail->rows == M && sxc == 1 && sxw == d.Cin &&
                          sxh == (long)d.W * d.Cin && sxb == (long)d.H * d.W * d.Cin &&

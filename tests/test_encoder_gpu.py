@@ -168,7 +168,7 @@ def _trunk_run(dev, monkeypatch, st, imgs, env):
     """A fresh encoder planned under the given environment switches (read by capnet_trunk_create): plan kinds,
     train-mode pooled features, one running mean afterwards, inference features."""
     L = capnet._lib.lib()
-    for k in ("CAPNET_NO_H3", "CAPNET_NO_STEM_H3", "CAPNET_NO_P3", "CAPNET_NO_TAIL_FUSION", "CAPNET_AREG", "CAPNET_NO_WIDE_TAIL"):
+    for k in ("CAPNET_NO_H3", "CAPNET_NO_STEM_H3", "CAPNET_NO_P3", "CAPNET_NO_TAIL_FUSION", "CAPNET_AREG", "CAPNET_NO_WIDE_TAIL", "CAPNET_WIDE_P3"):
         monkeypatch.delenv(k, raising=False)
     for k in env:
         monkeypatch.setenv(k, "1")
@@ -184,7 +184,7 @@ def _trunk_run(dev, monkeypatch, st, imgs, env):
     return kinds, pooled, rm, ev
 
 
-@pytest.mark.parametrize("switch", ["CAPNET_NO_H3", "CAPNET_NO_STEM_H3", "CAPNET_NO_P3", "CAPNET_NO_TAIL_FUSION", "CAPNET_AREG", "CAPNET_NO_WIDE_TAIL"])
+@pytest.mark.parametrize("switch", ["CAPNET_NO_H3", "CAPNET_NO_STEM_H3", "CAPNET_NO_P3", "CAPNET_NO_TAIL_FUSION", "CAPNET_AREG", "CAPNET_NO_WIDE_TAIL", "CAPNET_WIDE_P3"])
 def test_every_trunk_switch_is_a_working_configuration(dev, monkeypatch, switch):
     """Each environment switch the library still reads selects other kernels for part of the trunk (the f32-MFMA
     family for everything / for the stem, the implicit-GEMM kernel for the stride-1 3x3 convolutions, stand-alone

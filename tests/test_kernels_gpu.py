@@ -652,7 +652,8 @@ def test_conv_stem_f16x3_matches_fp64(dev, B, H, W):
 @pytest.mark.parametrize("shared", [0, 1])
 @pytest.mark.parametrize("B,H,W,Cin,Cout,bn,pre", [
     (2, 14, 14, 256, 256, 128, True), (3, 7, 7, 512, 512, 128, True), (1, 56, 56, 64, 64, 64, True),
-    (2, 28, 28, 128, 128, 128, False), (2, 9, 11, 64, 128, 64, True), (5, 3, 3, 32, 64, 64, False)])
+    (2, 28, 28, 128, 128, 128, False), (2, 9, 11, 64, 128, 64, True), (5, 3, 3, 32, 64, 64, False),
+    (2, 14, 14, 256, 256, 256, True), (3, 7, 7, 512, 512, 256, True), (2, 9, 11, 64, 256, 256, False)])   # the 128 x 256 tile
 def test_conv3x3_patch_matches_fp64(dev, B, H, W, Cin, Cout, bn, pre, shared):
     """Stride-1 3x3 convolution with the tile's input patch resident in LDS: fp32-grade against fp64 on the trunk's
     four map sizes, odd maps, tiles that span several images and ragged last tiles; same weight image as the
@@ -683,7 +684,7 @@ def test_conv3x3_patch_matches_fp64(dev, B, H, W, Cin, Cout, bn, pre, shared):
     assert rms < 8e-7          # K = 9 * 512 = 4 608 fp32 accumulations at the deep end
     assert rel_err(psum.sum(0), ref.sum(0)) < 1e-5
     assert rel_err(psq.sum(0), (ref ** 2).sum(0)) < 1e-5
-    if Cin % 64 == 0:
+    if Cin % 64 == 0 and bn <= 128:               # (the 256-wide image is the patch / tail kernels' own)
         y2 = torch.full_like(y, float("nan"))
         check(L.capnet_conv2d_fwd_f16x3(ptr(xd), H * W * Cin, W * Cin, Cin, ptr(img), bn, ptr(y2), ptr(sd), ptr(hd), int(pre),
                                         None, None, B, H, W, Cin, Cout, 3, 1, 1, None, None, None, 0, current_stream()))

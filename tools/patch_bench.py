@@ -10,14 +10,16 @@ B = 64
 for side, ch in ((56, 64), (28, 128), (14, 256), (7, 512)):
     M = B * side * side
     bn = L.capnet_conv1x1_f16x3_bn(M, ch)
+    bnp = 256 if (ch % 256 == 0 and not os.environ.get('P3_NARROW')) else bn
     x = torch.randn(M, ch, device=dev); w = torch.randn(ch, ch, 3, 3, device=dev) * 0.05
     sc = torch.rand(ch, device=dev) + 0.5; sh = torch.randn(ch, device=dev)
     img = ops.pack_conv_weight_f16x3(w, bn)
+    imgp = img if bnp == bn else ops.pack_conv_weight_f16x3(w, bnp)
     tiles = L.capnet_conv1x1_tiles_m(M)
     ps, pq = torch.empty(tiles, ch, device=dev), torch.empty(tiles, ch, device=dev)
     y1, y2 = torch.empty(M, ch, device=dev), torch.empty(M, ch, device=dev)
     def patch():
-        check(L.capnet_conv3x3_fwd_patch(ptr(x), ptr(img), bn, ptr(y1), ptr(sc), ptr(sh), 1, ptr(ps), ptr(pq), B, side, side, ch, ch, int(os.environ.get("P3_SHARED", "0")), current_stream()))
+        check(L.capnet_conv3x3_fwd_patch(ptr(x), ptr(imgp), bnp, ptr(y1), ptr(sc), ptr(sh), 1, ptr(ps), ptr(pq), B, side, side, ch, ch, int(os.environ.get("P3_SHARED", "0")), current_stream()))
     def gemm():
         check(L.capnet_conv2d_fwd_f16x3(ptr(x), side * side * ch, side * ch, ch, ptr(img), bn, ptr(y2), ptr(sc), ptr(sh), 1, ptr(ps), ptr(pq),
                                         B, side, side, ch, ch, 3, 1, 1, None, None, None, 0, current_stream()))
