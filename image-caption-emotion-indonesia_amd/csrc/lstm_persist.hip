@@ -10,14 +10,14 @@
 //     (m < 16) and ALL of Wcat; the dispatcher deals workgroups round-robin over the 8 XCDs, so a
 //     shard normally sits on ONE XCD and its 32 workgroups exchange h through that XCD's L2.
 //   * slot s owns hidden units 16 s .. 16 s + 15 = 64 gate columns, over the whole K = 512: 128 KB
-//     of fp32 weights = 128 VGPRs per lane, loaded once per launch. Wave w holds k in
-//     [128 w, 128 w + 128): split-K over the 4 waves, summed through LDS.
-//   * the product uses v_mfma_f32_4x4x1_16B_f32: 16 independent 4x4 outer products per instruction
-//     at the full f32 matrix rate (64 FLOP/clk/SIMD), so 8 rows per shard waste nothing (a 16x16x4
-//     tile would be half empty at b = 64). Block bl of an instruction = gate columns of unit bl of
-//     the slot; its A operand (4 rows x one k) comes from ONE VGPR that holds 16 different k (lane
-//     4 bl + i <-> row i, k0 + bl): the instruction's CBSZ = 4 / ABID = bl' broadcast selects which
-//     k. h_{t-1} therefore goes from global memory straight into MFMA operands: no LDS staging.
+//     of weights (two f16 pieces per weight, as many bytes as fp32) = 128 VGPRs per lane, loaded once
+//     per launch. Wave w holds k in [128 w, 128 w + 128): split-K over the 4 waves, summed through LDS.
+//   * the product is split-f16 on v_mfma_f32_16x16x32_f16 (three products per multiply, fp32
+//     accumulation: the trunk's arithmetic, see above persist_mfma): 16 rows of the shard x 64 columns
+//     x 128 k per wave = 48 MFMAs of 16 cycles per step. (Round 2 used v_mfma_f32_4x4x1_16B_f32, the
+//     f32 pipe without padding rows: 256 instructions of 8..10 cycles, 45 % of the step.) h_{t-1}
+//     goes from global memory into registers, is split there (5 VALU per pair) and fed to the MFMAs:
+//     no LDS staging.
 //   * exchange of h between the steps: the rows of h_t are the rows of the `hiddens` output
 //     itself. A wave stores its part, waits for the stores (vmcnt), then stores tick t + 1 into its
 //     flag; a consuming wave polls the 32 flags of the 8 slots that produce its k range, then loads
@@ -89,89 +89,112 @@ __device__ __forceinline__ void st_sc1_f32(float* p, float v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // 16-B load that bypasses the vector L1 (served by L2 or beyond); not valid before wait_vm0()
-__device__ __forceinline__ void ld16_sc1(pf32x4& dst, const float* p) {
-  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(dst) : "v"(p) : "memory");
+template <int OFF> __device__ __forceinline__ void ld16_sc1(pf32x4& dst, const float* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off offset:%2 sc1" : "=v"(dst) : "v"(p), "n"(OFF) : "memory");
 }
 __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-// out[r] = rows 4r..4r+3 of h . W^T over this wave's 128 k, for r < NRB.
-// v_mfma_f32_4x4x1 needs ~50 cycles before its result can be accumulated into again
-// (tools/native/mfma4x4_rate.hip: 48 / 28 / 16 / 12 cycles per instruction with 1 / 2 / 4 / 8
-// independent accumulators), so every row block accumulates into NS independent chains that are
-// summed at the end: 8 chains for one live row block, 4 for two or three, 2 for four.
-// (ABID must be an immediate: one macro instance per broadcast block.)
-constexpr int persist_chains(int nrb) { return nrb == 1 ? 8 : nrb == 4 ? 2 : 4; }
-constexpr int persist_max_chains(int rb) { return rb == 1 ? 8 : rb == 2 ? 8 : 12; }
+// ---- the product of one step: out[16 rows of the shard][64 gate columns] over this wave's 128 k ----
+// Split-f16 arithmetic on v_mfma_f32_16x16x32_f16 (the trunk's scheme, conv_f16x3.hip): x = hi + lo with
+// hi = f16(x), lo = f16(x - hi) (the subtraction is exact in fp32), and x w = lo hi' + hi lo' + hi hi' accumulated in
+// fp32; the dropped lo lo' term is 2^-22 of a product. W is split once per pack, scaled by 2^kWExp so that the
+// residuals of weights down to 2^-22 are normal f16 numbers (|w| < 2^(15 - kWExp) = 32 is the domain; beyond it the
+// f16 piece is inf and the loss is NaN, nothing is silent); h is split as it is (|h| < 65 504; its residual is a
+// subnormal f16 below |h| = 0.12, i.e. an absolute error of 2^-25 per element, fp32's own rounding at |h| = 0.5 --
+// subnormal operands run at full rate, tools/native/mfma_f16_denorm.hip).
+// 48 MFMAs of 16 cycles per wave and step where the f32 4x4x1 form issued 256 of 8..10 (round 2).
+//
+// Operand map: the MFMA computes out^T -- A = W (lane l holds gate column n = l & 15 of a 16-column block), B = h
+// (lane l holds batch row l & 15), both with the 8 k of k-quarter kq = l >> 4 of a 32-k group -- so that D puts the
+// four gates of ONE (batch row, unit) into the four registers of one lane (rows 4 kq + i of D = columns n = 4 kq + i
+// = gates i of unit kq of the block): one 16-B LDS write per column block instead of four scattered words. The k of element j of group g is NOT 32 g + 8 kq + j but
+//     k(g, kq, j) = 128 wave + 32 g + 16 (j >> 2) + 4 kq + (j & 3):
+// any one-to-one map works as long as the weight image uses the same one, and with this one every 16-B load
+// instruction of h reads 64 contiguous bytes per row (4 kq x 16 B) instead of every other 16 B of 128.
+// Column n of column block nb is gate n & 3 of unit 4 nb + (n >> 2) of the slot: D lands in the reduction buffer as
+// [batch row][4 unit + gate], the layout the epilogue reads (rows padded to 68 floats: the 16 lanes of a k-quarter
+// write 16 different rows at the same column, 4 banks apart).
+constexpr int kWExp = 10;
+typedef _Float16 ph16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 ph16x2 __attribute__((ext_vector_type(2)));
+typedef float pf32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned pu32x4 __attribute__((ext_vector_type(4)));
 
-template <int RB, int NRB, int Q>
-__device__ __forceinline__ void persist_mfma_half(const pf32x4 (&av)[RB][2], const pf32x4 (&wq)[32],
-                                                  pf32x4 (&acc)[persist_max_chains(RB)]) {
-  constexpr int NS = persist_chains(NRB);
-#define CAPNET_PBLK(B2)                                                                             \
-  _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                     \
-  _Pragma("unroll") for (int r = 0; r < NRB; ++r)                                                   \
-      acc[r * NS + ((e + 4 * (B2 & 1)) % NS)] = __builtin_amdgcn_mfma_f32_4x4x1f32(                 \
-          av[r][Q][e], wq[16 * Q + B2][e], acc[r * NS + ((e + 4 * (B2 & 1)) % NS)], 4, B2, 0);
-  CAPNET_PBLK(0) CAPNET_PBLK(1) CAPNET_PBLK(2) CAPNET_PBLK(3)
-  CAPNET_PBLK(4) CAPNET_PBLK(5) CAPNET_PBLK(6) CAPNET_PBLK(7)
-  CAPNET_PBLK(8) CAPNET_PBLK(9) CAPNET_PBLK(10) CAPNET_PBLK(11)
-  CAPNET_PBLK(12) CAPNET_PBLK(13) CAPNET_PBLK(14) CAPNET_PBLK(15)
-#undef CAPNET_PBLK
+// (x0, x1) -> packed f16 pairs of the two pieces
+__device__ __forceinline__ void p_split2(float x0, float x1, unsigned& h, unsigned& l) {
+  const pf32x2 v = {x0, x1};
+  const ph16x2 hh = __builtin_convertvector(v, ph16x2);          // v_cvt_pk_f16_f32, round to nearest even
+  const pf32x2 r = v - __builtin_convertvector(hh, pf32x2);
+  h = __builtin_bit_cast(unsigned, hh);
+  l = __builtin_bit_cast(unsigned, __builtin_convertvector(r, ph16x2));
+}
+__device__ __forceinline__ void p_split8(const pf32x4& x0, const pf32x4& x1, ph16x8& hi, ph16x8& lo) {
+  unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+  p_split2(x0[0], x0[1], h0, l0);
+  p_split2(x0[2], x0[3], h1, l1);
+  p_split2(x1[0], x1[1], h2, l2);
+  p_split2(x1[2], x1[3], h3, l3);
+  const pu32x4 h = {h0, h1, h2, h3}, l = {l0, l1, l2, l3};
+  hi = __builtin_bit_cast(ph16x8, h);
+  lo = __builtin_bit_cast(ph16x8, l);
 }
 
-// the k half Q = 0 runs while the loads of half Q = 1 are still in flight (vmcnt retires in issue
-// order: all but the RB youngest loads done = half 0 has landed)
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
-  static_assert(N >= 0 && N <= 13, "vmcnt immediate");
-  if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-  if (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-  if (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-  if (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  if (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-  if (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  if (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-  if (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  if (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-  if (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-  if (N == 11) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
-  if (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-  if (N == 13) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+  static_assert(N >= 0 && N <= 63, "vmcnt immediate");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// The k half Q = 0 runs while the loads of half Q = 1 are still in flight. vmcnt retires in issue
-// order; YOUNG = operations this wave issued after the h loads (pre-activation loads, deferred stores).
-template <int RB, int NRB, int YOUNG>
-__device__ __forceinline__ void persist_mfma(const pf32x4 (&av)[RB][2], const pf32x4 (&wq)[32],
-                                             pf32x4 (&out)[RB]) {
-  constexpr int NS = persist_chains(NRB);
-  pf32x4 acc[persist_max_chains(RB)];
+// wq[(4 nb + g) * 2 + plane]: the 8 f16 of (column block nb, k group g), plane 0 = hi, 1 = lo
+__device__ __forceinline__ void persist_mfma_group(const ph16x8& ahi, const ph16x8& alo, const pf32x4 (&wq)[32], int g,
+                                                   pf32x4 (&acc)[4]) {
+  // product-major: an accumulator is touched again three MFMAs later, past the instruction's own latency
 #pragma unroll
-  for (int c = 0; c < NRB * NS; ++c) acc[c] = pf32x4{0.f, 0.f, 0.f, 0.f};
+  for (int nb = 0; nb < 4; ++nb)
+    acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(ph16x8, wq[(4 * nb + g) * 2]), alo, acc[nb], 0, 0, 0);
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb)
+    acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(ph16x8, wq[(4 * nb + g) * 2 + 1]), ahi, acc[nb], 0, 0, 0);
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb)
+    acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(ph16x8, wq[(4 * nb + g) * 2]), ahi, acc[nb], 0, 0, 0);
+}
+
+// The 8 h loads of a step were issued in k order (group g = loads 2 g, 2 g + 1) and vmcnt retires in issue order:
+// group g has landed when at most 6 - 2 g + YOUNG operations are outstanding, YOUNG = what this wave issued after
+// the h loads (4 pre-activation loads and, if it executed them -- `stores` -- the 5 deferred stores). The MFMAs of
+// group g are issued together with the split of group g + 1, whose loads had the time of the previous stage to arrive.
+// Only the wait itself branches on `stores`: with the whole product duplicated under the two counts, hipcc hoisted
+// the arithmetic the two arms had in common -- the first split -- above both waits (tools/isa_inflight_check.py).
+template <int N> __device__ __forceinline__ void wait_h_loads(bool stores) {
+  if (stores) wait_vmcnt<N + 9>();
+  else wait_vmcnt<N + 4>();
+}
+__device__ __forceinline__ void persist_mfma(const pf32x4 (&hv)[8], const pf32x4 (&wq)[32], pf32x4 (&acc)[4], bool stores) {
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb) acc[nb] = pf32x4{0.f, 0.f, 0.f, 0.f};
+  ph16x8 ahi[2], alo[2];
   // (input-only markers for tools/isa_inflight_check.py: a "+v" tie here made hipcc copy the still-stale registers
-  //  above the wait in some of the eight instantiations a step branches to -- mfma_core.h, CAPNET_LANDED_IN)
-  wait_vmcnt<RB + YOUNG>();
-#pragma unroll
-  for (int r = 0; r < RB; ++r) CAPNET_LANDED_IN1(av[r][0]);
+  //  above the wait -- mfma_core.h, CAPNET_LANDED_IN)
+  wait_h_loads<6>(stores);
+  CAPNET_LANDED_IN1(hv[0]);
+  CAPNET_LANDED_IN1(hv[1]);
   __builtin_amdgcn_sched_barrier(0);
-  persist_mfma_half<RB, NRB, 0>(av, wq, acc);
-  __builtin_amdgcn_sched_barrier(0);
-  wait_vmcnt<YOUNG>();
-#pragma unroll
-  for (int r = 0; r < RB; ++r) CAPNET_LANDED_IN1(av[r][1]);
-  __builtin_amdgcn_sched_barrier(0);
-  persist_mfma_half<RB, NRB, 1>(av, wq, acc);
-#pragma unroll
-  for (int r = 0; r < RB; ++r) {
-    if (r < NRB) {
-      pf32x4 s = acc[r * NS];
-#pragma unroll
-      for (int c = 1; c < NS; ++c) s += acc[r * NS + c];
-      out[r] = s;
-    } else {
-      out[r] = pf32x4{0.f, 0.f, 0.f, 0.f};
-    }
-  }
+  p_split8(hv[0], hv[1], ahi[0], alo[0]);
+  // (the empty statements pin a split to the stage it is written in: hipcc otherwise sinks it past the next wait, to
+  //  just in front of its MFMAs, and nothing overlaps)
+  asm volatile("" : "+v"(ahi[0]), "+v"(alo[0]));
+#define CAPNET_PSTAGE(G)                                                                      \
+  __builtin_amdgcn_sched_barrier(0);                                                            \
+  wait_h_loads<4 - 2 * (G)>(stores);                                                           \
+  CAPNET_LANDED_IN1(hv[2 * (G) + 2]);                                                           \
+  CAPNET_LANDED_IN1(hv[2 * (G) + 3]);                                                           \
+  __builtin_amdgcn_sched_barrier(0);                                                            \
+  p_split8(hv[2 * (G) + 2], hv[2 * (G) + 3], ahi[((G) + 1) & 1], alo[((G) + 1) & 1]);           \
+  persist_mfma_group(ahi[(G) & 1], alo[(G) & 1], wq, G, acc);                                  \
+  asm volatile("" : "+v"(ahi[((G) + 1) & 1]), "+v"(alo[((G) + 1) & 1]));
+  CAPNET_PSTAGE(0) CAPNET_PSTAGE(1) CAPNET_PSTAGE(2)
+#undef CAPNET_PSTAGE
+  persist_mfma_group(ahi[1], alo[1], wq, 3, acc);
 }
 
 // sigmoid / tanh on v_exp_f32 + v_rcp_f32 (about 1 ulp each): the pointwise part sits on the
@@ -183,22 +206,22 @@ __device__ __forceinline__ float fast_tanh(float x) {
   return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
 }
 
-// RB: 4-row blocks per shard (rows per shard <= 4 RB)
 // DIAG: s_memtime stamps (tools/persist_phases.py); the product instantiation has none
-template <int RB, bool DIAG>
+template <bool DIAG>
 __global__ __launch_bounds__(256) void lstm_persist_kernel(const PersistArgs a) {
   constexpr int H = kPH;
-  __shared__ __attribute__((aligned(16))) float red[2][4][4 * RB][64];
+  __shared__ __attribute__((aligned(16))) float red[2][4][kPMaxRows][68];
   __shared__ int s_local, s_abort;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int shard = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int bl = lane >> 2, li = lane & 3;
+  const int lm = lane & 15, kq = lane >> 4;      // MFMA operand role: row (A) / column (B, D) and k quarter
   int* ctl = a.ctl;
   const int gi = a.cfg & 3, gf = (a.cfg >> 2) & 3, go = (a.cfg >> 4) & 3, gg = (a.cfg >> 6) & 3;
   const int tanh_out = (a.cfg >> 8) & 1;
   const int u0 = slot * kPUnits;
 
-  // ---- weights of this wave: 128 VGPRs, requested first so that the handshake hides behind them
+  // ---- weights of this wave: 128 VGPRs (16 (column block, k group) pairs x {hi, lo} x 8 f16), requested first so
+  // that the handshake hides behind them
   pf32x4 wq[32];
   {
     const pf32x4* wp = reinterpret_cast<const pf32x4*>(a.Wp) + ((long)(slot * 4 + wave) * 32) * 64 + lane;
@@ -242,7 +265,7 @@ __global__ __launch_bounds__(256) void lstm_persist_kernel(const PersistArgs a) 
   const int em = tid >> 4, eu = tid & 15;
   const int grow = 8 * em + shard;          // global batch row
   float c_reg = 0.f;
-  if (a.t0 > 0 && em < 4 * RB && grow < a.b[a.t0 - 1])
+  if (a.t0 > 0 && grow < a.b[a.t0 - 1])
     c_reg = a.Cst[(long)(a.off[a.t0 - 1] + grow) * H + u0 + eu];
   // flags this wave polls: the 8 slots that produce k in [128 wave, 128 wave + 128), 4 waves each
   const int* my_flags = ctl + kCtlFlags + (shard * kPSlots + 8 * wave) * 4 + (lane & 31);
@@ -261,7 +284,7 @@ __global__ __launch_bounds__(256) void lstm_persist_kernel(const PersistArgs a) 
   auto off_of = [&](int t) { return t < 64 ? __builtin_amdgcn_readlane(v_off0, t) : __builtin_amdgcn_readlane(v_off1, t - 64); };
   auto b_of = [&](int t) { return t < 64 ? __builtin_amdgcn_readlane(v_b0, t) : __builtin_amdgcn_readlane(v_b1, t - 64); };
   // Every vector-memory instruction of the loop is inline asm with hand-counted vmcnt (in issue
-  // order per step: [5 deferred stores of the previous step] 2 RB h loads, 4 pre-activation loads,
+  // order per step: 8 h loads, 4 pre-activation loads, [5 deferred stores of the previous step],
   // the h store). hipcc's own loads in a loop make its waitcnt pass drain vmcnt(0) at points it
   // cannot see our in-flight operations from; only the poll is a compiler-visible (atomic) load,
   // and at that point nothing but the previous flag store is in flight.
@@ -287,10 +310,10 @@ __global__ __launch_bounds__(256) void lstm_persist_kernel(const PersistArgs a) 
     const int bt = b_of(t);
     const int rows_t = (bt - shard + 7) >> 3;        // rows of this shard still alive
     const int ro = off_of(t);
-    const bool evalid = em < rows_t;                  // (rows_t <= 4 RB by construction)
+    const bool evalid = em < rows_t;                  // (rows_t <= 16 by construction)
     const long erow = ro + (evalid ? grow : 0);       // row `ro` always exists (b_t >= 1)
     const bool product = t > 0;
-    pf32x4 av[RB][2];
+    pf32x4 hv[8];
     if (product) {
       // ---- wait for h_{t-1}: produced inside this launch for t > t0, by earlier launches at t0
       if (t > a.t0) {
@@ -308,19 +331,24 @@ __global__ __launch_bounds__(256) void lstm_persist_kernel(const PersistArgs a) 
         }
       }
       if (DIAG) ts[1] = __builtin_amdgcn_s_memtime();
-      // ---- A operands: lane (bl, li) of row block r holds h[row 4 r + li][128 wave + 64 Q + 4 bl + e]
+      // ---- A operands: load q of lane (lm, kq) = h[row lm][128 wave + 16 q + 4 kq + e], e < 4 (see the k map above)
       const int rp = off_of(t - 1);
-      const float* hrow[RB];
+      // Only the lanes of live rows load (a dead row costs no L2 traffic; at b = 64 that is half of it). What the
+      // registers of the other lanes hold feeds output columns nobody reads.
+      const float* hrow = a.hiddens + (long)(rp + 8 * lm + shard) * H + 128 * wave + 4 * kq;
+      if (lm < rows_t) {
+        ld16_sc1<0>(hv[0], hrow);
+        ld16_sc1<64>(hv[1], hrow);
+        ld16_sc1<128>(hv[2], hrow);
+        ld16_sc1<192>(hv[3], hrow);
+        ld16_sc1<256>(hv[4], hrow);
+        ld16_sc1<320>(hv[5], hrow);
+        ld16_sc1<384>(hv[6], hrow);
+        ld16_sc1<448>(hv[7], hrow);
+      } else {
 #pragma unroll
-      for (int r = 0; r < RB; ++r) {
-        const int m = 4 * r + li;
-        const int g = m < rows_t ? 8 * m + shard : 0;   // clamped rows only feed ignored outputs
-        hrow[r] = a.hiddens + (long)(rp + g) * H + 128 * wave + 4 * bl;
+        for (int q = 0; q < 8; ++q) asm volatile("" : "=v"(hv[q]));
       }
-#pragma unroll
-      for (int r = 0; r < RB; ++r) ld16_sc1(av[r][0], hrow[r]);
-#pragma unroll
-      for (int r = 0; r < RB; ++r) ld16_sc1(av[r][1], hrow[r] + 64);
     }
     // ---- pre-activations of this step (written by the input-chain GEMMs before this launch):
     // behind the h loads, they have the whole product to arrive
@@ -339,37 +367,28 @@ __global__ __launch_bounds__(256) void lstm_persist_kernel(const PersistArgs a) 
     __builtin_amdgcn_sched_barrier(0);
 
     if (product) {
-      // Younger than the first k half of the h loads: RB loads, 4 loads and, if this wave executed
-      // them, the 5 deferred stores (the wave executes them iff one of its lanes had a live row; if
-      // the count assumed here were too low the wait would only be longer, never shorter).
-      pf32x4 sum[RB];
-      const int nrb = (rows_t + 3) >> 2;
+      // Younger than the h loads: 4 loads and, if this wave executed them, the 5 deferred stores (the wave executes
+      // them iff one of its lanes had a live row; if the count assumed here were too low the wait would only be
+      // longer, never shorter).
+      pf32x4 acc[4];
       const bool stores_in_flight = __any(had_deferred);
-      if (stores_in_flight) {
-        if (RB >= 4 && nrb >= 4) persist_mfma<RB, (RB >= 4 ? 4 : RB), 9>(av, wq, sum);
-        else if (RB >= 3 && nrb == 3) persist_mfma<RB, (RB >= 3 ? 3 : RB), 9>(av, wq, sum);
-        else if (RB >= 2 && nrb == 2) persist_mfma<RB, (RB >= 2 ? 2 : RB), 9>(av, wq, sum);
-        else persist_mfma<RB, 1, 9>(av, wq, sum);
-      } else {
-        if (RB >= 4 && nrb >= 4) persist_mfma<RB, (RB >= 4 ? 4 : RB), 4>(av, wq, sum);
-        else if (RB >= 3 && nrb == 3) persist_mfma<RB, (RB >= 3 ? 3 : RB), 4>(av, wq, sum);
-        else if (RB >= 2 && nrb == 2) persist_mfma<RB, (RB >= 2 ? 2 : RB), 4>(av, wq, sum);
-        else persist_mfma<RB, 1, 4>(av, wq, sum);
-      }
+      persist_mfma(hv, wq, acc, stores_in_flight);
       if (DIAG) ts[2] = __builtin_amdgcn_s_memtime();
-      // D: register i, lane 4 bl + j = out[row 4 r + i][unit bl, gate j]
+      // D: register i of lane (lm, kq) of column block nb = out[batch row lm][unit 4 nb + kq][gate i]
+      if (lm < rows_t) {
 #pragma unroll
-      for (int r = 0; r < RB; ++r)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) red[t & 1][wave][4 * r + i][lane] = sum[r][i];
+        for (int nb = 0; nb < 4; ++nb) *reinterpret_cast<pf32x4*>(&red[t & 1][wave][lm][4 * (4 * nb + kq)]) = acc[nb];
+      }
     }
     wait_vm0();     // pre-activations (and the deferred stores, long gone)
     __builtin_amdgcn_sched_barrier(0);
     if (product) {
       __syncthreads();
       if (evalid) {
+        pf32x4 sum = *reinterpret_cast<const pf32x4*>(&red[t & 1][0][em][4 * eu]);
 #pragma unroll
-        for (int w = 0; w < 4; ++w) pre += *reinterpret_cast<const pf32x4*>(&red[t & 1][w][em][4 * eu]);
+        for (int w = 1; w < 4; ++w) sum += *reinterpret_cast<const pf32x4*>(&red[t & 1][w][em][4 * eu]);
+        pre += sum * (1.f / (float)(1 << kWExp));
       }
     }
     if (DIAG) ts[3] = __builtin_amdgcn_s_memtime();
@@ -412,22 +431,30 @@ __global__ __launch_bounds__(256) void lstm_persist_kernel(const PersistArgs a) 
   }
 }
 
-// Wp[((slot*4 + w)*32 + q)*256 + lane*4 + e] = Wcat[grow[j]*H + 16 slot + bl][128 w + 4 q + e],
-// lane = 4 bl + j (bl: unit of the slot, j: gate role i,f,o,g)
+// The image, in 32-bit words (two f16 each): word [((slot*4 + w)*32 + (4 nb + g)*2 + plane)*256 + lane*4 + jp] holds
+// elements j = 2 jp, 2 jp + 1 of plane hi / lo of  2^kWExp Wcat[grow[n & 3]*H + 16 slot + 4 nb + (n >> 2)][k(g, kq, j)],
+// lane = 16 kq + n (the operand map above the kernel). As many bytes as the fp32 matrix.
 __global__ __launch_bounds__(256) void lstm_persist_pack_kernel(const float* __restrict__ Wcat,
-                                                                float* __restrict__ Wp, int g0,
+                                                                unsigned* __restrict__ Wp, int g0,
                                                                 int g1, int g2, int g3) {
   const int grow[4] = {g0, g1, g2, g3};
-  const long total = 4L * kPH * kPH;
+  const long total = 2L * kPH * kPH;                 // pairs of weights
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (long)gridDim.x * blockDim.x) {
-    const int e = (int)(i & 3), lane = (int)((i >> 2) & 63);
+    const int jp = (int)(i & 3), lane = (int)((i >> 2) & 63);
     long r = i >> 8;
-    const int q = (int)(r & 31); r >>= 5;
+    const int g = (int)(r & 3); r >>= 2;
+    const int nb = (int)(r & 3); r >>= 2;
     const int w = (int)(r & 3);
     const int slot = (int)(r >> 2);
-    const int bl = lane >> 2, j = lane & 3;
-    Wp[i] = Wcat[((long)grow[j] * kPH + 16 * slot + bl) * kPH + 128 * w + 4 * q + e];
+    const int n = lane & 15, kq = lane >> 4;
+    const int k = 128 * w + 32 * g + 16 * (jp >> 1) + 4 * kq + 2 * (jp & 1);
+    const float* src = Wcat + ((long)grow[n & 3] * kPH + 16 * slot + 4 * nb + (n >> 2)) * kPH + k;
+    unsigned h, l;
+    p_split2(src[0] * (float)(1 << kWExp), src[1] * (float)(1 << kWExp), h, l);
+    const long q = ((long)(slot * 4 + w) * 32 + (4 * nb + g) * 2) * 256 + lane * 4 + jp;
+    Wp[q] = h;
+    Wp[q + 256] = l;
   }
 }
 
@@ -458,7 +485,7 @@ static int persist_device_ok() {
     (void)hipGetLastError();
     return cached = 0;
   }
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)lstm_persist_kernel<4, false>, 256,
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)lstm_persist_kernel<false>, 256,
                                                    0) != hipSuccess) {
     (void)hipGetLastError();
     return cached = 0;
@@ -473,7 +500,8 @@ bool lstm_persist_supported(int b, int H) {
 
 int lstm_persist_pack(const float* Wcat, float* Wp, int gi, int gf, int go, int gg, hipStream_t stream) {
   CAPNET_REQUIRE(Wcat && Wp && aligned16(Wp), "lstm_persist_pack: bad argument");
-  hipLaunchKernelGGL(lstm_persist_pack_kernel, dim3(1024), dim3(256), 0, stream, Wcat, Wp, gi, gf, go, gg);
+  hipLaunchKernelGGL(lstm_persist_pack_kernel, dim3(1024), dim3(256), 0, stream, Wcat, reinterpret_cast<unsigned*>(Wp), gi, gf,
+                     go, gg);
   CAPNET_LAUNCH_CHECK();
   return kOk;
 }
@@ -502,20 +530,8 @@ int lstm_persist_run(const float* Wp, float* G, float* Cst, float* hiddens, cons
     prev = batch_sizes[t];
   }
   for (int t = 0; t < t1; ++t) a.b[t] = (short)batch_sizes[t];
-  const int rows0 = (batch_sizes[t0] + 7) / 8;        // rows of shard 0 at the first step
-  const int rb = (rows0 + 3) / 4;
-#define CAPNET_PLAUNCH(RBV)                                                                          \
-  do {                                                                                              \
-    if (stamps) hipLaunchKernelGGL((lstm_persist_kernel<RBV, true>), dim3(kPGrid), dim3(256), 0, stream, a); \
-    else hipLaunchKernelGGL((lstm_persist_kernel<RBV, false>), dim3(kPGrid), dim3(256), 0, stream, a);       \
-  } while (0)
-  switch (rb) {
-    case 1: CAPNET_PLAUNCH(1); break;
-    case 2: CAPNET_PLAUNCH(2); break;
-    case 3: CAPNET_PLAUNCH(3); break;
-    default: CAPNET_PLAUNCH(4); break;
-  }
-#undef CAPNET_PLAUNCH
+  if (stamps) hipLaunchKernelGGL((lstm_persist_kernel<true>), dim3(kPGrid), dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL((lstm_persist_kernel<false>), dim3(kPGrid), dim3(256), 0, stream, a);
   CAPNET_LAUNCH_CHECK();
   return kOk;
 }
