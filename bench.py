@@ -521,8 +521,9 @@ def main():
             # the whole launch (weight load, handshake, step 0) is charged to them
             res_bytes = (step_bytes - w_bytes) * n_steps + w_bytes        # W read once per launch
             lstm = {"bound": "hbm",
-                    "kernel": "lstm_persist_kernel<2> (b=64, H=512): %d dependent steps in ONE launch, weights "
-                              "register-resident, h handed between workgroups through L2" % n_steps,
+                    "kernel": "lstm_persist_kernel (b=64, H=512): %d dependent steps in ONE launch, weights register-resident "
+                              "as 2 f16 pieces each (3 v_mfma_f32_16x16x32_f16 products per multiply, f32 accumulate), h "
+                              "handed between workgroups through L2" % n_steps,
                     "how": "HIP events on the launch stream around bursts of %d back-to-back launches (median of 3 "
                            "bursts); per step = launch time / %d, so launch gap, weight load, handshake and the "
                            "product-less step 0 are all charged to the steps" % (n_rep, n_steps),
@@ -593,7 +594,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32 (trunk: operands as 2 f16 pieces each, 3 MFMA products per multiply, f32 accumulate; decoder: f32 MFMA)",
+            "dtype": "f32 (trunk: operands as 2 f16 pieces each, 3 MFMA products per multiply, f32 accumulate; decoder: f32 MFMA, the persistent LSTM kernel the same split-f16 scheme)",
             "data": "synthetic",
             "config": {"workload": "configs[1]: StyleNet FactoredLSTM (factored 512, hidden 512, 1 layer, "
                                    "emb 300, V=%d) + ResNet-152 train-mode trunk, batch %d/GPU, 224x224, "

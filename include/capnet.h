@@ -422,7 +422,8 @@ int capnet_lstm_step_fused_supported(int b, int H);
  * wavefront-resident kernel"; the loop it replaces: stylenet/model.py:180-191 for teacher-forced
  * steps, cell :147-153 / nic/model.py:77). H = 512, b <= 128, a device with >= 256 CUs
  * (capnet_lstm_persist_supported; CAPNET_NO_PERSISTENT_LSTM=1 disables it).
- *   w_img        capnet_lstm_persist_pack image of w_cat [4H][H]     (capnet_lstm_persist_w_floats)
+ *   w_img        capnet_lstm_persist_pack image of w_cat [4H][H]     (capnet_lstm_persist_w_floats; the weights as two f16
+ *                pieces each, scaled by 2^10, in MFMA operand order: fp32-grade products for |w| < 32)
  *   gates        [N][4H] packed time-major: in = pre-activations without the recurrent term,
  *                out = activated gates (blocks in the cell's order)
  *   cell_states  [N][H] out (row block of step t0-1 is read when t0 > 0)
