@@ -92,6 +92,9 @@ int trunk_create(int B, int H, int W, Trunk** out) {
   const bool no_folded = !env_on("CAPNET_EVAL_FOLDED");
   const bool wide_tails = t->fuse_tails && no_folded && !env_on("CAPNET_NO_WIDE_TAIL");
   const bool wide_p3 = t->use_patch && no_folded && env_on("CAPNET_WIDE_P3");
+  // the wide tail tile (one workgroup per 128 rows) only where that still makes a quarter of the chip's workgroups: at
+  // batch 64 stage 3 (98 row tiles) takes it, stage 4 (25) keeps 4 x 25 narrow ones (+0.5 % images/s); a 12-image batch none
+  const long wide_min_tiles = 64;
   auto add = [&](int cin, int cout, int k, int stride, int pad, int h, int w, bool activated_input = false,
                  bool tail_conv1 = false) {
     TrunkConv c;
@@ -111,7 +114,7 @@ int trunk_create(int B, int H, int W, Trunk** out) {
                                  activated_input ? nullptr : aligned, activated_input ? nullptr : aligned);
     }
     c.tile_n = c.h3 ? conv1x1_f16x3_bn((long)B * c.OH * c.OW, cout) : 0;
-    if (c.h3 && tail_conv1 && wide_tails && cout % 256 == 0 &&
+    if (c.h3 && tail_conv1 && wide_tails && cout % 256 == 0 && ((long)B * h * w + 127) / 128 >= wide_min_tiles &&
         conv1x1_tail_eligible(reinterpret_cast<const float*>(uintptr_t(256)), reinterpret_cast<const float*>(uintptr_t(256)),
                               (long)B * h * w, cin, cout))
       c.tile_n = 256;

@@ -178,6 +178,7 @@ def _trunk_run(dev, monkeypatch, st, imgs, env):
     runner = enc._trunk()
     plan = runner._plan(imgs.shape[0], 224, 224, dev)            # the environment is read here
     kinds = [L.capnet_trunk_conv_kmajor(plan["handle"], i) for i in range(155)]
+    _trunk_run.wide = sum(L.capnet_trunk_conv_tile_n(plan["handle"], i) == 256 for i in range(155))
     pooled, _ = runner.forward(imgs.to(dev), True, True, False)
     rm = enc.resnet[6][5].bn2.running_mean.clone()
     ev, _ = runner.forward(imgs.to(dev), False, True, False)
@@ -193,10 +194,16 @@ def test_every_trunk_switch_is_a_working_configuration(dev, monkeypatch, switch)
     fp32-grade kernels that differ in summation order)."""
     enc0 = EncoderCNN(300)
     st = _encoder_state(enc0)
-    imgs = synthetic.make_batch(8, 100, seed=2)[0]
+    # (the wide tail tile is planned only where it makes >= 64 workgroups: 48 images put stage 3's tails on it)
+    imgs = synthetic.make_batch(48 if switch == "CAPNET_NO_WIDE_TAIL" else 8, 100, seed=2)[0]
     k0, p0, rm0, e0 = _trunk_run(dev, monkeypatch, st, imgs, [])
+    wide0 = _trunk_run.wide
     k1, p1, rm1, e1 = _trunk_run(dev, monkeypatch, st, imgs, [switch])
     assert k0.count(5) == 154 and k0[0] == 6
+    if switch == "CAPNET_NO_WIDE_TAIL":
+        assert wide0 >= 35 and _trunk_run.wide == 0
+    if switch == "CAPNET_WIDE_P3":
+        assert _trunk_run.wide > wide0
     if switch == "CAPNET_NO_H3":
         assert k1.count(5) == 0 and k1.count(6) == 0
     if switch == "CAPNET_NO_STEM_H3":
