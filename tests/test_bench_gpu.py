@@ -28,7 +28,7 @@ def _run(cmd, env_extra, timeout=600):
 def test_bench_prints_one_json_line():
     d = _run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"], {})
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["unit"] == "images/sec" and d["scaling"] == "weak"
-    assert d["value"] > 0 and math.isfinite(d["loss_last"]) and d["dtype"] == "f32"
+    assert d["value"] > 0 and math.isfinite(d["loss_last"]) and d["dtype"].startswith("f32 (")
     r = d["roofline"]
     # `peak` is the rate at which both matrix pipes, each at its own peak, get through what the kernels issue
     # on them (Winograd 16/36 of the direct sum on the f32 pipe, the split 1x1 convs 3 f16 / 6 bf16 products per
