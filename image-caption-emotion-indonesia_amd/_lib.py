@@ -23,6 +23,7 @@ SIGNATURES = {
     "capnet_sgemm": (_i, [_i, _i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, _vp, _i, _i, _l, _l, _l,
                           _l, _i, _vp]),
     "capnet_sgemm_splitk": (_i, [_i, _i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, _vp, _i, _vp, _sz, _vp]),
+    "capnet_sgemm_splitk_fused": (_i, [_i, _i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, _vp, _i, _vp, _sz, _vp, _sz, _vp]),
     "capnet_colsum": (_i, [_vp, _l, _i, _i, _vp, _i, _vp]),
     "capnet_argmax_rows": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "capnet_resize_u8": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp]),

@@ -14,15 +14,35 @@ namespace capnet {
 
 constexpr int kAttThreads = 256;
 
+// Sum over the 64 lanes, the same value in every lane. Inside a row of 16 lanes by DPP (four VALU adds: no trip
+// through the LDS crossbar, which is what __shfl_xor compiles to -- six dependent ds_bpermute per sum, and the
+// per-pixel sums of the score / context kernels are chains of them), the four rows through v_readlane.
+template <int CTRL> __device__ __forceinline__ float dpp_get(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
+  v += dpp_get<0xB1>(v);      // quad_perm [1,0,3,2]
+  v += dpp_get<0x4E>(v);      // quad_perm [2,3,0,1]
+  v += dpp_get<0x141>(v);     // row_half_mirror
+  v += dpp_get<0x140>(v);     // row_mirror: every lane of a row holds the row's sum
+  const int b = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0));
+  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32));
+  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+  return ((r0 + r1) + r2) + r3;
 }
 
 // ---- forward 1: raw scores ----------------------------------------------------------------
-// grid = (rows of the step, kScoreChunks pixel chunks): 256 workgroups at b = 64 instead of 64.
+// grid = (rows of the step, pixel chunks): 4 chunks at b = 64 (256 workgroups), more for fewer rows so that a
+// 12-row step still makes ~150 workgroups (score_chunks). A pixel's score is one wave's sum whatever the chunking.
 // att1 [B][P][A] (indexed by sample), att2 rows at ld `ldz`. escore [rows][P]: e before softmax.
-constexpr int kScoreChunks = 4;
+static int score_chunks(int rows, int P) {
+  int c = (512 + rows - 1) / rows;
+  const int most = (P + 15) / 16;          // >= 16 pixels per workgroup: one sweep of its four waves
+  if (c > most) c = most;
+  return c < 4 ? 4 : c;
+}
 
 __global__ __launch_bounds__(kAttThreads) void att_scores_fwd_kernel(
     const float* __restrict__ att1, const float* __restrict__ att2, long ldz,
@@ -30,8 +50,9 @@ __global__ __launch_bounds__(kAttThreads) void att_scores_fwd_kernel(
     float* __restrict__ escore) {
   const int j = blockIdx.x;      // row inside the step == sample index
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int pc = (P + kScoreChunks - 1) / kScoreChunks;
+  const int pc = (P + (int)gridDim.y - 1) / (int)gridDim.y;
   const int p0 = blockIdx.y * pc, p1 = min(P, p0 + pc);
+  if (p0 >= p1) return;
   const float* a1 = att1 + (long)j * P * A;
   const float* a2 = att2 + (long)j * ldz;
   const float b0 = bf[0];
@@ -62,22 +83,26 @@ __global__ __launch_bounds__(kAttThreads) void att_scores_fwd_kernel(
 }
 
 // ---- forward 2: softmax + context vector + gate ----------------------------------------------
-// grid = (rows, C/512); 128 threads x float4. Every workgroup of a row recomputes the row's
+// grid = (rows, C/256); 256 threads: lane = 4 channels (float4), the four waves split the pixels (a quarter each, 14
+// independent 16-B loads in flight per lane: 4 dependent round trips for P = 196 where one wave per 512 channels needed
+// 14) and their partial sums meet in LDS, added in wave order. Every workgroup of a row recomputes the row's
 // softmax over P from the raw scores (P is a few hundred values); workgroup y = 0 stores alpha
 // (packed [N][P] row) and the user-visible alphas_bt [B][steps][P] row (j, t).
 // gate_io: in = f_beta(h) pre-activation (ld ldz), out = sigmoid of it (saved for backward).
 // awe_out [rows][C] (pre-gate, saved), xa_out: the decoder input slice (ld ldx) = gate * awe.
-__global__ __launch_bounds__(128) void att_context_fwd_kernel(
+constexpr int kCtxCh = 256;
+
+__global__ __launch_bounds__(kAttThreads) void att_context_fwd_kernel(
     const float* __restrict__ feat, const float* __restrict__ escore, int P, int C,
     float* __restrict__ gate_io, long ldz, float* __restrict__ alpha_out,
     float* __restrict__ alphas_bt, int steps, int t, float* __restrict__ awe_out,
     float* __restrict__ xa_out, long ldx) {
-  extern __shared__ float al[];  // alpha[P]
-  __shared__ float red[4];
+  extern __shared__ float al[];  // alpha[P], then the waves' partial sums [4][64] float4
+  __shared__ float red[8];
   const int j = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float m = -INFINITY;
-  for (int p = threadIdx.x; p < P; p += 128) {
+  for (int p = threadIdx.x; p < P; p += kAttThreads) {
     const float e = escore[(long)j * P + p];
     al[p] = e;
     m = fmaxf(m, e);
@@ -85,18 +110,18 @@ __global__ __launch_bounds__(128) void att_context_fwd_kernel(
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
   if (lane == 0) red[wave] = m;
   __syncthreads();
-  m = fmaxf(red[0], red[1]);
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
   float z = 0.f;
-  for (int p = threadIdx.x; p < P; p += 128) {
+  for (int p = threadIdx.x; p < P; p += kAttThreads) {
     const float e = expf(al[p] - m);
     al[p] = e;
     z += e;
   }
   z = wave_sum(z);
-  if (lane == 0) red[2 + wave] = z;
+  if (lane == 0) red[4 + wave] = z;
   __syncthreads();
-  const float inv = 1.f / (red[2] + red[3]);
-  for (int p = threadIdx.x; p < P; p += 128) {
+  const float inv = 1.f / (red[4] + red[5] + red[6] + red[7]);
+  for (int p = threadIdx.x; p < P; p += kAttThreads) {
     const float a = al[p] * inv;
     al[p] = a;
     if (blockIdx.y == 0) {
@@ -105,11 +130,12 @@ __global__ __launch_bounds__(128) void att_context_fwd_kernel(
     }
   }
   __syncthreads();
-  const int c = blockIdx.y * 512 + threadIdx.x * 4;
+  const int c = blockIdx.y * kCtxCh + lane * 4;
   const float* f = feat + (long)j * P * C + c;
+  const int pq = (P + 3) / 4, pa = wave * pq, pb = min(P, pa + pq);
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-  int p = 0;
-  for (; p + 14 <= P; p += 14) {   // 14 independent 16-B loads in flight per lane
+  int p = pa;
+  for (; p + 14 <= pb; p += 14) {   // 14 independent 16-B loads in flight per lane
     float4 v[14];
 #pragma unroll
     for (int u = 0; u < 14; ++u) v[u] = *reinterpret_cast<const float4*>(f + (long)(p + u) * C);
@@ -120,10 +146,25 @@ __global__ __launch_bounds__(128) void att_context_fwd_kernel(
       s.z = fmaf(a, v[u].z, s.z); s.w = fmaf(a, v[u].w, s.w);
     }
   }
-  for (; p < P; ++p) {
-    const float4 v = *reinterpret_cast<const float4*>(f + (long)p * C);
-    const float a = al[p];
-    s.x = fmaf(a, v.x, s.x); s.y = fmaf(a, v.y, s.y); s.z = fmaf(a, v.z, s.z); s.w = fmaf(a, v.w, s.w);
+  if (p < pb) {                      // the rest of the quarter, still all at once (clamped, weight 0 past the end)
+    float4 v[14];
+#pragma unroll
+    for (int u = 0; u < 14; ++u) v[u] = *reinterpret_cast<const float4*>(f + (long)min(p + u, pb - 1) * C);
+#pragma unroll
+    for (int u = 0; u < 14; ++u) {
+      const float a = p + u < pb ? al[p + u] : 0.f;
+      s.x = fmaf(a, v[u].x, s.x); s.y = fmaf(a, v[u].y, s.y);
+      s.z = fmaf(a, v[u].z, s.z); s.w = fmaf(a, v[u].w, s.w);
+    }
+  }
+  float4* part = reinterpret_cast<float4*>(al + ((P + 3) & ~3));
+  part[wave * 64 + lane] = s;
+  __syncthreads();
+  if (wave != 0) return;
+  {
+    const float4 s1 = part[64 + lane], s2 = part[128 + lane], s3 = part[192 + lane];
+    s.x = ((s.x + s1.x) + s2.x) + s3.x; s.y = ((s.y + s1.y) + s2.y) + s3.y;
+    s.z = ((s.z + s1.z) + s2.z) + s3.z; s.w = ((s.w + s1.w) + s2.w) + s3.w;
   }
   float4 g = *reinterpret_cast<const float4*>(gate_io + (long)j * ldz + c);
   g.x = 1.f / (1.f + expf(-g.x)); g.y = 1.f / (1.f + expf(-g.y));
@@ -144,52 +185,53 @@ int att_step_fwd(const float* att1, const float* feat, const float* att2, float*
                      xa_out && escore, "att_step_fwd: null argument");
   CAPNET_REQUIRE(A % 4 == 0 && C % 512 == 0 && P > 0 && P <= 4096 && ldz % 4 == 0 && ldx % 4 == 0,
                  "att_step_fwd: A=%d C=%d P=%d (need A%%4==0, C%%512==0)", A, C, P);
-  hipLaunchKernelGGL(att_scores_fwd_kernel, dim3(rows, kScoreChunks), dim3(kAttThreads), 0, stream,
+  CAPNET_REQUIRE(aligned16(feat) && aligned16(gate_io) && aligned16(awe_out) && aligned16(xa_out) && aligned16(att1) &&
+                     aligned16(att2) && aligned16(wf), "att_step_fwd: 16-byte alignment of the rows");
+  hipLaunchKernelGGL(att_scores_fwd_kernel, dim3(rows, score_chunks(rows, P)), dim3(kAttThreads), 0, stream,
                      att1, att2, ldz, wf, bf, P, A, escore);
-  hipLaunchKernelGGL(att_context_fwd_kernel, dim3(rows, C / 512), dim3(128), P * sizeof(float),
-                     stream, feat, escore, P, C, gate_io, ldz, alpha_out, alphas_bt, steps, t, awe_out,
+  hipLaunchKernelGGL(att_context_fwd_kernel, dim3(rows, C / kCtxCh), dim3(kAttThreads),
+                     (((P + 3) & ~3) + 4 * 64 * 4) * sizeof(float), stream, feat, escore, P, C, gate_io, ldz, alpha_out, alphas_bt, steps, t, awe_out,
                      xa_out, ldx);
   CAPNET_LAUNCH_CHECK();
   return kOk;
 }
 
 // ---- backward 1: gate and d(alpha) partials -----------------------------------------------
-// grid = (rows, C/512), 256 threads = 4 waves; a wave owns 7 pixels at a time (14 independent
-// 16-B loads in flight), its lanes 512 channels (2 x float4). dxa: gradient of the gated context
-// (ld ldx). Outputs: dgate_out (ld ldz) = d f_beta pre-activation; dalpha_part [rows][C/512][P].
+// grid = (rows, C/256), 256 threads = 4 waves; a wave owns 14 pixels at a time (14 independent
+// 16-B loads in flight: 4 sweeps for P = 196), its lanes 256 channels (float4). dxa: gradient of the gated context
+// (ld ldx). Outputs: dgate_out (ld ldz) = d f_beta pre-activation; dalpha_part [rows][C/256][P].
 __global__ __launch_bounds__(kAttThreads) void att_context_bwd_kernel(
     const float* __restrict__ feat, const float* __restrict__ dxa, long ldx,
     const float* __restrict__ gate, long ldzg, const float* __restrict__ awe, int P, int C,
     float* __restrict__ dgate_out, long ldz, float* __restrict__ dalpha_part) {
   const int j = blockIdx.x, cb = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int c = cb * 512 + lane * 8;
-  float d[8];
+  const int c = cb * kCtxCh + lane * 4;
+  float d[4];
   {
-    const float* gx = dxa + (long)j * ldx + c;
-    const float* gg = gate + (long)j * ldzg + c;
-    const float* aw = awe + (long)j * C + c;
+    // (three independent 16-B loads, then the store: element-wise dword loads around a conditional store came out
+    //  as four dependent round trips)
+    const float4 dg4 = *reinterpret_cast<const float4*>(dxa + (long)j * ldx + c);
+    const float4 g4 = *reinterpret_cast<const float4*>(gate + (long)j * ldzg + c);
+    const float4 aw4 = *reinterpret_cast<const float4*>(awe + (long)j * C + c);
+    const float dg[4] = {dg4.x, dg4.y, dg4.z, dg4.w}, g[4] = {g4.x, g4.y, g4.z, g4.w}, aw[4] = {aw4.x, aw4.y, aw4.z, aw4.w};
+    float o[4];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const float g = gg[k], dg = gx[k];
-      d[k] = dg * g;  // d(awe)
-      if (wave == 0) dgate_out[(long)j * ldz + c + k] = dg * aw[k] * g * (1.f - g);
+    for (int k = 0; k < 4; ++k) {
+      d[k] = dg[k] * g[k];  // d(awe)
+      o[k] = dg[k] * aw[k] * g[k] * (1.f - g[k]);
     }
+    if (wave == 0) *reinterpret_cast<float4*>(dgate_out + (long)j * ldz + c) = make_float4(o[0], o[1], o[2], o[3]);
   }
   const float* f = feat + (long)j * P * C + c;
-  constexpr int U = 7;
+  constexpr int U = 14;
   for (int p = U * wave; p < P; p += U * (kAttThreads / 64)) {
-    float4 v0[U], v1[U];
+    float4 v0[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v0[u] = *reinterpret_cast<const float4*>(f + (long)min(p + u, P - 1) * C);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const long pp = min(p + u, P - 1);
-      v0[u] = *reinterpret_cast<const float4*>(f + pp * C);
-      v1[u] = *reinterpret_cast<const float4*>(f + pp * C + 4);
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      float s = d[0] * v0[u].x + d[1] * v0[u].y + d[2] * v0[u].z + d[3] * v0[u].w + d[4] * v1[u].x +
-                d[5] * v1[u].y + d[6] * v1[u].z + d[7] * v1[u].w;
+      float s = d[0] * v0[u].x + d[1] * v0[u].y + d[2] * v0[u].z + d[3] * v0[u].w;
       s = wave_sum(s);
       if (lane == 0 && p + u < P) dalpha_part[((long)j * gridDim.y + cb) * P + p + u] = s;
     }
@@ -198,7 +240,7 @@ __global__ __launch_bounds__(kAttThreads) void att_context_bwd_kernel(
 
 // ---- backward 2: softmax, relu, full_att / decoder_att gradients ---------------------------
 // grid = (rows, A/128): a workgroup owns 128 attention channels of a row (lane = 2 channels),
-// its 4 waves sweep the pixels 7 at a time. Every workgroup of a row recomputes d e = softmax
+// its 4 waves sweep the pixels 14 at a time. Every workgroup of a row recomputes d e = softmax
 // backward over P (a few hundred values); workgroup y = 0 stores it (de_out [rows][P], read after
 // the time loop by att_datt1_kernel) and the full_att bias gradient.
 // dalphas_bt: gradient of the user-visible alphas tensor [B][steps][P] (may be null).
@@ -248,7 +290,7 @@ __global__ __launch_bounds__(kAttThreads) void att_scores_bwd_kernel(
     const float* a1 = att1 + (long)j * P * A + a0;
     const float2 y = *reinterpret_cast<const float2*>(att2 + (long)j * ldz2 + a0);
     const float2 w = *reinterpret_cast<const float2*>(wf + a0);
-    constexpr int U = 7;
+    constexpr int U = 14;
     for (int p = U * wave; p < P; p += U * (kAttThreads / 64)) {
       float2 x[U];
 #pragma unroll
@@ -289,15 +331,17 @@ int att_step_bwd(const float* att1, const float* feat, const float* att2, long l
   CAPNET_REQUIRE(att1 && feat && att2 && gate && awe && alpha && wf && dxa && dalpha_part &&
                      dgate_out && datt2 && de_out && dwf_rows && dbf_rows,
                  "att_step_bwd: null argument");
-  CAPNET_REQUIRE(A % 4 == 0 && C % 512 == 0 && P > 0 && ldz % 4 == 0 && ldx % 4 == 0 && ldz2 % 2 == 0 &&
+  CAPNET_REQUIRE(ldzg % 4 == 0 && aligned16(dxa) && aligned16(gate) && aligned16(awe) && aligned16(dgate_out) && aligned16(feat),
+                 "att_step_bwd: 16-byte alignment of the context rows");
+  CAPNET_REQUIRE(A % 4 == 0 && C % kCtxCh == 0 && P > 0 && ldz % 4 == 0 && ldx % 4 == 0 && ldz2 % 2 == 0 &&
                      (size_t)(P + 8 * kScoreBwdCh) * 4 <= 64 * 1024,
                  "att_step_bwd: A=%d C=%d P=%d", A, C, P);
   // gate rows use their own leading dimension (saved forward Z buffer)
-  hipLaunchKernelGGL(att_context_bwd_kernel, dim3(rows, C / 512), dim3(kAttThreads), 0, stream, feat,
+  hipLaunchKernelGGL(att_context_bwd_kernel, dim3(rows, C / kCtxCh), dim3(kAttThreads), 0, stream, feat,
                      dxa, ldx, gate, ldzg, awe, P, C, dgate_out, ldz, dalpha_part);
   hipLaunchKernelGGL(att_scores_bwd_kernel, dim3(rows, cdiv(A, kScoreBwdCh)), dim3(kAttThreads),
                      (P + 8 * kScoreBwdCh) * sizeof(float), stream, att1, att2, ldz2, wf, alpha,
-                     dalpha_part, C / 512, dalphas_bt, steps, t, P, A, datt2, ldz, de_out, dwf_rows,
+                     dalpha_part, C / kCtxCh, dalphas_bt, steps, t, P, A, datt2, ldz, de_out, dwf_rows,
                      dbf_rows);
   CAPNET_LAUNCH_CHECK();
   return kOk;

@@ -135,6 +135,14 @@ int capnet_sgemm_splitk(int transA, int transB, int M, int N, int K, const float
   return sgemm_splitk(transA != 0, transB != 0, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate,
                       workspace, workspace_floats, S(stream));
 }
+int capnet_sgemm_splitk_fused(int transA, int transB, int M, int N, int K, const float* A, long lda,
+                              const float* B, long ldb, float* C, long ldc, const float* bias,
+                              int accumulate, float* workspace, size_t workspace_floats, int* counters,
+                              size_t n_counters, capnet_stream_t stream) {
+  CAPNET_REQUIRE(M >= 0 && N >= 0 && K >= 0, "sgemm_splitk_fused: negative dimension");
+  return sgemm_splitk(transA != 0, transB != 0, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate,
+                      workspace, workspace_floats, S(stream), counters, n_counters);
+}
 int capnet_colsum(const float* x, long ld, int rows, int C, float* out, int accumulate,
                   capnet_stream_t stream) {
   return colsum(x, ld, rows, C, out, accumulate, S(stream));

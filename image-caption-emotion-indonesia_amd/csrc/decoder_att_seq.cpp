@@ -70,6 +70,7 @@ ALayout make_alayout(const AttDims& d) {
 }
 
 constexpr size_t kAttSplitKFloats = 32ull * 64 * 4608;
+constexpr size_t kAttSplitKWs = kAttSplitKFloats - kSplitKCounters;   // slabs | tile counters
 
 int check(const AttDims& d, const int* bs) {
   CAPNET_REQUIRE(d.cell == kCellFactored || d.cell == kCellLSTM, "att decoder: unknown cell %d", d.cell);
@@ -107,7 +108,7 @@ size_t att_bwd_scratch_floats(const AttDims& d) {
   const ALayout L = make_alayout(d);
   const size_t N = d.N;
   return N * L.ZW + 2 * (d.cell == kCellFactored ? N * 4 * d.F : 8) + N * L.XW + N * d.H + 2 * (size_t)d.B * d.H +
-         (size_t)d.B * (d.C / 512) * d.P + (size_t)d.B * d.P * d.A + N * d.A + N + N * d.P + 4096 +
+         (size_t)d.B * (d.C / 256) * d.P + (size_t)d.B * d.P * d.A + N * d.A + N + N * d.P + 4096 +
          kAttSplitKFloats;
 }
 
@@ -178,20 +179,21 @@ int att_seq_forward(const AttDims& d, const int* bs, const unsigned char* tf,
 
   float* skws = scratch + (size_t)d.B * d.V + 64;
   float* escore = skws + kAttSplitKFloats;   // raw attention scores of the current step [b][P]
+  // tile counters of the one-launch products for steps of <= 16 rows (gemm_rows16_kernel): the tail of the slab area
+  int* skctr = reinterpret_cast<int*>(skws + kAttSplitKWs);
+  CAPNET_HIP_CHECK(hipMemsetAsync(skctr, 0, kSplitKCounters * sizeof(int), s));
   for (int t = 0; t < d.steps; ++t) {
     const int b = bs[t], r0 = off[t];
     const float* hprev = t > 0 ? hiddens + (size_t)off[t - 1] * H : sv + L.h0;
     const float* cprev = t > 0 ? sv + L.Cst + (size_t)off[t - 1] * H : sv + L.c0;
     float* Z = sv + L.Zf + (size_t)r0 * ZW;
     // Z = h . Wz^T + bz  ->  [recurrent gate pre-acts | att2 | f_beta(h)]
-    RC(sgemm_splitk(false, true, b, ZW, H, hprev, H, sv + L.Wz, H, Z, ZW, sv + L.bz, 0, skws,
-                    kAttSplitKFloats, s));
+    RC(sgemm_splitk(false, true, b, ZW, H, hprev, H, sv + L.Wz, H, Z, ZW, sv + L.bz, 0, skws, kAttSplitKWs, s, skctr, kSplitKCounters));
     RC(att_step_fwd(sv + L.att1, feat, Z + 4 * H, Z + 4 * H + A, ZW, w.full_att_w, w.full_att_b, b, P,
                     A, C, sv + L.alpha + (size_t)r0 * P, alphas_bt, d.steps, t,
                     sv + L.awe + (size_t)r0 * C, sv + L.XA + (size_t)r0 * XW + E, XW, escore, s));
     if (t > 0 && !tf[t]) {
-      RC(sgemm_splitk(false, true, b, d.V, H, hprev, H, Cw, H, scratch, d.V, Cb, 0, skws,
-                      kAttSplitKFloats, s));
+      RC(sgemm_splitk(false, true, b, d.V, H, hprev, H, Cw, H, scratch, d.V, Cb, 0, skws, kAttSplitKWs, s, skctr, kSplitKCounters));
       RC(argmax_rows(scratch, b, d.V, d.V, saved_i + L.row_token + r0, s));
       RC(gather_inputs(captions, d.T, nullptr, emb, E, d.V, saved_i + L.row_sample,
                        saved_i + L.row_col, saved_i + L.row_token, sv + L.XA, XW, r0, r0 + b,
@@ -200,17 +202,16 @@ int att_seq_forward(const AttDims& d, const int* bs, const unsigned char* tf,
     if (fac) {
       // factored chain on [x | gated context]
       RC(sgemm_splitk(false, true, b, 4 * F, XW, sv + L.XA + (size_t)r0 * XW, XW, sv + L.Vcat, XW,
-                      sv + L.A1 + (size_t)r0 * 4 * F, 4 * F, sv + L.bV, 0, skws, kAttSplitKFloats, s));
+                      sv + L.A1 + (size_t)r0 * 4 * F, 4 * F, sv + L.bV, 0, skws, kAttSplitKWs, s, skctr, kSplitKCounters));
       RC(sgemm_splitk_batched(false, true, b, F, F, sv + L.A1 + (size_t)r0 * 4 * F, 4 * F, sv + L.Scat,
                               F, sv + L.A2 + (size_t)r0 * 4 * F, 4 * F, sv + L.bS, 0, 4, F,
-                              (long)F * F, F, F, skws, kAttSplitKFloats, s));
+                              (long)F * F, F, F, skws, kAttSplitKWs, s, skctr, kSplitKCounters));
       RC(sgemm_splitk_batched(false, true, b, H, F, sv + L.A2 + (size_t)r0 * 4 * F, 4 * F, sv + L.Ucat,
-                              F, Z, ZW, nullptr, 1, 4, F, (long)H * F, H, 0, skws, kAttSplitKFloats,
-                              s));
+                              F, Z, ZW, nullptr, 1, 4, F, (long)H * F, H, 0, skws, kAttSplitKWs, s, skctr, kSplitKCounters));
     } else {
       // nn.LSTMCell input product: gates += [x | gated context] . weight_ih^T
       RC(sgemm_splitk(false, true, b, 4 * H, XW, sv + L.XA + (size_t)r0 * XW, XW, sv + L.Vcat, XW, Z,
-                      ZW, nullptr, 1, skws, kAttSplitKFloats, s));
+                      ZW, nullptr, 1, skws, kAttSplitKWs, s, skctr, kSplitKCounters));
     }
     RC(lstm_pointwise_fwd(Z, ZW, cprev, sv + L.Cst + (size_t)r0 * H, hiddens + (size_t)r0 * H, b, H,
                           go.gi, go.gf, go.go, go.gg, go.tanh_out, s));
@@ -243,12 +244,14 @@ int att_seq_backward(const AttDims& d, const int* bs, const float* dH, const flo
   float* Hprev = scratch + take((size_t)N * H);
   float* dh_rec = scratch + take((size_t)d.B * H);
   float* dc = scratch + take((size_t)d.B * H);
-  float* dalpha_part = scratch + take((size_t)d.B * (C / 512) * P);
+  float* dalpha_part = scratch + take((size_t)d.B * (C / 256) * P);
   float* datt1 = scratch + take((size_t)d.B * P * A);
   float* dwf_rows = scratch + take((size_t)N * A);
   float* dbf_rows = scratch + take((size_t)N);
   float* de_all = scratch + take((size_t)N * P);   // softmax-backward scores of every row
   float* skws = scratch + take(kAttSplitKFloats);
+  int* skctr = reinterpret_cast<int*>(skws + kAttSplitKWs);
+  CAPNET_HIP_CHECK(hipMemsetAsync(skctr, 0, kSplitKCounters * sizeof(int), s));
   CAPNET_HIP_CHECK(hipMemsetAsync(dh_rec, 0, (size_t)d.B * H * sizeof(float), s));
   CAPNET_HIP_CHECK(hipMemsetAsync(dc, 0, (size_t)d.B * H * sizeof(float), s));
 
@@ -262,24 +265,23 @@ int att_seq_backward(const AttDims& d, const int* bs, const float* dH, const flo
                           Z, ZW, b, b_next, H, go.gi, go.gf, go.go, go.gg, go.tanh_out, s));
     if (fac) {
       RC(sgemm_splitk_batched(false, false, b, F, H, Z, ZW, sv + L.Ucat, F, dA2 + (size_t)r0 * 4 * F,
-                              4 * F, nullptr, 0, 4, H, (long)H * F, F, 0, skws, kAttSplitKFloats, s));
+                              4 * F, nullptr, 0, 4, H, (long)H * F, F, 0, skws, kAttSplitKWs, s, skctr, kSplitKCounters));
       RC(sgemm_splitk_batched(false, false, b, F, F, dA2 + (size_t)r0 * 4 * F, 4 * F, sv + L.Scat, F,
                               dA1 + (size_t)r0 * 4 * F, 4 * F, nullptr, 0, 4, F, (long)F * F, F, 0,
-                              skws, kAttSplitKFloats, s));
+                              skws, kAttSplitKWs, s, skctr, kSplitKCounters));
       RC(sgemm_splitk(false, false, b, XW, 4 * F, dA1 + (size_t)r0 * 4 * F, 4 * F, sv + L.Vcat, XW,
-                      dXA + (size_t)r0 * XW, XW, nullptr, 0, skws, kAttSplitKFloats, s));
+                      dXA + (size_t)r0 * XW, XW, nullptr, 0, skws, kAttSplitKWs, s, skctr, kSplitKCounters));
     } else {
       // d[x | ctx] = d gates . weight_ih
       RC(sgemm_splitk(false, false, b, XW, 4 * H, Z, ZW, sv + L.Vcat, XW, dXA + (size_t)r0 * XW, XW,
-                      nullptr, 0, skws, kAttSplitKFloats, s));
+                      nullptr, 0, skws, kAttSplitKWs, s, skctr, kSplitKCounters));
     }
     RC(att_step_bwd(sv + L.att1, feat, Zf + 4 * H, ZW, Zf + 4 * H + A, ZW, sv + L.awe + (size_t)r0 * C,
                     sv + L.alpha + (size_t)r0 * P, w.full_att_w, dXA + (size_t)r0 * XW + E, XW,
                     dalphas_bt, d.steps, t, b, P, A, C, dalpha_part, Z + 4 * H + A, Z + 4 * H, ZW,
                     de_all + (size_t)r0 * P, dwf_rows + (size_t)r0 * A, dbf_rows + r0, s));
     // dh_{t-1} (or dh0) = dZ . Wz
-    RC(sgemm_splitk(false, false, b, H, ZW, Z, ZW, sv + L.Wz, H, dh_rec, H, nullptr, 0, skws,
-                    kAttSplitKFloats, s));
+    RC(sgemm_splitk(false, false, b, H, ZW, Z, ZW, sv + L.Wz, H, dh_rec, H, nullptr, 0, skws, kAttSplitKWs, s, skctr, kSplitKCounters));
   }
   // ---- weight gradients over all rows at once
   RC(gather_prev_rows(hiddens, saved_i + L.prev_row, sv + L.h0, saved_i + L.row_sample, Hprev, N, H, s));
@@ -305,7 +307,7 @@ int att_seq_backward(const AttDims& d, const int* bs, const float* dH, const flo
   RC(att_datt1(sv + L.att1, sv + L.Zf + 4 * H, ZW, de_all, w.full_att_w, off.data(), d.steps, d.B, P, A,
                datt1, s));
   RC(sgemm(true, false, A, C, d.B * P, datt1, A, feat, C, g.dWe, C, nullptr, 0, 1, 0, 0, 0, 0, 0, s));
-  RC(colsum(datt1, A, d.B * P, A, g.dbe, 0, s, skws, kAttSplitKFloats));
+  RC(colsum(datt1, A, d.B * P, A, g.dbe, 0, s, skws, kAttSplitKWs));
   // init_h / init_c: dh0 = dh_rec, dc0 = dc (all B rows are alive at t = 0)
   RC(sgemm(true, false, H, C, d.B, dh_rec, H, sv + L.mean, C, g.dWih, C, nullptr, 0, 1, 0, 0, 0, 0, 0, s));
   RC(colsum(dh_rec, H, d.B, H, g.dbih, 0, s));

@@ -101,7 +101,7 @@ int copy_d2d(float* dst, const float* src, size_t n, hipStream_t s) {
 // gate pre-activations of rows [r0, r1) from their inputs X. ws: slab workspace of the per-step
 // (few rows) products; the all-rows call up front has enough tiles for the plain kernel.
 int input_chain(const SeqDims& d, const Layout& L, float* sv, int r0, int r1, float* ws,
-                size_t ws_floats, hipStream_t s) {
+                size_t ws_floats, hipStream_t s, int* ctr = nullptr) {
   const int n = r1 - r0;
   if (n <= 0) return kOk;
   const int E = d.E, F = d.F, H = d.H;
@@ -109,20 +109,20 @@ int input_chain(const SeqDims& d, const Layout& L, float* sv, int r0, int r1, fl
     // A1 = X . Vcat^T + bV                          [n x 4F]
     RC(sgemm_splitk(false, true, n, 4 * F, E, sv + L.X + (size_t)r0 * E, E, sv + L.Vcat, E,
                     sv + L.A1 + (size_t)r0 * 4 * F, 4 * F, sv + L.bV, 0, n <= 128 ? ws : nullptr,
-                    ws_floats, s));
+                    ws_floats, s, ctr, kSplitKCounters));
     // A2[:, g] = A1[:, g] . S_g^T + bS_g             4 gate groups
     RC(sgemm_splitk_batched(false, true, n, F, F, sv + L.A1 + (size_t)r0 * 4 * F, 4 * F, sv + L.Scat, F,
                             sv + L.A2 + (size_t)r0 * 4 * F, 4 * F, sv + L.bS, 0, 4, F, (long)F * F, F,
-                            F, n <= 128 ? ws : nullptr, ws_floats, s));
+                            F, n <= 128 ? ws : nullptr, ws_floats, s, ctr, kSplitKCounters));
     // G[:, g] = A2[:, g] . U_g^T + (bU_g + bW_g)
     RC(sgemm_splitk_batched(false, true, n, H, F, sv + L.A2 + (size_t)r0 * 4 * F, 4 * F, sv + L.Ucat, F,
                             sv + L.G + (size_t)r0 * 4 * H, 4 * H, sv + L.bUW, 0, 4, F, (long)H * F, H,
-                            H, n <= 128 ? ws : nullptr, ws_floats, s));
+                            H, n <= 128 ? ws : nullptr, ws_floats, s, ctr, kSplitKCounters));
   } else {
     // G = X . W_ih^T + (b_ih + b_hh)
     RC(sgemm_splitk(false, true, n, 4 * H, E, sv + L.X + (size_t)r0 * E, E, sv + L.Vcat, E,
                     sv + L.G + (size_t)r0 * 4 * H, 4 * H, sv + L.bUW, 0, n <= 128 ? ws : nullptr,
-                    ws_floats, s));
+                    ws_floats, s, ctr, kSplitKCounters));
   }
   return kOk;
 }
@@ -133,6 +133,7 @@ size_t seq_saved_floats(const SeqDims& d) { return make_layout(d).total; }
 size_t seq_saved_ints(const SeqDims& d) { return make_layout(d).itotal; }
 
 constexpr size_t kSplitKFloats = 32ull * 64 * 2048;  // slabs for the per-step skinny GEMMs (16 MB)
+constexpr size_t kSplitKWs = kSplitKFloats - kSplitKCounters;   // slabs | tile counters of the one-launch products (<= 16 rows)
 
 size_t seq_fwd_scratch_floats(const SeqDims& d) { return (size_t)d.B * d.V + 64 + kSplitKFloats; }
 
@@ -212,7 +213,9 @@ int seq_forward(const SeqDims& d, const int* batch_sizes, const unsigned char* t
                    saved_i + L.row_col, saved_i + L.row_token, sv + L.X, E, 0, N, dropout_p, seed,
                    training && dropout_p > 0.f, 0, err_flag, s));
   float* skws = scratch + (size_t)d.B * d.V + 64;
-  RC(input_chain(d, L, sv, 0, N, skws, kSplitKFloats, s));
+  int* skctr = reinterpret_cast<int*>(skws + kSplitKWs);
+  CAPNET_HIP_CHECK(hipMemsetAsync(skctr, 0, kSplitKCounters * sizeof(int), s));
+  RC(input_chain(d, L, sv, 0, N, skws, kSplitKWs, s, skctr));
 
   // ---- recurrence
   for (int t = 0; t < d.steps; ++t) {
@@ -222,12 +225,12 @@ int seq_forward(const SeqDims& d, const int* batch_sizes, const unsigned char* t
       if (!tf_mask[t]) {
         // predicted = argmax(C h_{t-1}) for the b surviving rows; then this step's input chain
         RC(sgemm_splitk(false, true, b, d.V, H, h_prev, H, Cw, H, scratch, d.V, Cb, 0, skws,
-                        kSplitKFloats, s));
+                        kSplitKWs, s, skctr, kSplitKCounters));
         RC(argmax_rows(scratch, b, d.V, d.V, saved_i + L.row_token + r0, s));
         RC(gather_inputs(captions, d.T, features, emb, E, d.V, saved_i + L.row_sample,
                          saved_i + L.row_col, saved_i + L.row_token, sv + L.X, E, r0, r0 + b,
                          dropout_p, seed, 0, 1, err_flag, s));
-        RC(input_chain(d, L, sv, r0, r0 + b, skws, kSplitKFloats, s));
+        RC(input_chain(d, L, sv, r0, r0 + b, skws, kSplitKWs, s, skctr));
       }
     }
     if (persist) {
@@ -254,7 +257,7 @@ int seq_forward(const SeqDims& d, const int* batch_sizes, const unsigned char* t
       }
       // G[rows] += h_{t-1} . Wcat^T
       RC(sgemm_splitk(false, true, b, 4 * H, H, h_prev, H, sv + L.Wcat, H,
-                      sv + L.G + (size_t)r0 * 4 * H, 4 * H, nullptr, 1, skws, kSplitKFloats, s));
+                      sv + L.G + (size_t)r0 * 4 * H, 4 * H, nullptr, 1, skws, kSplitKWs, s, skctr, kSplitKCounters));
     }
     RC(lstm_pointwise_fwd(sv + L.G + (size_t)r0 * 4 * H, 4 * H,
                           t > 0 ? sv + L.Cst + (size_t)off[t - 1] * H : nullptr,

@@ -314,6 +314,222 @@ static int launch_skinny(const float* A, long lda, const float* B, long ldb, flo
   return kOk;
 }
 
+
+// ---- M <= 16 rows (a 12-image batch's time step; decode; beam search): one launch, no reduce kernel --------------
+// The 64 x 64-tile kernel above loads 64 rows to use 12 and leaves the K-chunk sum to a second launch, whose
+// ~4 us + a kernel boundary is as long as the product itself at these sizes. Here a workgroup owns 16 rows x 64
+// columns x ONE 256-k chunk (v_mfma_f32_16x16x4_f32, one 16-column strip per wave, everything loaded in one round
+// trip), writes its partial tile to a slab, and the workgroup that arrives LAST at the tile's counter sums the
+// slabs -- in slab order, so the result does not depend on who was last -- adds the bias and writes C.
+// Cross-workgroup visibility is MI355X_MICROARCH.md's first measured hand-off row, cell by cell: every partial byte
+// stored `sc1` (16-B stores), every storing wave `s_waitcnt vmcnt(0)` (asm), a workgroup barrier, ONE lane's
+// agent-scope atomic add whose returned value tells the last arriver, that workgroup's other waves behind a barrier
+// the adding wave joins, every load of the partials `sc1`; hipMalloc memory; one workgroup per CU (the LDS
+// request is padded past half a CU's). The counters (one int per output tile, caller-provided, zero before the first
+// use) are put back to zero by the workgroup that consumed them.
+// The product is computed transposed (first MFMA operand = B) so that a lane holds 4 consecutive columns of one row.
+constexpr int kR16KC = 256;                 // k per workgroup
+constexpr int kR16ACell = 17;               // float4 cells per k-quad of the A image (16 rows + 1)
+constexpr int kR16BCell = 65;               // ... of the B^T image (64 columns + 1)
+constexpr int kR16Ldb = 68;                 // dword row stride of the [k][n] image (TB = false): the four k-quads of a
+                                            // fragment read land 16 banks apart
+constexpr size_t kR16LdsBytes = 100 * 1024; // > 80 KB: one workgroup per CU
+
+struct R16Args {
+  const float* A; const float* B; float* slab; float* C; const float* bias; int* counters;
+  long lda, ldb, ldc, sA, sB;
+  int M, N, K, tiles_n, splits, sub, accumulate;   // a workgroup owns `sub` consecutive 256-k chunks
+};
+
+template <bool TB>
+__global__ __launch_bounds__(256) void gemm_rows16_kernel(const R16Args g) {
+  typedef float f32x4v __attribute__((ext_vector_type(4)));
+  constexpr int KQ = kR16KC / 4;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  __shared__ int s_last;
+  f32x4v* a_cells = reinterpret_cast<f32x4v*>(lds);                    // [KQ][17] cells
+  float* b_img = lds + (size_t)KQ * kR16ACell * 4;                     // TB: [KQ][65] cells; else [KC][80]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tn = blockIdx.x % g.tiles_n, ks = blockIdx.x / g.tiles_n, z = blockIdx.z;
+  const int n0 = tn * 64;
+  const float* A = g.A + (long)z * g.sA;
+  const float* B = g.B + (long)z * g.sB;
+  // this workgroup's k range: `sub` chunks of 256, one load round trip each, the next one requested before the
+  // MFMAs of the current one (the host sizes splits x sub so that the grid is one wave of workgroups)
+  f32x4v va[4], vb[16];
+  auto request = [&](int k0) {
+    const int kq_real = (min(kR16KC, g.K - k0) + 3) / 4;   // K % 4 == 0 is required by the host
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int idx = tid + 256 * q, row = idx >> 6, kq = idx & 63;
+      va[q] = *reinterpret_cast<const f32x4v*>(A + (long)min(row, g.M - 1) * g.lda + k0 + 4 * min(kq, kq_real - 1));
+    }
+    if (TB) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int idx = tid + 256 * q, col = idx >> 6, kq = idx & 63;
+        vb[q] = *reinterpret_cast<const f32x4v*>(B + (long)min(n0 + col, g.N - 1) * g.ldb + k0 + 4 * min(kq, kq_real - 1));
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int idx = tid + 256 * q, kr = idx >> 4, c4 = idx & 15;
+        vb[q] = *reinterpret_cast<const f32x4v*>(B + (long)min(k0 + kr, g.K - 1) * g.ldb + min(n0 + 4 * c4, g.N - 4));
+      }
+    }
+  };
+  auto stage = [&](int k0) {
+    const int kq_real = (min(kR16KC, g.K - k0) + 3) / 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int idx = tid + 256 * q, row = idx >> 6, kq = idx & 63;
+      a_cells[kq * kR16ACell + row] = va[q] * ((row < g.M && kq < kq_real) ? 1.f : 0.f);
+    }
+    if (TB) {
+      f32x4v* b_cells = reinterpret_cast<f32x4v*>(b_img);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int idx = tid + 256 * q, col = idx >> 6, kq = idx & 63;
+        b_cells[kq * kR16BCell + col] = vb[q] * ((n0 + col < g.N && kq < kq_real) ? 1.f : 0.f);
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int idx = tid + 256 * q, kr = idx >> 4, c4 = idx & 15;
+        *reinterpret_cast<f32x4v*>(b_img + kr * kR16Ldb + 4 * c4) =
+            vb[q] * ((k0 + kr < g.K && n0 + 4 * c4 < g.N) ? 1.f : 0.f);   // N % 4 == 0: groups are all-or-nothing
+      }
+    }
+  };
+  // lane (r, q): operand element r (a row of A / a column of the wave's strip), k = 16 i + 4 q + e
+  const int r = lane & 15, q4 = lane >> 4;
+  f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+  const int kbeg = ks * g.sub * kR16KC;
+  request(kbeg);
+  for (int sc = 0; sc < g.sub; ++sc) {
+    const int k0 = kbeg + sc * kR16KC;
+    if (k0 >= g.K) break;                                  // (uniform: the last split may own fewer chunks)
+    stage(k0);
+    __syncthreads();
+    if (sc + 1 < g.sub && k0 + kR16KC < g.K) request(k0 + kR16KC);
+    if (TB) {
+      const f32x4v* b_cells = reinterpret_cast<const f32x4v*>(b_img);
+#pragma unroll 4
+      for (int i = 0; i < KQ / 4; ++i) {
+        const f32x4v a = a_cells[(4 * i + q4) * kR16ACell + r];
+        const f32x4v b = b_cells[(4 * i + q4) * kR16BCell + 16 * wave + r];
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(b[0], a[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(b[1], a[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(b[2], a[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(b[3], a[3], acc, 0, 0, 0);
+      }
+    } else {
+      const float* bp = b_img + (4 * q4) * kR16Ldb + 16 * wave + r;
+#pragma unroll 4
+      for (int i = 0; i < KQ / 4; ++i) {
+        const f32x4v a = a_cells[(4 * i + q4) * kR16ACell + r];
+        const float* bk = bp + (16 * i) * kR16Ldb;
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(bk[0], a[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(bk[kR16Ldb], a[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(bk[2 * kR16Ldb], a[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(bk[3 * kR16Ldb], a[3], acc, 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  // D^T: lane (r, q) holds row m = r, columns n0 + 16 wave + 4 q + (0..3)
+  const int m = r, n = n0 + 16 * wave + 4 * q4;
+  const long ldo = (long)gridDim.z * g.N;               // a slab row: the batch members' columns side by side
+  const long col = (long)z * g.N + n;
+  if (g.splits == 1) {                                  // the whole K in this workgroup: no slab, no hand-off
+    if (m < g.M && n < g.N) {
+      float* o = g.C + (long)m * g.ldc + col;
+      f32x4v v = acc;
+      if (g.bias) v += *reinterpret_cast<const f32x4v*>(g.bias + col);
+      if (g.accumulate) v += *reinterpret_cast<const f32x4v*>(o);
+      *reinterpret_cast<f32x4v*>(o) = v;
+    }
+    return;
+  }
+  if (m < g.M && n < g.N) {
+    float* o = g.slab + ((long)ks * g.M + m) * ldo + col;
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(o), "v"(acc) : "memory");
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int* ctr = g.counters + z * g.tiles_n + tn;
+  if (tid == 0) s_last = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == g.splits - 1;
+  __syncthreads();
+  if (!s_last) return;
+  {
+    // 16 rows x 16 column quads = one per thread; every slab in flight at once (4-B sc1 loads)
+    const int rm = tid >> 4, rn = n0 + 4 * (tid & 15);
+    if (rm < g.M && rn < g.N) {
+      const long rc = (long)z * g.N + rn;
+      const float* p = g.slab + (long)rm * ldo + rc;
+      const long slab_stride = (long)g.M * ldo;
+      f32x4v sum = {0.f, 0.f, 0.f, 0.f};
+      for (int k = 0; k < g.splits; k += 16) {
+        f32x4v v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const float* pk = p + (long)min(k + u, g.splits - 1) * slab_stride;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[u][e] = __hip_atomic_load(pk + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+          if (k + u < g.splits) sum += v[u];
+      }
+      float* o = g.C + (long)rm * g.ldc + rc;
+      if (g.bias) sum += *reinterpret_cast<const f32x4v*>(g.bias + rc);
+      if (g.accumulate) sum += *reinterpret_cast<const f32x4v*>(o);
+      *reinterpret_cast<f32x4v*>(o) = sum;
+    }
+    if (tid == 0) __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// true when the shape went to gemm_rows16_kernel
+static bool try_rows16(bool tb, int M, int N, int K, const float* A, long lda, const float* B, long ldb, float* C,
+                       long ldc, const float* bias, int accumulate, int batch, long sA, long sB, float* ws,
+                       size_t ws_floats, int* counters, size_t n_counters, hipStream_t stream) {
+  if (!counters || M > 16 || N % 4 != 0 || N < 4 || ldc % 4 != 0 || !aligned16(C) || (bias && !aligned16(bias)) ||
+      !aligned16(ws))
+    return false;
+  // One wave of workgroups (<= 256, one per CU). A workgroup takes `sub` chunks of 256 k one after the other
+  // (load round trip + staging + MFMAs: ~2.2 us each); K cut into `splits` costs the hand-off once (~3.5 us + 0.25 us
+  // per slab the last workgroup has to fetch). Fitted to a sweep over `sub` on the six step shapes of a 12-image
+  // attention batch (12 x {4608,8192,512} x 512: no split, 7.7-7.9 us against 10.6-11.4 for skinny + reduce;
+  // 12 x 2048 x 2348: 2 chunks x 5 splits, 12.1 against 15.7; tools/rows16_bench.py).
+  const int tiles_n = cdiv(N, 64), chunks = cdiv(K, kR16KC);
+  int sub = chunks, splits = 1;
+  float best = 2.2f * chunks;
+  for (int ns = 1; ns < chunks; ++ns) {
+    const int sp = cdiv(chunks, ns);
+    if ((long)tiles_n * batch * sp > 256) continue;
+    const float cost = 2.2f * ns + 3.5f + 0.25f * sp;
+    if (cost < best) { best = cost; sub = ns; splits = sp; }
+  }
+  if ((size_t)tiles_n * batch > n_counters || (splits > 1 && (size_t)splits * M * N * batch > ws_floats)) return false;
+  R16Args g;
+  g.A = A; g.B = B; g.slab = ws; g.C = C; g.bias = bias; g.counters = counters;
+  g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.sA = sA; g.sB = sB;
+  g.M = M; g.N = N; g.K = K; g.tiles_n = tiles_n; g.splits = splits; g.sub = sub; g.accumulate = accumulate;
+  static bool attr_set[2] = {false, false};
+  const void* kern = tb ? (const void*)gemm_rows16_kernel<true> : (const void*)gemm_rows16_kernel<false>;
+  if (!attr_set[tb]) {
+    if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kR16LdsBytes) != hipSuccess) {
+      (void)hipGetLastError();
+      return false;
+    }
+    attr_set[tb] = true;
+  }
+  if (tb) hipLaunchKernelGGL(gemm_rows16_kernel<true>, dim3(tiles_n * splits, 1, batch), dim3(256), kR16LdsBytes, stream, g);
+  else hipLaunchKernelGGL(gemm_rows16_kernel<false>, dim3(tiles_n * splits, 1, batch), dim3(256), kR16LdsBytes, stream, g);
+  return true;
+}
+
 int reduce_slabs(const float* slab, int count, int M, int N, float* out, long ldc, const float* bias,
                  int accumulate, hipStream_t stream) {
   CAPNET_REQUIRE(slab && out && count > 0 && M > 0 && N > 0, "reduce_slabs: bad argument");
@@ -329,7 +545,7 @@ int reduce_slabs(const float* slab, int count, int M, int N, float* out, long ld
 int sgemm_splitk_batched(bool ta, bool tb, int M, int N, int K, const float* A, long lda,
                          const float* B, long ldb, float* C, long ldc, const float* bias,
                          int accumulate, int batch, long sA, long sB, long sC, long sBias, float* ws,
-                         size_t ws_floats, hipStream_t stream) {
+                         size_t ws_floats, hipStream_t stream, int* counters, size_t n_counters) {
   if (M == 0 || N == 0 || batch == 0) return kOk;
   const bool skinny_ok = !ta && ws && M <= 128 && K % 4 == 0 && lda % 4 == 0 && aligned16(A) &&
                          aligned16(B) && ldb % 4 == 0 && (tb || N % 4 == 0) && N >= 4 && K >= 64 &&
@@ -364,6 +580,11 @@ int sgemm_splitk_batched(bool ta, bool tb, int M, int N, int K, const float* A, 
                  0, stream);
   }
   CAPNET_REQUIRE(A && B && C, "sgemm_splitk: null operand");
+  if (try_rows16(tb, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, batch, sA, sB, ws, ws_floats, counters, n_counters,
+                 stream)) {
+    CAPNET_LAUNCH_CHECK();
+    return kOk;
+  }
   const long tiles = (long)cdiv(M, 64) * cdiv(N, 64) * batch;
   const size_t out_floats = (size_t)M * N * batch;
   // one K chunk per workgroup: 64 when that still leaves the chip under-filled, else 128
@@ -415,9 +636,9 @@ int sgemm_splitk_slabs(bool tb, int M, int N, int K, const float* A, long lda, c
 
 int sgemm_splitk(bool ta, bool tb, int M, int N, int K, const float* A, long lda, const float* B,
                  long ldb, float* C, long ldc, const float* bias, int accumulate, float* ws,
-                 size_t ws_floats, hipStream_t stream) {
+                 size_t ws_floats, hipStream_t stream, int* counters, size_t n_counters) {
   return sgemm_splitk_batched(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, 1, 0, 0, 0, 0,
-                              ws, ws_floats, stream);
+                              ws, ws_floats, stream, counters, n_counters);
 }
 
 }  // namespace capnet

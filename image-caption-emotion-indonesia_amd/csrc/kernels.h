@@ -10,15 +10,19 @@ int sgemm(bool ta, bool tb, int M, int N, int K, const float* A, long lda, const
           long ldb, float* C, long ldc, const float* bias, int accumulate, int batch, long sA,
           long sB, long sC, long sBias, int force_tile, hipStream_t stream);
 
+// counters (optional): n_counters ints, zero before the first use and left zero by every call -- one per 64-column
+// output tile and batch member; with them, products of M <= 16 rows are ONE launch (gemm_rows16_kernel: the
+// workgroup that arrives last at a tile sums the K-chunk partials)
+constexpr size_t kSplitKCounters = 1024;
 int sgemm_splitk(bool ta, bool tb, int M, int N, int K, const float* A, long lda, const float* B,
                  long ldb, float* C, long ldc, const float* bias, int accumulate, float* ws,
-                 size_t ws_floats, hipStream_t stream);
+                 size_t ws_floats, hipStream_t stream, int* counters = nullptr, size_t n_counters = 0);
 int sgemm_splitk_slabs(bool tb, int M, int N, int K, const float* A, long lda, const float* B, long ldb,
                        float* ws, size_t ws_floats, int* n_slabs, hipStream_t stream);
 int sgemm_splitk_batched(bool ta, bool tb, int M, int N, int K, const float* A, long lda,
                          const float* B, long ldb, float* C, long ldc, const float* bias,
                          int accumulate, int batch, long sA, long sB, long sC, long sBias, float* ws,
-                         size_t ws_floats, hipStream_t stream);
+                         size_t ws_floats, hipStream_t stream, int* counters = nullptr, size_t n_counters = 0);
 
 // conv_f32.hip
 int conv2d_fwd(const float* x, long sxb, long sxh, long sxw, long sxc, const float* w_packed,

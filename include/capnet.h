@@ -57,6 +57,16 @@ int capnet_sgemm_splitk(int transA, int transB, int M, int N, int K, const float
                         int accumulate, float* workspace, size_t workspace_floats,
                         capnet_stream_t stream);
 
+/* The same, with tile counters: `counters` = n_counters ints (>= ceil(N/64)), zero before the first call and left
+ * zero by every call. With them a product of M <= 16 rows (the time step of a 12-image batch, decoding) is ONE
+ * launch: a workgroup per (16 rows x 64 columns, 256-k chunk), and the workgroup that arrives last at a tile's
+ * counter sums the chunk partials in chunk order (csrc/gemm_f32.hip, gemm_rows16_kernel). Other shapes: as
+ * capnet_sgemm_splitk. Calls that share `counters` or `workspace` must be ordered on one stream. */
+int capnet_sgemm_splitk_fused(int transA, int transB, int M, int N, int K, const float* A, long lda,
+                              const float* B, long ldb, float* C, long ldc, const float* bias,
+                              int accumulate, float* workspace, size_t workspace_floats, int* counters,
+                              size_t n_counters, capnet_stream_t stream);
+
 /* out[c] (+)= sum_r x[r][c]  -- bias gradients (autograd of nn.Linear bias). */
 int capnet_colsum(const float* x, long ld, int rows, int C, float* out, int accumulate,
                   capnet_stream_t stream);

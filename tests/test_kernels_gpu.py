@@ -316,6 +316,51 @@ def test_sgemm_splitk_matches_fp64(dev, M, N, K, tb):
     assert (Cd2.cpu().double() - ref).abs().max().item() / ref.abs().max().item() < 6e-6
 
 
+# ---- the same for steps of <= 16 rows: one launch, the last workgroup of a tile sums the K chunks ---------
+@pytest.mark.parametrize("tb", [True, False])
+@pytest.mark.parametrize("M,N,K", [(12, 4608, 512), (12, 2048, 2348), (12, 512, 4608), (12, 2348, 2048), (16, 8192, 512),
+                                   (1, 64, 64), (5, 36, 72), (3, 300, 1000), (12, 512, 256), (9, 2048, 9216)])
+def test_sgemm_rows16_one_launch_matches_fp64_and_is_reproducible(dev, M, N, K, tb):
+    """gemm_rows16_kernel (csrc/gemm_f32.hip): every step product of a 12-image attention batch
+    (model_att.py:59-60,196-236,283 at b = 12), against float64; the result does not depend on which workgroup
+    arrives last (20 repeats are bit-identical, also with other work on the device), the counters are left zero,
+    bias and accumulation as in the two-launch path."""
+    from capnet._lib import lib, check, ptr, current_stream
+    g = torch.Generator().manual_seed(M * 7 + N + K)
+    A = torch.randn(M, K, generator=g)
+    B = torch.randn(N, K, generator=g) if tb else torch.randn(K, N, generator=g)
+    bias = torch.randn(N, generator=g)
+    C0 = torch.randn(M, N, generator=g)
+    ref = A.double() @ (B.double().t() if tb else B.double()) + bias.double() + C0.double()
+    Ad, Bd, bd = A.to(dev), B.to(dev), bias.to(dev)
+    ws = torch.empty(40 * 16 * 8192, device=dev)
+    ctr = torch.zeros(1024, dtype=torch.int32, device=dev)
+    noise = torch.randn(4096, 4096, device=dev)
+    side = torch.cuda.Stream()
+    outs = []
+    for rep in range(20):
+        Cd = C0.to(dev)
+        if rep >= 10:                                  # uneven load beside it
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                noise @ noise
+        check(lib().capnet_sgemm_splitk_fused(0, int(tb), M, N, K, ptr(Ad), K, ptr(Bd), Bd.shape[1], ptr(Cd), N,
+                                              ptr(bd), 1, ptr(ws), ws.numel(), ptr(ctr), ctr.numel(), current_stream()))
+        outs.append(Cd)
+    torch.cuda.synchronize()
+    assert int(ctr.abs().sum().item()) == 0
+    err = (outs[0].cpu().double() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 2e-6, err
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    # without bias, without accumulation
+    Cd = torch.full((M, N), float("nan"), device=dev)
+    check(lib().capnet_sgemm_splitk_fused(0, int(tb), M, N, K, ptr(Ad), K, ptr(Bd), Bd.shape[1], ptr(Cd), N,
+                                          None, 0, ptr(ws), ws.numel(), ptr(ctr), ctr.numel(), current_stream()))
+    ref0 = A.double() @ (B.double().t() if tb else B.double())
+    assert (Cd.cpu().double() - ref0).abs().max().item() / ref0.abs().max().item() < 2e-6
+
+
 # ---- LDS-DMA NT GEMM / 1x1 convolution core (csrc/gemm_dma.hip) --------------------------------
 @pytest.mark.parametrize("M,N,K,bias", [(999, 8192, 512, True),     # the vocabulary projection of configs[1]
                                         (128, 128, 32, False),       # one tile, one k-tile
