@@ -61,11 +61,15 @@ def main():
             ps = torch.empty(t1, Cout, device=dev)
             pq = torch.empty(t1, Cout, device=dev)
 
+        # (the split-f16 kernel keeps a folded input's scale / shift in LDS: Cin <= 512; the wider 1x1 inputs of the trunk
+        #  arrive activated, from the tail-absorbing conv1)
+        no_pre = args.no_pre or (use_h3 and Cin > 512)
+
         def run():
             if use_h3:
                 check(lib().capnet_conv2d_fwd_f16x3(ptr(x), H * H * Cin, H * Cin, Cin, ptr(img), bn, ptr(y),
-                                                    None if args.no_pre else ptr(sc), None if args.no_pre else ptr(sh),
-                                                    0 if args.no_pre else 1, ptr(ps), ptr(pq), B, H, H, Cin, Cout, k, stride, pad,
+                                                    None if no_pre else ptr(sc), None if no_pre else ptr(sh),
+                                                    0 if no_pre else 1, ptr(ps), ptr(pq), B, H, H, Cin, Cout, k, stride, pad,
                                                     None, None, None, 0, current_stream()))
                 return
             if not args.v1:
