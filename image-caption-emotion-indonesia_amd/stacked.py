@@ -16,10 +16,12 @@ With num_layers = 1 it is DecoderFactoredLSTM's function (tests/test_stacked_gpu
 checked against the same definition restated on the CPU (oracle/decoders_ref.py: stacked_factored_lstm_forward).
 
 Engine: runs of teacher-forced steps are processed layer by layer -- a layer's input chain U(S(V x)) over all rows of
-the run as batched MFMA GEMMs (ops.linear), the recurrence step by step (W GEMM + the fused cell kernel,
-ops.lstm_cell) -- with torch autograd composing the backward from those kernels' own backward functions. It is the
-simple engine, not the fast one: the single-layer path's fused sequence driver and persistent kernel do not apply
-to it yet."""
+the run as three MFMA GEMMs (the four gates' layers stacked: GateLinearFn), then the run's recurrence in ONE launch of the persistent kernel with its
+own backward through time (LstmRunFn below; H = 512, <= 128 rows) -- or, for a lone step and for sizes the persistent
+kernel does not take, step by step (W GEMM + the fused cell kernel, ops.lstm_cell, torch autograd composing the
+backward). torch is glue here (embedding gather, dropout masks, bias adds, concatenations). The single-layer path's
+fused sequence driver (csrc/decoder_seq.cpp) is still the faster structure; it does not apply to stacked cells yet
+(DESIGN 7)."""
 import random
 import sys
 
@@ -27,12 +29,131 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as Fn
 
-from . import ops
-from ._lib import CapnetError
+from torch.autograd.function import once_differentiable
+
+from . import _lib, ops
+from ._lib import CapnetError, check, current_stream, int_array, ptr
 from .model import Embedding as _Embedding, Linear as _Linear
 
 MODES = ("factual", "happy", "sad", "angry")
 _S_PREFIX = {"factual": "f", "happy": "happy_", "sad": "sad_", "angry": "angry_"}
+
+
+class LstmRunFn(torch.autograd.Function):
+    """A run of recurrent steps of one LSTM layer in ONE launch of the persistent kernel (csrc/lstm_persist.hip), with
+    its backward through time: the recurrence of stylenet/model.py:147-153,180-191 (cell 0) / nn.LSTMCell (cell 1) over
+    steps whose inputs are all known up front.
+
+        pre   [sum(bs), 4H]  pre-activations of the steps without the recurrent product (all biases included), packed
+                             step-major (rows of step t: bs[t], non-increasing)
+        w     [4H, H]        the recurrent weights (gate blocks in the cell's order)
+        h0, c0 [bs[0], H]     state in front of the first step
+    -> hiddens [sum(bs), H] (packed like pre), c_last [bs[-1], H]
+
+    Backward: per step (last to first) one gate-backward kernel and one product dPre . w for the state gradient,
+    then the weight gradient over all rows at once."""
+
+    @staticmethod
+    def forward(ctx, pre, w, h0, c0, bs, cell):
+        ops._need_cuda(pre, w, h0, c0)
+        L = _lib.lib()
+        n, rows, H = len(bs), sum(bs), w.shape[1]
+        b0 = bs[0]
+        if pre.shape != (rows, 4 * H) or h0.shape != (b0, H) or c0.shape != (b0, H) or w.shape[0] != 4 * H:
+            raise CapnetError("lstm_run: shapes do not match the batch sizes")
+        if not L.capnet_lstm_persist_supported(b0, H) or n + 1 > 128:
+            raise CapnetError("lstm_run: the persistent kernel does not take b=%d H=%d steps=%d" % (b0, H, n))
+        dev = pre.device
+        # step 0 of the buffers is the incoming state: the kernel picks h, c of step t0 - 1 up from the output buffers
+        G = torch.empty((b0 + rows, 4 * H), dtype=torch.float32, device=dev)
+        G[b0:].copy_(pre.detach())
+        hid = torch.empty((b0 + rows, H), dtype=torch.float32, device=dev)
+        cst = torch.empty((b0 + rows, H), dtype=torch.float32, device=dev)
+        hid[:b0].copy_(h0.detach())
+        cst[:b0].copy_(c0.detach())
+        img = torch.empty(L.capnet_lstm_persist_w_floats(), dtype=torch.float32, device=dev)
+        wc = w.detach().contiguous()
+        check(L.capnet_lstm_persist_pack(ptr(wc), ptr(img), cell, current_stream()), "capnet_lstm_persist_pack")
+        ctl = torch.zeros(L.capnet_lstm_persist_ctl_ints(), dtype=torch.int32, device=dev)
+        full = [b0] + list(bs)
+        check(L.capnet_lstm_persist_run(ptr(img), ptr(G), ptr(cst), ptr(hid), int_array(full), 1, n + 1, H, cell, 1,
+                                        ptr(ctl), ptr(ops.err_flag(dev)), None, current_stream()), "capnet_lstm_persist_run")
+        ctx.save_for_backward(G, cst, hid, wc)
+        ctx.full, ctx.cell = full, cell
+        return hid[b0:], cst[b0 + rows - bs[-1]:]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, d_hid, d_clast):
+        G, cst, hid, w = ctx.saved_tensors
+        full, cell = ctx.full, ctx.cell
+        L = _lib.lib()
+        n, b0, H = len(full) - 1, full[0], w.shape[1]
+        off = [0]
+        for v in full:
+            off.append(off[-1] + v)
+        rows = off[-1] - b0
+        dev = G.device
+        d_hid = d_hid.contiguous() if d_hid is not None else torch.zeros((rows, H), dtype=torch.float32, device=dev)
+        dpre = torch.empty((rows, 4 * H), dtype=torch.float32, device=dev)
+        dh_rec = torch.zeros((b0, H), dtype=torch.float32, device=dev)      # rows beyond a step's batch: samples that
+        dc = torch.zeros((b0, H), dtype=torch.float32, device=dev)          # have ended -- their later steps give nothing
+        if d_clast is not None:
+            dc[:full[-1]] += d_clast
+        for t in range(n, 0, -1):
+            bt, r0 = full[t], off[t]
+            dh = d_hid[r0 - b0:r0 - b0 + bt] + dh_rec[:bt]
+            cp = cst[off[t - 1]:off[t - 1] + bt]
+            dp = dpre[r0 - b0:r0 - b0 + bt]
+            check(L.capnet_lstm_pointwise_bwd(ptr(G[r0:r0 + bt]), ptr(cst[r0:r0 + bt]), ptr(cp), ptr(dh), ptr(dc[:bt]),
+                                              ptr(dp), bt, H, cell, current_stream()), "capnet_lstm_pointwise_bwd")
+            dh_rec[:bt] = ops.sgemm_splitk(dp, w)                                 # [bt, 4H] @ [4H, H]
+        hprev = torch.cat([hid[off[t - 1]:off[t - 1] + full[t]] for t in range(1, n + 1)], 0)
+        dw = ops.sgemm(dpre, hprev, transA=True)                                 # [4H, rows] @ [rows, H]
+        return dpre, dw, dh_rec, dc, None, None
+
+
+def lstm_run(pre, w, h0, c0, batch_sizes, cell=0):
+    return LstmRunFn.apply(pre, w, h0, c0, [int(v) for v in batch_sizes], cell)
+
+
+def lstm_run_supported(b, H, steps):
+    return bool(_lib.lib().capnet_lstm_persist_supported(int(b), int(H))) and 2 <= steps < 128
+
+
+class GateLinearFn(torch.autograd.Function):
+    """The four gates' nn.Linear layers of one stage of the factored chain (S_g or U_g, stylenet/model.py:119-150) as
+    ONE batched product: y[:, g-th block of `out`] = x[:, g-th block of `inp`] @ w[g]^T + b[g].
+        x [rows, 4*inp], w [4, out, inp] (the four weights stacked), b [4*out]  ->  y [rows, 4*out]
+    Forward, d x and d w are one capnet_sgemm call each (batch = 4 over column blocks), d b a column sum."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ops._need_cuda(x, w, b)
+        x, w = x.contiguous(), w.contiguous()
+        rows, out, inp = x.shape[0], w.shape[1], w.shape[2]
+        if w.shape[0] != 4 or x.shape[1] != 4 * inp or b.shape[0] != 4 * out:
+            raise CapnetError("gate_linear: shapes")
+        y = torch.empty((rows, 4 * out), dtype=torch.float32, device=x.device)
+        check(_lib.lib().capnet_sgemm(0, 1, rows, out, inp, ptr(x), 4 * inp, ptr(w), inp, ptr(y), 4 * out, ptr(b), 0,
+                                      4, inp, out * inp, out, out, 0, current_stream()), "capnet_sgemm")
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        rows, out, inp = x.shape[0], w.shape[1], w.shape[2]
+        L = _lib.lib()
+        dx = torch.empty_like(x)
+        check(L.capnet_sgemm(0, 0, rows, inp, out, ptr(dy), 4 * out, ptr(w), inp, ptr(dx), 4 * inp, None, 0,
+                             4, out, out * inp, inp, 0, 0, current_stream()), "capnet_sgemm")
+        dw = torch.empty_like(w)
+        check(L.capnet_sgemm(1, 0, out, inp, rows, ptr(dy), 4 * out, ptr(x), 4 * inp, ptr(dw), inp, None, 0,
+                             4, out, inp, out * inp, 0, 0, current_stream()), "capnet_sgemm")
+        return dx, dw, ops.colsum(dy)
 
 
 class StackedFactoredLSTM(nn.Module):
@@ -51,6 +172,7 @@ class StackedFactoredLSTM(nn.Module):
         self.vocab_size, self.num_layers = vocab_size, num_layers
         self.feature_size, self.max_seq_length = feature_size, max_seq_length
         self.dropout_p = dropout
+        self.fast_runs = True        # runs of teacher-forced steps through the persistent kernel (False: step by step)
         self.B = _Embedding(vocab_size, embed_size)
         for l in range(num_layers):
             tag = "" if l == 0 else str(l)
@@ -86,11 +208,21 @@ class StackedFactoredLSTM(nn.Module):
                 [getattr(self, "U%s_%s" % (tag, g)) for g in "ifoc"],
                 [getattr(self, "W%s_%s" % (tag, g)) for g in "ifoc"])
 
-    def _chain(self, l, mode, x):
-        """U_g(S_g(V_g(x))) for the four gates over all rows of x -> [rows, 4H] (gate order i,f,o,c)."""
+    def _chain(self, l, mode, x, cat=None):
+        """U_g(S_g(V_g(x))) for the four gates over all rows of x -> [rows, 4H] (gate order i,f,o,c). `cat`: the layer's
+        gate-stacked weights (_chain_cat, built once per forward): three products instead of twelve."""
+        if cat is not None:
+            Vw, Vb, Sw, Sb, Uw, Ub = cat
+            return GateLinearFn.apply(GateLinearFn.apply(ops.linear(x, Vw, Vb), Sw, Sb), Uw, Ub)
         V, S, U, _ = self._mods(l, mode)
         return torch.cat([ops.linear(ops.linear(ops.linear(x, V[k].weight, V[k].bias), S[k].weight, S[k].bias),
                                      U[k].weight, U[k].bias) for k in range(4)], 1)
+
+    def _chain_cat(self, l, mode):
+        V, S, U, _ = self._mods(l, mode)
+        return (torch.cat([m.weight for m in V], 0), torch.cat([m.bias for m in V], 0),
+                torch.stack([m.weight for m in S], 0), torch.cat([m.bias for m in S], 0),
+                torch.stack([m.weight for m in U], 0), torch.cat([m.bias for m in U], 0))
 
     def _wcat(self, l, mode):
         _, _, _, W = self._mods(l, mode)
@@ -119,6 +251,7 @@ class StackedFactoredLSTM(nn.Module):
         if features is not None:
             emb = torch.cat((features.unsqueeze(1), emb), 1)
         wcat = [self._wcat(l, mode) for l in range(L)]
+        ccat = [self._chain_cat(l, mode) if self.fast_runs else None for l in range(L)]
         h = [torch.zeros(Bn, H, device=captions.device) for _ in range(L)]
         c = [torch.zeros(Bn, H, device=captions.device) for _ in range(L)]
         top = []                                                          # top-layer hiddens, step by step
@@ -136,16 +269,21 @@ class StackedFactoredLSTM(nn.Module):
                     predicted = captions[:, 0]
                 x = Fn.embedding(predicted[:bs[t]], self.B.weight)        # no dropout on the feedback (model.py:184)
             for l in range(L):
-                pre = self._chain(l, mode, x)
+                pre = self._chain(l, mode, x, ccat[l])
                 Wc, bc = wcat[l]
-                outs, off = [], 0
-                for u in range(t, t1):
-                    b = bs[u]
-                    g = pre[off:off + b] + ops.linear(h[l][:b], Wc, bc)
-                    h[l], c[l] = ops.lstm_cell(g, c[l][:b], 0)
-                    outs.append(h[l])
-                    off += b
-                x = torch.cat(outs, 0) if len(outs) > 1 else outs[0]
+                if self.fast_runs and lstm_run_supported(bs[t], H, t1 - t):
+                    # the run's recurrence in ONE launch of the persistent kernel (and one backward function)
+                    x, c[l] = lstm_run(pre + bc, Wc, h[l][:bs[t]], c[l][:bs[t]], bs[t:t1], 0)
+                    h[l] = x[x.shape[0] - bs[t1 - 1]:]
+                else:
+                    outs, off = [], 0
+                    for u in range(t, t1):
+                        b = bs[u]
+                        g = pre[off:off + b] + ops.linear(h[l][:b], Wc, bc)
+                        h[l], c[l] = ops.lstm_cell(g, c[l][:b], 0)
+                        outs.append(h[l])
+                        off += b
+                    x = torch.cat(outs, 0) if len(outs) > 1 else outs[0]
                 if l + 1 < L and self.training and self.dropout_p > 0:
                     x = Fn.dropout(x, self.dropout_p, True)
             top.append(x)

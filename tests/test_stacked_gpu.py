@@ -83,6 +83,42 @@ def test_one_layer_is_the_reference_decoder(dev):
     assert rel_err(dec.B.weight.grad, ref.B.weight.grad) < 1e-4
 
 
+def test_runs_through_the_persistent_kernel_equal_the_step_by_step_engine(dev):
+    """Three layers at the size the persistent kernel takes (H = 512): logits, loss and every gradient of the engine
+    that runs each teacher-forced run of a layer in one launch (capnet.stacked.LstmRunFn: forward on
+    csrc/lstm_persist.hip, its own backward through time) against the step-by-step engine (W GEMM + cell kernel per step,
+    autograd composing the backward), same weights, same scheduled-sampling decisions, shrinking batches."""
+    E, H, F, V, B, layers = 300, 512, 256, 500, 9, 3
+    a = StackedFactoredLSTM(E, H, F, V, layers, dropout=0.0)
+    p = synthetic.decoder_state(a.state_dict(), seed=21)
+    a.load_state_dict(p)
+    b = StackedFactoredLSTM(E, H, F, V, layers, dropout=0.0)
+    b.load_state_dict(p)
+    b.fast_runs = False
+    a.to(dev).train()
+    b.to(dev).train()
+    _, caps, lens = synthetic.make_batch(B, V, seed=4)
+    feats = torch.randn(B, E, generator=torch.Generator().manual_seed(3)).to(dev)
+    random.seed(8)
+    tf = [random.random() < 0.75 for _ in range(max(lens))]
+    assert not all(tf) and sum(tf) >= 4
+    oa = a(caps.to(dev), lens, feats, mode="happy", tf_mask=tf)
+    ob = b(caps.to(dev), lens, feats, mode="happy", tf_mask=tf)
+    assert rel_err(oa, ob) < 1e-5
+    la = ops.cross_entropy(oa, ops.packed_targets(caps.to(dev), lens)); la.backward()
+    lb = ops.cross_entropy(ob, ops.packed_targets(caps.to(dev), lens)); lb.backward()
+    ops.check_device_errors()
+    assert abs(la.item() - lb.item()) / lb.item() < 1e-6
+    n = 0
+    for (k, pa), pb in zip(a.named_parameters(), b.parameters()):
+        if pb.grad is None:
+            assert pa.grad is None, k
+            continue
+        assert rel_err(pa.grad, pb.grad) < 1e-4, k
+        n += 1
+    assert n >= 1 + layers * 16 + 2
+
+
 def test_stacked_train_step_runs_and_learns(dev):
     """configs[4]'s decoder shape (3 layers, factored 1024) through capnet.train.train_step with capnet.optim.Adam."""
     from capnet.optim import Adam
