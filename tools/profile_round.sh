@@ -14,6 +14,8 @@ timeout -k 10 300 python bench.py --decoder att --no-cpu-baseline 2> $OUT/bench_
 # SURVEY 8(d) Config 4: the attention decoder at 12 images per GPU (global 96 on 8 GPUs) and at 96 per GPU
 timeout -k 10 300 python bench.py --decoder att --batch 12 --no-cpu-baseline --no-lstm-roofline 2> $OUT/bench_att_b12.log | tail -1 > $OUT/bench_att_b12.json || exit 1
 timeout -k 10 300 python bench.py --decoder att --batch 96 --steps 40 --no-cpu-baseline --no-lstm-roofline 2> $OUT/bench_att_b96.log | tail -1 > $OUT/bench_att_b96.json || exit 1
+# configs[4]'s decoder shape on capnet.stacked (perf-only, parity unpinned)
+timeout -k 10 300 python bench.py --layers 3 --factored 1024 --batch 96 --steps 60 --no-cpu-baseline --no-lstm-roofline 2> $OUT/bench_stacked3.log | tail -1 > $OUT/bench_stacked3.json || exit 1
 timeout -k 10 300 python bench.py --decoder nic --no-cpu-baseline 2> $OUT/bench_nic.log | tail -1 > $OUT/bench_nic.json || exit 1
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- \
