@@ -97,6 +97,51 @@ def test_persistent_sequence_matches_float64(dev, name, cell):
     _close(gates, rg, 2e-6)
 
 
+def _reference32(W, pre, bs, cell):
+    """the same loop in float32 (torch CPU): how far plain fp32 arithmetic sits from float64 on the same case"""
+    off = [0]
+    for b in bs:
+        off.append(off[-1] + b)
+    hs, cs = [], []
+    h = torch.zeros(bs[0], H)
+    c = torch.zeros(bs[0], H)
+    for t, b in enumerate(bs):
+        g = pre[off[t]:off[t + 1]] + (h[:b] @ W.t() if t > 0 else 0)
+        if cell == 0:
+            i, f, o, gg = [g[:, k * H:(k + 1) * H] for k in range(4)]
+        else:
+            i, f, gg, o = [g[:, k * H:(k + 1) * H] for k in range(4)]
+        i, f, o, gg = torch.sigmoid(i), torch.sigmoid(f), torch.sigmoid(o), torch.tanh(gg)
+        c = f * c[:b] + i * gg
+        h = o * c if cell == 0 else o * torch.tanh(c)
+        hs.append(h)
+        cs.append(c)
+    return torch.cat(hs), torch.cat(cs)
+
+
+@pytest.mark.parametrize("wscale", [2.0 ** -16, 2.0 ** -6, 30.0, 400.0])
+def test_split_f16_weights_cover_small_and_large_magnitudes(dev, wscale):
+    """The recurrent weights enter the MFMAs as two f16 pieces scaled by 2^10 (csrc/lstm_persist.hip): weights of
+    1e-6 (their residuals still normal f16 numbers), ordinary ones and |w| up to 24 -- the documented domain is |w| < 32,
+    far beyond anything a clamped Adam leaves in W_hh. Against float64 the kernel may not sit further away than plain
+    fp32 arithmetic does on the same case (with large weights the pre-activations are sums of thousands and no fp32
+    method holds 2e-6 of them); h = o c grows with the weights, which exercises the f16 range of h as well."""
+    if not capnet.lib().capnet_lstm_persist_supported(64, H):
+        pytest.skip("persistent kernel not supported on this device")
+    bs = [64, 64, 60, 40, 33, 8]
+    W, pre = _case(5, bs)
+    W = W * wscale                       # max |w| = 0.06 * wscale
+    hid, cst, gates = _run(dev, W, pre, bs, 0, [(0, len(bs))])
+    rh, rc, rg = _reference(W, pre, bs, 0)
+    fh, fc = _reference32(W, pre, bs, 0)
+    assert torch.isfinite(hid).all() and torch.isfinite(cst).all()
+    for got, f32, ref in ((hid, fh, rh), (cst, fc, rc)):
+        e_k = ((got.double() - ref).abs().max() / ref.abs().max()).item()
+        e_f = ((f32.double() - ref).abs().max() / ref.abs().max()).item()
+        print("max |w| %.3g: kernel %.2e, fp32 loop %.2e of the largest value" % (0.06 * wscale, e_k, e_f))
+        assert e_k < max(2e-6, 3 * e_f)
+
+
 def test_segments_restart_from_global_state(dev):
     """A forward pass with free-running steps cuts the recurrence into several launches: each one
     picks h and c of the previous step up from the output buffers (same control block, segment
