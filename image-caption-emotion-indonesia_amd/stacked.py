@@ -242,8 +242,9 @@ class StackedFactoredLSTM(nn.Module):
         steps = len(bs)
         if tf_mask is None:
             tf_mask = [random.random() < teacher_forcing_ratio for _ in range(steps)]
-        if len(tf_mask) != steps:
-            raise CapnetError("tf_mask must have one entry per time step")
+        if len(tf_mask) < steps:
+            raise CapnetError("tf_mask has %d entries, %d steps needed" % (len(tf_mask), steps))
+        tf_mask = [bool(v) for v in tf_mask[:steps]]         # (longer masks are cut, as the other decoders do)
         Bn = captions.size(0)
         emb = Fn.embedding(captions, self.B.weight)                       # B(captions)
         if self.training and self.dropout_p > 0:

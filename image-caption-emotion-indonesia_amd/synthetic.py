@@ -24,6 +24,11 @@ def make_batch(batch, vocab_size, seed=0, image_size=224, min_len=8, max_len=24,
         mean = torch.tensor(IMAGENET_MEAN).view(1, 3, 1, 1)
         std = torch.tensor(IMAGENET_STD).view(1, 3, 1, 1)
         imgs = (imgs - mean) / std
+    else:
+        # the same draws, discarded: captions and lengths of a seed must not depend on whether the images were asked for
+        # (bench.py rebuilds every rank's lengths with images=False)
+        for _ in range(batch):
+            torch.rand(3, image_size, image_size, generator=g)
     lengths = torch.randint(min_len, max_len + 1, (batch,), generator=g)
     lengths = sorted(lengths.tolist(), reverse=True)
     T = lengths[0]

@@ -43,6 +43,15 @@ def test_bench_prints_one_json_line():
     assert d["roofline_lstm_step"]["bound"] == "hbm"
 
 
+@pytest.mark.parametrize("extra", [["--decoder", "att", "--batch", "12"], ["--decoder", "nic"],
+                                   ["--layers", "3", "--factored", "1024", "--batch", "16"]])
+def test_secondary_workloads_run(extra):
+    """The secondary bench lines of profiles/ (attention decoder at 12 per GPU: the one-launch step products; NIC;
+    configs[4]'s stacked decoder shape) start, train and print the contract's line."""
+    d = _run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-lstm-roofline"] + extra, {})
+    assert d["value"] > 0 and math.isfinite(d["loss_first"]) and math.isfinite(d["loss_last"])
+
+
 def test_two_rank_rehearsal_on_one_gpu():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", "29541", "bench.py", "--gpus", "2", "--steps", "2",
