@@ -175,36 +175,58 @@ def gen_nic_tiny():
     save("decoder_nic_tiny.npz", arrays)
 
 
+def input_digest(*tensors):
+    """crc32 over the raw bytes of the given tensors / lists: stored in every fixture whose inputs are NOT in the file
+    but re-drawn by capnet.synthetic on both sides, and asserted on CPU (tests/test_fixture_inputs_cpu.py) -- a change
+    of synthetic.py's draw order then fails in the GPU-less container, not in the driver's GPU run."""
+    import zlib
+    c = 0
+    for x in tensors:
+        a = np.ascontiguousarray(x.numpy() if torch.is_tensor(x) else np.asarray(x))
+        c = zlib.crc32(a.tobytes(), c)
+    return c
+
+
 def gen_factored_full():
-    """Config 2 decoder at full size (E=300, F=H=512, V=8192, B=64): scalars only."""
+    """Config 2 decoder at full size (E=300, F=H=512, V=8192, B=64): scalars only -- per step the loss, a logits
+    checksum and EVERY parameter's gradient norm (a 1e-4 bound on a first loss near ln V cannot tell inputs apart,
+    VERDICT r3 weak #3), plus digests of the inputs both sides re-draw from capnet.synthetic."""
     ref = load_ref("stylenet", "model")
     utils = load_ref("stylenet", "utils")
     E, H, F, V, B = 300, 512, 512, 8192, 64
     dec = ref.DecoderFactoredLSTM(E, H, F, V, 1, dropout=0.0)
     dec.train()
-    dec.load_state_dict(synthetic.decoder_state(dec.state_dict(), seed=1234))
+    state = synthetic.decoder_state(dec.state_dict(), seed=1234)
+    dec.load_state_dict(state)
     _, captions, lengths = synthetic.make_batch(B, V, seed=0, images=False)
     g = torch.Generator().manual_seed(77)
     features = torch.randn(B, E, generator=g)
     opt = torch.optim.Adam(dec.parameters(), lr=2e-4, betas=(0.9, 0.999), eps=1e-8)
-    losses, gnorms = [], {}
+    names = [k for k, _ in dec.named_parameters()]
+    losses, gnorms, lsum, labs, tfm = [], [], [], [], []
     random.seed(0)
     for it in range(4):
+        st = random.getstate()
+        tfm.append([random.random() < 0.8 for _ in range(lengths[0])])
+        random.setstate(st)
         outputs = dec(captions, lengths, features, teacher_forcing_ratio=0.8, mode="factual")
         targets = pack_padded_sequence(captions, lengths, batch_first=True)[0]
         loss = nn.CrossEntropyLoss()(outputs, targets)
         dec.zero_grad()
         loss.backward()
-        if it == 0:
-            for k, p in dec.named_parameters():
-                if p.grad is not None:
-                    gnorms[k] = float(p.grad.norm())
+        gnorms.append([float(p.grad.double().norm()) if p.grad is not None else 0.0 for _, p in dec.named_parameters()])
+        lsum.append(float(outputs.double().sum()))
+        labs.append(float(outputs.double().abs().sum()))
         utils.clip_gradient(opt, 0.5)
         opt.step()
         losses.append(float(loss))
-        print("full step", it, float(loss))
+        print("full step", it, float(loss), "logits sum", lsum[-1], "abs", labs[-1])
     arrays = {"losses": np.array(losses), "dims": np.array([E, H, F, V, B]),
-              "grad_names": np.array(list(gnorms.keys())), "grad_norms": np.array(list(gnorms.values()))}
+              "grad_names": np.array(names), "grad_norms": np.array(gnorms),
+              "logits_sum": np.array(lsum), "logits_abs_sum": np.array(labs), "tf_masks": np.array(tfm),
+              "digest_batch": np.array(input_digest(captions, lengths), dtype=np.int64),
+              "digest_features": np.array(input_digest(features), dtype=np.int64),
+              "digest_params": np.array(input_digest(*[state[k] for k in sorted(state)]), dtype=np.int64)}
     save("decoder_factored_full_scalars.npz", arrays)
 
 
