@@ -104,7 +104,7 @@ def host_cores():
     return max(1, min(n, 16))
 
 
-def cpu_baseline(args, steps, warmup=2):
+def cpu_baseline(args, steps, warmup=2, parity=None):
     """The CPU oracle (oracle/: torch-CPU restatement of the reference step) timed on this host's
     cores, same workload as the GPU line: batch 64, ResNet-152 train-mode trunk + head +
     FactoredLSTM-512, V=8192, tf 0.8, dropout as on the GPU (a host-drawn mask). SURVEY 8(d) /
@@ -161,12 +161,90 @@ def cpu_baseline(args, steps, warmup=2):
         losses.append(float(loss))
     med = lambda v: sorted(v)[len(v) // 2]
     t, tt = med(t_all), med(t_trunk)
+    if parity is not None:
+        parity.update(oracle_parity_losses(parity, S, D, EncoderCNNRef, Fn))
     return {"value": round(B / t, 3), "unit": "images/sec", "cores": cores, "kind": "port",
             "sample": "%d full train steps at batch %d after %d warm-up steps (median %.2f s/step: trunk "
                       "%.2f s + head/decoder/loss/backward/clamp/Adam %.2f s), oracle/ torch-CPU fp32, "
                       "dropout %.2f" % (steps, B, warmup, t, tt, t - tt, args.dropout),
             "trunk_s": round(tt, 3), "decoder_s": round(t - tt, 3), "step_s": round(t, 3),
             "loss_first": losses[0]}
+
+
+PARITY_STEPS, PARITY_LR, PARITY_TF_SEED = 2, 2e-3, 3
+
+
+def parity_inputs(B, V):
+    """Inputs of the untimed loss-parity leg: BASELINE configs[1] (batch 64, V 8192), seeded weights on both sides
+    (capnet.synthetic), dropout 0 (the GPU's dropout stream is its own), one fixed teacher-forcing mask per step."""
+    from capnet import synthetic
+    imgs, captions, lengths = synthetic.make_batch(B, V, seed=0)
+    random.seed(PARITY_TF_SEED)
+    tfs = [[random.random() < 0.8 for _ in range(max(lengths))] for _ in range(PARITY_STEPS)]
+    return imgs, captions, lengths, tfs
+
+
+def gpu_parity_losses(dev, B, V):
+    """The PRODUCT side of `loss_parity`: PARITY_STEPS whole train steps (stylenet/train_multitask.py:373-389: trunk,
+    head, decoder, NLL, backward, clamp, Adam) through capnet's sequential loop entry on fresh modules."""
+    from capnet import ops, synthetic
+    from capnet.model import DecoderFactoredLSTM, EncoderCNN
+    from capnet.optim import Adam
+    from capnet.train import CrossEntropyLoss, train_step
+    enc = EncoderCNN(300)
+    est = synthetic.encoder_state(enc.state_dict(), seed=1234)
+    enc.load_state_dict(est)
+    dec = DecoderFactoredLSTM(300, 512, 512, V, 1, dropout=0.0)
+    p = synthetic.decoder_state(dec.state_dict(), seed=1234)
+    dec.load_state_dict(p)
+    enc.to(dev).train()
+    dec.to(dev).train()
+    imgs, captions, lengths, tfs = parity_inputs(B, V)
+    opt = Adam(list(dec.parameters()) + list(enc.linear.parameters()) + list(enc.bn.parameters()), lr=PARITY_LR)
+    imgs_d, caps_d = imgs.to(dev), captions.to(dev)
+    got = [float(train_step(enc, dec, opt, CrossEntropyLoss(), imgs_d, caps_d, lengths, 0.5, tf_mask=tfs[it]).item())
+           for it in range(PARITY_STEPS)]
+    ops.check_device_errors()
+    return {"B": B, "V": V, "gpu": got, "est": est, "p": p}
+
+
+def oracle_parity_losses(parity, S, D, EncoderCNNRef, Fn):
+    """The CHECKER side of `loss_parity`, run inside the cpu_baseline leg (the only place bench.py touches oracle/):
+    the same steps through the CPU restatement, fp32."""
+    B, V = parity["B"], parity["V"]
+    imgs, captions, lengths, tfs = parity_inputs(B, V)
+    ref_enc = EncoderCNNRef(300)
+    ref_enc.load_state_dict({k: v.clone() for k, v in parity.pop("est").items()})
+    ref_enc.train()
+    p_ref = {k: v.clone() for k, v in parity.pop("p").items()}
+    opt_ref = S.AdamRef(lr=PARITY_LR)
+    out = []
+    for it in range(PARITY_STEPS):
+        leaves = {k: v.detach().clone().requires_grad_(True) for k, v in p_ref.items()}
+        feats = ref_enc(imgs)
+        logits = D.factored_lstm_forward(leaves, captions, lengths, feats, tfs[it], "factual")
+        loss = Fn.cross_entropy(logits, D.packed_targets(captions, lengths))
+        ref_enc.zero_grad()
+        loss.backward()
+        grads = {k: v.grad for k, v in leaves.items()}
+        S.clip_gradient_(grads.values(), 0.5)
+        with torch.no_grad():
+            hp = {("enc." + k): v for k, v in ref_enc.named_parameters() if not k.startswith("resnet.")}
+            hg = {k: v.grad for k, v in hp.items()}
+            S.clip_gradient_([g_ for g_ in hg.values() if g_ is not None], 0.5)
+            both, both_g = dict(p_ref), dict(grads)
+            both.update(hp)
+            both_g.update(hg)
+            opt_ref.step(both, both_g)
+        out.append(float(loss.detach()))
+        log("loss parity step %d: oracle %.6f, gpu %.6f" % (it, out[-1], parity["gpu"][it]))
+    rel = [abs(a - b) / abs(b) for a, b in zip(parity["gpu"], out)]
+    return {"oracle": out, "rel": [float("%.3e" % r) for r in rel], "rel_max": float("%.3e" % max(rel)),
+            "steps": PARITY_STEPS, "tolerance": 1e-4,
+            "what": "whole train step (ResNet-152 train-mode trunk + head + FactoredLSTM-512 + NLL + backward + clamp 0.5 "
+                    "+ Adam %g), batch %d, V %d, dropout 0, tf 0.8 with a fixed mask per step (random.seed(%d)), seeded "
+                    "weights on both sides; gpu = capnet.train.train_step through libcapnet_hip.so, oracle = oracle/ "
+                    "torch-CPU fp32; untimed" % (PARITY_LR, B, V, PARITY_TF_SEED)}
 
 
 def self_launch(args):
@@ -581,6 +659,7 @@ def main():
                                "bytes_per_step": by, "us_per_step": round(us_a, 1)},
         }
 
+    parity_failed = False
     if rank == 0:
         total_images = B * world * args.steps
         out = {
@@ -617,14 +696,23 @@ def main():
                 "secondary (PERF-ONLY, PARITY UNPINNED: the reference ignores num_layers, capnet.stacked defines the "
                 "stacking): FactoredLSTM (factored %d, hidden 512, %d layers," % (args.factored, args.layers))
         if world == 1 and not args.no_cpu_baseline and args.decoder == "factored" and args.layers == 1 and args.factored == 512:
-            out["cpu_baseline"] = cpu_baseline(args, args.cpu_steps)
+            # `metric` says "+ NLL loss match": the evidence is in the line itself. Untimed.
+            parity = gpu_parity_losses(dev, B, V)
+            out["cpu_baseline"] = cpu_baseline(args, args.cpu_steps, parity=parity)
+            out["loss_parity"] = parity
+            if parity["rel_max"] > parity["tolerance"]:
+                log("LOSS PARITY FAILED: %s" % parity)
+                parity_failed = True
         else:
             out["cpu_baseline"] = None
+            out["loss_parity"] = None
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     os.close(json_fd)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+    if parity_failed:
+        raise SystemExit("loss parity beyond 1e-4 (the JSON line was still printed)")
 
 
 if __name__ == "__main__":

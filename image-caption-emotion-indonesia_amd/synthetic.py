@@ -106,3 +106,17 @@ def trunk_state(state_dict_like, seed=1234):
         else:
             out[name] = torch.zeros_like(t)
     return out
+
+
+def encoder_state(state_dict_like, seed=1234):
+    """Deterministic EncoderCNN state (stylenet/model.py:11-27): trunk_state for `resnet.*`, a xavier Linear with small
+    biases and a BatchNorm1d with non-trivial weight / bias, fresh running statistics."""
+    sd = state_dict_like
+    new = trunk_state({k: v for k, v in sd.items() if k.startswith("resnet.")}, seed=seed)
+    new["linear.weight"] = param_tensor("linear.weight", sd["linear.weight"].shape, seed, "xavier")
+    new["linear.bias"] = param_tensor("linear.bias", sd["linear.bias"].shape, seed, "bias", 0.05)
+    new["bn.weight"] = param_tensor("bn.weight", sd["bn.weight"].shape, seed, "bias", 0.5) + 1.0
+    new["bn.bias"] = param_tensor("bn.bias", sd["bn.bias"].shape, seed, "bias", 0.2)
+    for k in ("bn.running_mean", "bn.running_var", "bn.num_batches_tracked"):
+        new[k] = sd[k].clone()
+    return new
