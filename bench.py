@@ -247,6 +247,25 @@ def oracle_parity_losses(parity, S, D, EncoderCNNRef, Fn):
                     "torch-CPU fp32; untimed" % (PARITY_LR, B, V, PARITY_TF_SEED)}
 
 
+def rank_shard(B, V, rank, world, images=True):
+    """(images, captions, lengths, loss_scale, global_steps) of `rank`'s shard of the weak-scaling job: B seeded
+    (image, caption) pairs per rank. Every rank can rebuild every rank's lengths (seeded), so the token weights and the
+    global number of decoder steps need no communication. loss_scale = N_rank / N_global: with a SUM all-reduce of the
+    gradients that is the gradient of the global token-mean loss; global_steps = the longest caption of the
+    job, so that every rank consumes the same teacher-forcing draws.
+    tests/test_bench_gpu.py::test_two_rank_gradient_is_the_token_weighted_mean holds this very function, with
+    capnet.parallel.DataParallelAdam behind it, to the per-shard oracle gradients."""
+    from capnet import synthetic
+    all_lengths = [synthetic.make_batch(B, V, seed=r, images=False)[2] for r in range(world)]
+    n_global = sum(sum(l) for l in all_lengths)
+    global_steps = max(l[0] for l in all_lengths)
+    imgs, captions, lengths = synthetic.make_batch(B, V, seed=rank, images=images)
+    if lengths != all_lengths[rank]:
+        raise RuntimeError("synthetic.make_batch: lengths of a seed depend on the images flag")
+    loss_scale = float(sum(lengths)) / n_global if world > 1 else None
+    return imgs, captions, lengths, loss_scale, global_steps
+
+
 def self_launch(args):
     """`python3 bench.py --gpus N` without a launcher: start N rank processes of this script (one
     per GPU, env-style rendezvous on 127.0.0.1) BEFORE anything in this process touches the GPU,
@@ -343,15 +362,8 @@ def main():
         optimizer.attach(encoder)
     criterion = CrossEntropyLoss()
 
-    # every rank can rebuild every rank's lengths (seeded), so token weights and the global
-    # number of steps need no communication
-    all_lengths = [synthetic.make_batch(B, V, seed=r, images=False)[2] for r in range(world)]
-    n_global = sum(sum(l) for l in all_lengths)
-    global_steps = max(l[0] for l in all_lengths)
-    images, captions, lengths = synthetic.make_batch(B, V, seed=rank)
+    images, captions, lengths, loss_scale, global_steps = rank_shard(B, V, rank, world)
     images, captions = images.to(dev), captions.to(dev)
-    # SUM all-reduce of grads scaled by N_rank/N_global == gradient of the global token-mean loss
-    loss_scale = float(sum(lengths)) / n_global if world > 1 else None
     random.seed(0)
 
     pipe = None

@@ -532,6 +532,14 @@ int capnet_pack_tensors(int n, float* const* tensors, const long* numel, float* 
   return pack_tensors(n, tensors, numel, flat, direction, scale, S(stream));
 }
 
+int capnet_err_word_exchange(int* err_flag, float* slot, int direction, capnet_stream_t stream) {
+  return err_word_exchange(err_flag, slot, direction, S(stream));
+}
+
+int capnet_count_skipped(const int* err_flag, int* counter, capnet_stream_t stream) {
+  return count_skipped(err_flag, counter, S(stream));
+}
+
 int capnet_clamp(float* x, long n, float lo, float hi, capnet_stream_t stream) {
   return clamp_inplace(x, n, lo, hi, S(stream));
 }

@@ -250,6 +250,36 @@ int pack_tensors(int n_tensors, float* const* tensors, const long* numel, float*
   return kOk;
 }
 
+// ---- the device error word across ranks and across dropped steps ------------------------------------
+// clamp_adam skips its update while the LOCAL error word is set; with several ranks that decision has to be the same
+// everywhere or the replicas' parameters drift apart. The word rides in one extra float behind the flat gradient buffer
+// that is all-reduced anyway: dir 0 writes (word != 0) into the slot, dir 1 (after the SUM) raises bit 4 (16, "another
+// rank dropped this step") locally when any rank had a fault.
+__global__ void err_word_exchange_kernel(int* __restrict__ err_flag, float* __restrict__ slot, int dir) {
+  if (dir == 0) *slot = (*err_flag != 0) ? 1.f : 0.f;
+  else if (*slot > 0.f && *err_flag == 0) *err_flag = 16;
+}
+
+int err_word_exchange(int* err_flag, float* slot, int dir, hipStream_t stream) {
+  CAPNET_REQUIRE(err_flag && slot && (dir == 0 || dir == 1), "err_word_exchange: bad argument");
+  hipLaunchKernelGGL(err_word_exchange_kernel, dim3(1), dim3(1), 0, stream, err_flag, slot, dir);
+  CAPNET_LAUNCH_CHECK();
+  return kOk;
+}
+
+// counter += 1 while the error word is set: launched once per optimizer step in front of its clamp_adam launches, so that
+// the host can take the dropped steps out of its per-parameter step counts (Adam's bias correction) when it learns of them.
+__global__ void count_skipped_kernel(const int* __restrict__ err_flag, int* __restrict__ counter) {
+  if (*err_flag != 0) *counter += 1;
+}
+
+int count_skipped(const int* err_flag, int* counter, hipStream_t stream) {
+  CAPNET_REQUIRE(err_flag && counter, "count_skipped: bad argument");
+  hipLaunchKernelGGL(count_skipped_kernel, dim3(1), dim3(1), 0, stream, err_flag, counter);
+  CAPNET_LAUNCH_CHECK();
+  return kOk;
+}
+
 // ---- top-k accuracy: utils.accuracy (stylenet/utils.py:127-140) --------------------------------
 // count += #rows whose target is among the k largest logits. Rank of the target = number of
 // entries that beat it (strictly larger, or equal with a lower index: the order torch.topk

@@ -140,6 +140,12 @@ class _TrunkRunner:
         self.timing = False
         self.packed = None
         self.packed_key = None
+        self._exp_epoch = 0
+
+    def invalidate_exponents(self):
+        """Forget the cached per-layer prescale exponents (see _input_exponents): call after writing BatchNorm
+        parameters of the trunk through anything that does not bump torch's version counters."""
+        self._exp_epoch += 1
 
     def _plan(self, b, h, w, dev):
         key = (b, h, w, str(dev))
@@ -215,8 +221,12 @@ class _TrunkRunner:
         error word (bit 3: the launches without statistics look at their own outputs) to say so if an activation
         exceeds it. Images are taken as they come (exponent 0): normalised pixels.
         -> (train exponents, inference exponents) as ctypes int arrays."""
-        key = (b, h, w) + tuple((bn.weight._version, bn.bias._version, bn.weight.data_ptr())
-                                for bn in (self.bns[0], self.bns[len(self.bns) // 2], self.bns[-1]))
+        # every BatchNorm's version and storage (ADVICE r3: three of 155 missed partial loads). Kernels that write
+        # parameters through raw pointers (capnet.optim.Adam on a trunk someone fine-tunes) do not bump `_version`:
+        # such a caller invalidates by hand, `runner.invalidate_exponents()`; the reference workflow keeps the trunk
+        # under no_grad and only load_state_dict() touches these tensors.
+        key = (b, h, w, self._exp_epoch) + tuple(x for bn in self.bns for x in
+                                                 (bn.weight._version, bn.bias._version, bn.weight.data_ptr()))
         hit = plan.get("exps")
         if hit is not None and hit[0] == key:
             return hit[1], hit[3]

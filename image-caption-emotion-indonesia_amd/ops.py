@@ -6,6 +6,9 @@ this file computes on the CPU or through a torch operator. Inputs must be CUDA f
 """
 import ctypes as C
 
+import sys
+import weakref
+
 import torch
 from torch.autograd.function import once_differentiable
 
@@ -48,22 +51,60 @@ _ERR_BITS = {1: "token id out of range", 2: "target out of range",
                 "allows for the split-f16 operands -- possible only in inference, with running statistics far from the data "
                 "-- or a genuine fp32 overflow)",
              4: "a bounded wait of the persistent LSTM kernel expired (its 256 workgroups were not co-resident in time); "
-                "the process now runs one launch per LSTM step, as CAPNET_NO_PERSISTENT_LSTM=1 does from the start"}
+                "the process now runs one launch per LSTM step, as CAPNET_NO_PERSISTENT_LSTM=1 does from the start",
+             16: "another rank of the data-parallel job raised its error word: this rank dropped the same steps so that "
+                 "the replicas stay identical (capnet.parallel)",
+             32: "a recurrent LSTM weight beyond the persistent kernel's split-f16 domain (|w| >= 32): its hiddens are "
+                 "not finite; run with CAPNET_NO_PERSISTENT_LSTM=1 for such weights"}
+
+_optimizers = weakref.WeakSet()      # capnet.optim.Adam instances: they hold the per-optimizer dropped-step counters
 
 
-def check_device_errors():
+def register_optimizer(opt):
+    _optimizers.add(opt)
+
+
+def skip_counter(device):
+    return torch.zeros(1, dtype=torch.int32, device=device)
+
+
+def count_skipped(counter):
+    """counter += 1 on the device while the error word is set (one launch per optimizer step)."""
+    check(_lib.lib().capnet_count_skipped(ptr(err_flag(counter.device)), ptr(counter), current_stream()),
+          "capnet_count_skipped")
+
+
+def err_word_exchange(slot, direction):
+    check(_lib.lib().capnet_err_word_exchange(ptr(err_flag(slot.device)), ptr(slot), int(direction), current_stream()),
+          "capnet_err_word_exchange")
+
+
+def check_device_errors(recover_lstm_timeout=False):
     """Synchronising check of the device-side error flags (call where the loop already syncs).
 
     While a flag is set capnet.optim.Adam's update kernel leaves parameters and moments alone (capnet_clamp_adam's
-    skip_flag), so the steps between the fault and this check were DROPPED, not applied with garbage gradients."""
+    skip_flag), so the steps between the fault and this check were DROPPED, not applied with garbage gradients; every
+    registered optimizer takes the dropped steps out of its host-side step counts here (bias correction stays in step
+    with the moments on the device), whether or not the error is then raised.
+    recover_lstm_timeout: an expired wait of the persistent LSTM kernel ALONE (bit 4: a transient loss of co-residency
+    beside the trunk passes) is logged instead of raised -- the process continues on the launch-per-step kernel, as the
+    training loops do (capnet.train.train_factual / train_emotion)."""
     for f in _err_flags.values():
         v = int(f.item())
-        if v:
-            f.zero_()
-            if v & 4:
-                _lib.lib().capnet_lstm_persist_set_mode(1)
-            raise CapnetError("device-side error flag %d: %s. The optimizer steps since the previous check were skipped."
-                              % (v, "; ".join(m for b, m in _ERR_BITS.items() if v & b) or "?"))
+        if not v:
+            continue
+        f.zero_()
+        dropped = [o.forget_dropped_steps() for o in list(_optimizers)]
+        if v & 4:
+            _lib.lib().capnet_lstm_persist_set_mode(1)
+        msg = ("device-side error flag %d: %s. %s optimizer steps since the previous check were skipped."
+               % (v, "; ".join(m for b, m in _ERR_BITS.items() if v & b) or "?", sum(dropped) if dropped else "The"))
+        if recover_lstm_timeout and v == 4:
+            sys.stderr.write("[capnet] " + msg + " Continuing.\n")
+            continue
+        raise CapnetError(msg)
+    for o in list(_optimizers):
+        o.forget_dropped_steps(none_dropped=True)
 
 
 # ---------------------------------------------------------------------------------------

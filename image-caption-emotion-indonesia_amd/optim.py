@@ -36,6 +36,9 @@ class Adam:
             self.param_groups.append(g)
         self.state = {}
         self._pending_clip = None
+        self._skipped = None           # device counter of steps the update kernel dropped (error word set)
+        self._history = []             # per step() since the last error check: the parameters it stepped
+        ops.register_optimizer(self)
         self.grad_sync = None  # optional callable(list_of_params) run before the update (data parallel)
 
     def zero_grad(self, set_to_none=True):
@@ -91,6 +94,21 @@ class Adam:
                 "exp_avg": st["exp_avg"].to(device=p.device, dtype=p.dtype).clone(),
                 "exp_avg_sq": st["exp_avg_sq"].to(device=p.device, dtype=p.dtype).clone()}
 
+    def forget_dropped_steps(self, none_dropped=False):
+        """Called by ops.check_device_errors() (which has just synchronised). The update kernel drops a step while the
+        device's error word is set; the host had already counted it. Take the dropped steps -- the device counter says
+        how many, and they are the LAST ones, the word stays set until the check -- out of the per-parameter step
+        counts, so that Adam's bias correction matches the moments on the device. Returns their number."""
+        n = 0
+        if not none_dropped and self._skipped is not None:
+            n = int(self._skipped.item())
+            self._skipped.zero_()
+            for stepped in self._history[len(self._history) - n:] if n else []:
+                for p in stepped:
+                    self.state[p]["step"] -= 1
+        self._history = []
+        return n
+
     def set_pending_clip(self, grad_clip):
         """Called by utils.clip_gradient: the clamp is applied inside the next step()'s kernel
         (and written back to .grad, so the visible effect equals clamp_ followed by step)."""
@@ -102,6 +120,10 @@ class Adam:
         self._pending_clip = None
         if self.grad_sync is not None:
             self.grad_sync([p for g in self.param_groups for p in g["params"] if p.grad is not None])
+        stepped = []
+        if len(self._history) < 4096:      # loops check the error word every log_step steps; unbounded without checks
+            self._history.append(stepped)
+        counted = False
         for g in self.param_groups:
             ps, gs, ms, vs, steps = [], [], [], [], []
             for p in g["params"]:
@@ -114,6 +136,12 @@ class Adam:
                     st = {"step": 0, "exp_avg": torch.zeros_like(p), "exp_avg_sq": torch.zeros_like(p)}
                     self.state[p] = st
                 st["step"] += 1
+                stepped.append(p)
+                if not counted:
+                    if self._skipped is None or self._skipped.device != p.device:
+                        self._skipped = ops.skip_counter(p.device)
+                    ops.count_skipped(self._skipped)
+                    counted = True
                 if not p.grad.is_contiguous():
                     p.grad = p.grad.contiguous()
                 ps.append(p.data)

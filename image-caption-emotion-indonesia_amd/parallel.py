@@ -52,12 +52,21 @@ class GradAllReducer:
         n = sum(g.numel() for g in grads)
         if n == 0:
             return
-        if self.flat is None or self.flat.numel() < n or self.flat.device != grads[0].device:
-            self.flat = torch.empty(n, dtype=torch.float32, device=grads[0].device)
-        flat = self.flat[:n]
-        self.pack_fn(grads, flat)
+        if self.flat is None or self.flat.numel() < n + 1 or self.flat.device != grads[0].device:
+            self.flat = torch.empty(n + 1, dtype=torch.float32, device=grads[0].device)
+        flat = self.flat[:n + 1]
+        self.pack_fn(grads, flat[:n])
+        # the update kernel drops a step while the LOCAL error word is set: the word rides behind the gradients so that
+        # every rank drops the same steps (replicas stay bit-identical)
+        share = grads[0].is_cuda
+        if share:
+            ops.err_word_exchange(flat[n:], 0)
+        else:
+            flat[n] = 0.0
         self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM, group=self.group)
-        self.unpack_fn(grads, flat, scale)
+        if share:
+            ops.err_word_exchange(flat[n:], 1)
+        self.unpack_fn(grads, flat[:n], scale)
 
 
 class DataParallelAdam(Adam):

@@ -302,12 +302,12 @@ def train_factual(encoder, decoder, optimizer, criterion, data_loader, log_step,
             if pipe is not None:
                 pipe.finish()
             _drain(pending, losses)
-            ops.check_device_errors()
+            ops.check_device_errors(recover_lstm_timeout=True)
             print("""Step [{}/{}], [FAC], Loss: {:.4f}""".format(i, len(data_loader), losses.val))
     if pipe is not None:
         pipe.finish()
     _drain(pending, losses)
-    ops.check_device_errors()
+    ops.check_device_errors(recover_lstm_timeout=True)
     return losses.avg
 
 
@@ -336,13 +336,13 @@ def train_emotion(encoder, decoder, optimizer, criterion, data_loaders, tags, lo
                 if pipe is not None:
                     pipe.finish()
                 _drain(pending, losses[j])
-                ops.check_device_errors()
+                ops.check_device_errors(recover_lstm_timeout=True)
                 print("""Step [{}/{}], [{}], Loss: {:.4f}""".format(
                     i, len(data_loaders[j]), tags[j][:3].upper(), losses[j].val))
         if pipe is not None:
             pipe.finish()
         _drain(pending, losses[j])
-    ops.check_device_errors()
+    ops.check_device_errors(recover_lstm_timeout=True)
     return [l.avg for l in losses]
 
 

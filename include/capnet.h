@@ -520,6 +520,17 @@ int capnet_packed_targets(const long long* captions, int T, int steps, const int
 int capnet_pack_tensors(int n, float* const* tensors, const long* numel, float* flat,
                         int direction, float scale, capnet_stream_t stream);
 
+/* Data-parallel plumbing, the error word: capnet_clamp_adam drops a step while the LOCAL device error word is set, and
+ * every rank has to take that decision alike. direction 0: *slot = (word != 0) -- the slot is one extra float behind the
+ * flat gradient buffer, so it is summed by the same all-reduce; direction 1: if the sum is positive and the local word is
+ * clear, set it to 16 ("another rank dropped this step"). No reference counterpart. */
+int capnet_err_word_exchange(int* err_flag, float* slot, int direction, capnet_stream_t stream);
+
+/* *counter += 1 while *err_flag != 0. capnet.optim.Adam launches it once per step() in front of capnet_clamp_adam and
+ * takes the dropped steps out of its host-side step counts (torch.optim.Adam's bias correction, train_multitask.py:389)
+ * when check_device_errors() reports them. */
+int capnet_count_skipped(const int* err_flag, int* counter, capnet_stream_t stream);
+
 /* x[i] = min(max(x[i], lo), hi): utils.clip_gradient alone (stylenet/utils.py:57-60). */
 int capnet_clamp(float* x, long n, float lo, float hi, capnet_stream_t stream);
 

@@ -78,3 +78,97 @@ def test_self_launch_propagates_a_rank_failure():
                         "--decoder", "factored", "--batch", "0"], cwd=ROOT, env=env, capture_output=True,
                        text=True, timeout=300)
     assert p.returncode != 0 and not [l for l in p.stdout.splitlines() if l.startswith("{")]
+
+
+# ---- bench.py's multi-rank weighting, numerically ------------------------------------------------
+def _dp_worker(rank, world, port, outdir, B, V):
+    """One rank of a two-rank job on device 0 over gloo: bench.py's own rank_shard() + DataParallelAdam (HIP pack ->
+    all-reduce -> unpack -> fused clamp+Adam), decoder only (seeded features stand in for the trunk)."""
+    import random
+    import torch
+    import torch.distributed as dist
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    import bench
+    import capnet  # noqa: F401
+    from capnet import ops, synthetic
+    from capnet.model import DecoderFactoredLSTM
+    from capnet.parallel import DataParallelAdam
+    from capnet.train import _backward
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    _, captions, lengths, loss_scale, global_steps = bench.rank_shard(B, V, rank, world, images=False)
+    dec = DecoderFactoredLSTM(300, 512, 512, V, 1, dropout=0.0)
+    dec.load_state_dict(synthetic.decoder_state(dec.state_dict(), seed=1234))
+    dec.to(dev).train()
+    feats = torch.randn(B, 300, generator=torch.Generator().manual_seed(500 + rank)).to(dev)
+    opt = DataParallelAdam(dec.parameters(), lr=2e-4, overlap=False)
+    assert opt.reducer is not None
+    random.seed(0)
+    tf = [random.random() < 0.8 for _ in range(global_steps)]
+    cap_d = captions.to(dev)
+    out = dec(cap_d, lengths, feats, tf_mask=tf)
+    loss = ops.cross_entropy(out, ops.packed_targets(cap_d, lengths))
+    dec.zero_grad()
+    _backward(loss, loss_scale)
+    opt.step()                     # no clamp pending: .grad afterwards is the reduced gradient
+    torch.cuda.synchronize()
+    ops.check_device_errors()
+    torch.save({"grads": {k: p.grad.cpu() for k, p in dec.named_parameters() if p.grad is not None},
+                "params": {k: p.detach().cpu() for k, p in dec.named_parameters()},
+                "loss": float(loss.item()), "loss_scale": loss_scale, "tf": tf, "lengths": lengths},
+               os.path.join(outdir, "rank%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_is_the_token_weighted_mean(tmp_path):
+    """the reduced gradient equals the N-weighted mean of the per-shard reference gradients, and every
+    rank holds the same parameters after the update. Two ranks on this box's one GPU over gloo (RCCL refuses two ranks
+    per device) through bench.py's own shard / loss_scale / global_steps code; the expectation is built from the
+    shards' ACTUAL batches (make_batch with images), so a rank_shard that rebuilds other ranks' lengths from different
+    draws (the bug behind commit 3464b6a) fails here."""
+    import socket
+    import torch
+    import torch.multiprocessing as mp
+    sys.path.insert(0, ROOT)
+    from capnet import synthetic
+    from oracle import decoders_ref as D
+    from oracle import step_ref as S
+    B, V, world = 64, 8192, 2
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    mp.spawn(_dp_worker, args=(world, port, str(tmp_path), B, V), nprocs=world, join=True)
+    got = [torch.load(str(tmp_path / ("rank%d.pt" % r)), weights_only=True) for r in range(world)]
+    torch.set_num_threads(16)
+    from capnet.model import DecoderFactoredLSTM
+    p = synthetic.decoder_state(DecoderFactoredLSTM(300, 512, 512, V, 1).state_dict(), seed=1234)
+    shards_full = [synthetic.make_batch(B, V, seed=r)[1:] for r in range(world)]      # the TRUE batches (images drawn)
+    n_global = sum(sum(sh[1]) for sh in shards_full)
+    want = None
+    for r in range(world):
+        captions, lengths = shards_full[r]
+        assert lengths == got[r]["lengths"]
+        assert abs(got[r]["loss_scale"] - sum(lengths) / n_global) < 1e-12
+        feats = torch.randn(B, 300, generator=torch.Generator().manual_seed(500 + r))
+        tf = got[r]["tf"]
+        assert tf == got[0]["tf"]
+        loss, grads, _, _ = S.decoder_loss_and_grads(D.factored_lstm_forward, p, captions, lengths, feats,
+                                                     tf[:max(lengths)], mode="factual")
+        assert abs(got[r]["loss"] - float(loss)) < 1e-4 * float(loss)
+        w = sum(lengths) / n_global
+        if want is None:
+            want = {k: g * w for k, g in grads.items() if g is not None}
+        else:
+            for k, g in grads.items():
+                if g is not None:
+                    want[k] += g * w
+    for k, g in want.items():
+        for r in range(world):
+            err = (got[r]["grads"][k] - g).abs().max().item()
+            assert err <= 2e-5 * max(g.abs().max().item(), 1e-8) + 1e-9, (k, r, err)
+    for k in got[0]["params"]:
+        assert torch.equal(got[0]["params"][k], got[1]["params"][k]), k

@@ -142,3 +142,56 @@ def test_step_cap_and_bad_lengths_raise(dev):
     dec(bad.to(dev), [4, 3], None, tf_mask=[True] * 4)
     with pytest.raises(capnet.CapnetError):
         ops.check_device_errors()
+
+
+# ---- the device error word: dropped steps are taken out of Adam's step counts; the word crosses ranks ----
+def test_dropped_steps_leave_parameters_moments_and_step_counts_consistent(dev):
+    """While the error word is set capnet_clamp_adam drops its update; the host-side step counts (bias correction of
+    torch.optim.Adam, train_multitask.py:389) must not run ahead of the moments. Two good steps, two dropped ones, the
+    check (raises, rolls the counts back), one more good step == three good steps of an untouched twin."""
+    from capnet.optim import Adam
+    torch.manual_seed(0)
+    w0 = torch.randn(300, 17)
+    gs = [torch.randn(300, 17) * 0.1 for _ in range(5)]
+
+    def run(fault):
+        p = torch.nn.Parameter(w0.clone().to(dev))
+        opt = Adam([p], lr=1e-2)
+        for i, g in enumerate(gs):
+            if fault and i in (2, 3):
+                if i == 2:
+                    ops.err_flag(dev).fill_(1)
+            elif not fault and i in (2, 3):
+                continue
+            p.grad = g.clone().to(dev)
+            opt.step()
+            if fault and i == 3:
+                before = p.detach().clone()
+                with pytest.raises(capnet.CapnetError, match="2 optimizer steps"):
+                    ops.check_device_errors()
+                assert opt.state[p]["step"] == 2 and torch.equal(before, p.detach())
+        ops.check_device_errors()
+        return p.detach().cpu(), opt.state[p]["step"], opt.state[p]["exp_avg"].cpu()
+    a, b = run(True), run(False)
+    assert a[1] == b[1] == 3
+    assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2])
+
+
+def test_error_word_rides_behind_the_flat_gradient(dev):
+    slot = torch.full((1,), 7.0, device=dev)
+    err = ops.err_flag(dev)
+    ops.err_word_exchange(slot, 0)
+    assert slot.item() == 0.0 and err.item() == 0
+    err.fill_(2)
+    ops.err_word_exchange(slot, 0)
+    assert slot.item() == 1.0
+    err.zero_()
+    slot.fill_(3.0)                    # "three ranks had a fault" after the SUM all-reduce
+    ops.err_word_exchange(slot, 1)
+    assert err.item() == 16
+    with pytest.raises(capnet.CapnetError, match="another rank"):
+        ops.check_device_errors()
+    slot.zero_()
+    ops.err_word_exchange(slot, 1)
+    assert err.item() == 0
+    ops.check_device_errors()
