@@ -134,6 +134,10 @@ SIGNATURES = {
     "capnet_trunk_collect_timing": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(_l),
                                          C.POINTER(C.c_double)]),
     "capnet_packed_targets": (_i, [_vp, _i, _i, _ip, _vp, _vp]),
+    "capnet_comm_unique_id": (_i, [_vp]),
+    "capnet_comm_create": (_i, [_vp, _i, _i, C.POINTER(_vp)]),
+    "capnet_comm_destroy": (_i, [_vp]),
+    "capnet_allreduce_grads": (_i, [_vp, _vp, _l, _vp]),
     "capnet_err_word_exchange": (_i, [_vp, _vp, _i, _vp]),
     "capnet_count_skipped": (_i, [_vp, _vp, _vp]),
     "capnet_pack_tensors": (_i, [_i, C.POINTER(_vp), C.POINTER(_l), _vp, _i, C.c_float, _vp]),

@@ -532,6 +532,15 @@ int capnet_pack_tensors(int n, float* const* tensors, const long* numel, float* 
   return pack_tensors(n, tensors, numel, flat, direction, scale, S(stream));
 }
 
+int capnet_comm_unique_id(void* id128) { return comm_unique_id(id128); }
+int capnet_comm_create(const void* id128, int rank, int world, capnet_comm_t** out) {
+  return comm_create(id128, rank, world, reinterpret_cast<Comm**>(out));
+}
+int capnet_comm_destroy(capnet_comm_t* comm) { return comm_destroy(reinterpret_cast<Comm*>(comm)); }
+int capnet_allreduce_grads(capnet_comm_t* comm, float* flat, long count, capnet_stream_t stream) {
+  return allreduce_grads(reinterpret_cast<Comm*>(comm), flat, count, S(stream));
+}
+
 int capnet_err_word_exchange(int* err_flag, float* slot, int direction, capnet_stream_t stream) {
   return err_word_exchange(err_flag, slot, direction, S(stream));
 }

@@ -266,6 +266,11 @@ int lstm_persist_set_mode(int mode);
 int clamp_adam(int n_tensors, float* const* params, float* const* grads, float* const* exp_avg,
                float* const* exp_avg_sq, const long* numel, const int* step, float lr, float b1,
                float b2, float eps, float clip, int write_grad, const int* skip_flag, hipStream_t stream);
+struct Comm;
+int comm_unique_id(void* id128);
+int comm_create(const void* id128, int rank, int world, Comm** out);
+int comm_destroy(Comm* c);
+int allreduce_grads(Comm* c, float* flat, long count, hipStream_t stream);
 int err_word_exchange(int* err_flag, float* slot, int dir, hipStream_t stream);
 int count_skipped(const int* err_flag, int* counter, hipStream_t stream);
 int pack_tensors(int n_tensors, float* const* tensors, const long* numel, float* flat, int dir,

@@ -53,9 +53,7 @@ _ERR_BITS = {1: "token id out of range", 2: "target out of range",
              4: "a bounded wait of the persistent LSTM kernel expired (its 256 workgroups were not co-resident in time); "
                 "the process now runs one launch per LSTM step, as CAPNET_NO_PERSISTENT_LSTM=1 does from the start",
              16: "another rank of the data-parallel job raised its error word: this rank dropped the same steps so that "
-                 "the replicas stay identical (capnet.parallel)",
-             32: "a recurrent LSTM weight beyond the persistent kernel's split-f16 domain (|w| >= 32): its hiddens are "
-                 "not finite; run with CAPNET_NO_PERSISTENT_LSTM=1 for such weights"}
+                 "the replicas stay identical (capnet.parallel)"}
 
 _optimizers = weakref.WeakSet()      # capnet.optim.Adam instances: they hold the per-optimizer dropped-step counters
 

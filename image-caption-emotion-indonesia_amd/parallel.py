@@ -34,16 +34,58 @@ def draw_tf_mask(n_steps, teacher_forcing_ratio):
     return [random.random() < teacher_forcing_ratio for _ in range(n_steps)]
 
 
+class NativeComm:
+    """RCCL through the C ABI (capnet_comm_create / capnet_allreduce_grads, include/capnet.h) instead of through
+    torch.distributed: the 128-byte unique id is drawn on rank 0 and handed round with torch.distributed's object
+    broadcast (any backend), the communicator binds to the current device, the all-reduce is enqueued on the CURRENT
+    torch stream. Opt-in (CAPNET_NATIVE_RCCL=1 or GradAllReducer(native=True)): the default stays torch.distributed,
+    whose process group the caller has anyway."""
+
+    def __init__(self, process_group=None):
+        import ctypes as C
+        import torch.distributed as dist
+        from . import _lib
+        self._lib, self._C = _lib, C
+        if dist.is_initialized():
+            rank, world = dist.get_rank(process_group), dist.get_world_size(process_group)
+        else:
+            rank, world = 0, 1
+        buf = (C.c_ubyte * 128)()
+        if rank == 0:
+            _lib.check(_lib.lib().capnet_comm_unique_id(buf), "capnet_comm_unique_id")
+        ids = [bytes(buf)]
+        if world > 1:
+            dist.broadcast_object_list(ids, src=0, group=process_group)
+        idbuf = (C.c_ubyte * 128).from_buffer_copy(ids[0])
+        self.handle = C.c_void_p()
+        _lib.check(_lib.lib().capnet_comm_create(idbuf, rank, world, C.byref(self.handle)), "capnet_comm_create")
+        self.rank, self.world = rank, world
+
+    def all_reduce(self, flat):
+        if not (flat.is_cuda and flat.dtype == torch.float32 and flat.is_contiguous()):
+            raise ops.CapnetError("NativeComm.all_reduce: a contiguous fp32 CUDA tensor is required")
+        self._lib.check(self._lib.lib().capnet_allreduce_grads(self.handle, flat.data_ptr(), flat.numel(),
+                                                               self._lib.current_stream()), "capnet_allreduce_grads")
+
+    def destroy(self):
+        if self.handle:
+            self._lib.check(self._lib.lib().capnet_comm_destroy(self.handle), "capnet_comm_destroy")
+            self.handle = None
+
+
 class GradAllReducer:
     """Packs gradients into one flat buffer, all-reduces it, scatters it back.
 
     pack_fn(tensors, flat) / unpack_fn(tensors, flat, scale) default to the HIP kernels; the
     CPU gloo tests inject torch versions (test infrastructure) to exercise this logic."""
 
-    def __init__(self, process_group=None, pack_fn=None, unpack_fn=None):
+    def __init__(self, process_group=None, pack_fn=None, unpack_fn=None, native=None):
         import torch.distributed as dist
         self.dist = dist
         self.group = process_group
+        if native is None:
+            native = os.environ.get("CAPNET_NATIVE_RCCL") == "1"
+        self.native = NativeComm(process_group) if native else None
         self.pack_fn = pack_fn or (lambda ts, flat: ops.pack_tensors(ts, flat, unpack=False))
         self.unpack_fn = unpack_fn or (lambda ts, flat, s: ops.pack_tensors(ts, flat, unpack=True, scale=s))
         self.flat = None
@@ -63,7 +105,10 @@ class GradAllReducer:
             ops.err_word_exchange(flat[n:], 0)
         else:
             flat[n] = 0.0
-        self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM, group=self.group)
+        if self.native is not None:
+            self.native.all_reduce(flat)
+        else:
+            self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM, group=self.group)
         if share:
             ops.err_word_exchange(flat[n:], 1)
         self.unpack_fn(grads, flat[:n], scale)

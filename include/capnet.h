@@ -520,6 +520,19 @@ int capnet_packed_targets(const long long* captions, int T, int steps, const int
 int capnet_pack_tensors(int n, float* const* tensors, const long* numel, float* flat,
                         int direction, float scale, capnet_stream_t stream);
 
+/* Data-parallel plumbing, the collective (no reference counterpart -- the reference is single-device): an
+ * RCCL communicator behind an opaque handle and the step's ONE collective, an in-place SUM all-reduce of the flat fp32
+ * gradient buffer, enqueued on the caller's stream (the side stream of capnet.parallel: it overlaps the next trunk
+ * passes). One process per GPU. capnet_comm_unique_id fills 128 bytes on ONE rank; the caller hands them to every rank
+ * by its own means (capnet.parallel: torch.distributed's store); capnet_comm_create is collective over the `world`
+ * ranks and binds the communicator to the calling process's current HIP device. librccl is resolved at run time (an
+ * RCCL already mapped into the process first, then /opt/rocm/lib): a single-GPU host never loads it. */
+typedef struct capnet_comm capnet_comm_t;
+int capnet_comm_unique_id(void* id128);
+int capnet_comm_create(const void* id128, int rank, int world, capnet_comm_t** out);
+int capnet_comm_destroy(capnet_comm_t* comm);
+int capnet_allreduce_grads(capnet_comm_t* comm, float* flat, long count, capnet_stream_t stream);
+
 /* Data-parallel plumbing, the error word: capnet_clamp_adam drops a step while the LOCAL device error word is set, and
  * every rank has to take that decision alike. direction 0: *slot = (word != 0) -- the slot is one extra float behind the
  * flat gradient buffer, so it is summed by the same all-reduce; direction 1: if the sum is positive and the local word is

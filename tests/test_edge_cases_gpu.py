@@ -195,3 +195,24 @@ def test_error_word_rides_behind_the_flat_gradient(dev):
     ops.err_word_exchange(slot, 1)
     assert err.item() == 0
     ops.check_device_errors()
+
+
+def test_native_rccl_allreduce_single_rank(dev):
+    """capnet_comm_create / capnet_allreduce_grads (include/capnet.h): an RCCL communicator of one rank, the flat
+    gradient's size, on a side stream; a one-rank SUM leaves the buffer as it is. (Two ranks need two GPUs: RCCL refuses
+    two ranks per device; the N > 1 logic runs over gloo in tests/test_parallel_cpu.py and tests/test_bench_gpu.py.)"""
+    from capnet.parallel import GradAllReducer
+    red = GradAllReducer(native=True)
+    assert red.native.world == 1
+    gs = [torch.randn(1000, 300, device=dev), torch.randn(7, device=dev), torch.randn(8192, 512, device=dev)]
+    want = [g.clone() for g in gs]
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        red(gs, 1.0)
+        red(gs, 0.5)
+    torch.cuda.current_stream().wait_stream(side)
+    for g, w in zip(gs, want):
+        assert torch.equal(g, w * 0.5)
+    red.native.destroy()
+    ops.check_device_errors()
