@@ -134,6 +134,13 @@ SIGNATURES = {
     "capnet_trunk_collect_timing": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(_l),
                                          C.POINTER(C.c_double)]),
     "capnet_packed_targets": (_i, [_vp, _i, _i, _ip, _vp, _vp]),
+    "capnet_fused_block_weight_words": (_sz, [_i, _i, _i]),
+    "capnet_fused_block_pack": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "capnet_fused_block_stats_floats": (_sz, [_l, _i]),
+    "capnet_fused_block_stats": (_i, [_vp, _vp, _vp, _vp, _l, _i, _i, _vp, _vp, _vp, _vp, C.c_float, C.c_float, _vp, _vp, _vp,
+                                      _vp, _vp]),
+    "capnet_fused_block_tiles": (_i, [_l, _i]),
+    "capnet_fused_block_forward": (_i, [_vp] * 14 + [_l, _i, _i, _i, _vp, _vp]),
     "capnet_comm_unique_id": (_i, [_vp]),
     "capnet_comm_create": (_i, [_vp, _i, _i, C.POINTER(_vp)]),
     "capnet_comm_destroy": (_i, [_vp]),

@@ -532,6 +532,27 @@ int capnet_pack_tensors(int n, float* const* tensors, const long* numel, float* 
   return pack_tensors(n, tensors, numel, flat, direction, scale, S(stream));
 }
 
+size_t capnet_fused_block_weight_words(int C, int MID, int role) { return fused_block_weight_words(C, MID, role); }
+int capnet_fused_block_pack(const float* w, unsigned* img, int C, int MID, int role, capnet_stream_t stream) {
+  return fused_block_pack(w, img, C, MID, role, S(stream));
+}
+size_t capnet_fused_block_stats_floats(long M, int MID) { return fused_block_stats_floats(M, MID); }
+int capnet_fused_block_stats(const float* y2, const float* s2, const float* t2, const unsigned* w3img, long M, int MID,
+                             int in_exp, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                             float momentum, float eps, float* scale, float* shift, float* work, int* err_flag,
+                             capnet_stream_t stream) {
+  return fused_block_stats(y2, s2, t2, w3img, M, MID, in_exp, gamma, beta, running_mean, running_var, momentum, eps, scale,
+                           shift, nullptr, nullptr, work, err_flag, S(stream));
+}
+int capnet_fused_block_tiles(long M, int MID) { return fused_block_tiles(M, MID); }
+int capnet_fused_block_forward(const float* y2, const float* s2, const float* t2, const unsigned* w3img, const float* s3,
+                               const float* t3, const float* res, const float* sd, const float* td, float* out,
+                               const unsigned* w1img, float* y1, float* part_sum, float* part_sq, long M, int MID, int e3,
+                               int e1, int* err_flag, capnet_stream_t stream) {
+  return fused_block_forward(y2, s2, t2, w3img, s3, t3, res, sd, td, out, w1img, y1, part_sum, part_sq, M, MID, e3, e1,
+                             err_flag, S(stream));
+}
+
 int capnet_comm_unique_id(void* id128) { return comm_unique_id(id128); }
 int capnet_comm_create(const void* id128, int rank, int world, capnet_comm_t** out) {
   return comm_create(id128, rank, world, reinterpret_cast<Comm**>(out));

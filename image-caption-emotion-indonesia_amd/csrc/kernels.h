@@ -266,6 +266,18 @@ int lstm_persist_set_mode(int mode);
 int clamp_adam(int n_tensors, float* const* params, float* const* grads, float* const* exp_avg,
                float* const* exp_avg_sq, const long* numel, const int* step, float lr, float b1,
                float b2, float eps, float clip, int write_grad, const int* skip_flag, hipStream_t stream);
+// fused_block.hip: conv3 + BatchNorm3 + residual + ReLU + the next conv1 without y3 (statistics from the Gram matrix of conv3's input)
+bool fused_block_shape_ok(long M, int MID);
+size_t fused_block_weight_words(int C, int MID, int role);
+int fused_block_pack(const float* w, unsigned* img, int C, int MID, int role, hipStream_t stream);
+size_t fused_block_stats_floats(long M, int K);
+int fused_block_stats(const float* y2, const float* s2, const float* t2, const unsigned* w3img, long M, int MID, int in_exp,
+                      const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                      float* scale, float* shift, float* batch_mean, float* batch_var, float* work, int* err, hipStream_t stream);
+int fused_block_tiles(long M, int MID);
+int fused_block_forward(const float* y2, const float* s2, const float* t2, const unsigned* w3img, const float* s3, const float* t3,
+                        const float* res, const float* sd, const float* td, float* out, const unsigned* w1img, float* y1,
+                        float* part_sum, float* part_sq, long M, int MID, int e3, int e1, int* err, hipStream_t stream);
 struct Comm;
 int comm_unique_id(void* id128);
 int comm_create(const void* id128, int rank, int world, Comm** out);

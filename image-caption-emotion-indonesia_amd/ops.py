@@ -344,6 +344,49 @@ def pack_conv_weight_f16x3(w_oihw, bn):
     return out
 
 
+def pack_fused_block_weight(w_oihw, role):
+    """1x1 OIHW weights -> the image of capnet_fused_block_forward: role 0 = conv3 of a bottleneck ([C][MID][1][1]),
+    role 1 = the next block's conv1 ([MID][C][1][1])."""
+    _need_cuda(w_oihw)
+    w = _c(w_oihw)
+    co, ci = w.shape[0], w.shape[1]
+    cc, mid = (co, ci) if role == 0 else (ci, co)
+    if tuple(w.shape[2:]) != (1, 1) or cc != 4 * mid:
+        raise CapnetError("pack_fused_block_weight: role %d expects a 1x1 convolution between MID and 4 MID channels" % role)
+    out = torch.empty(_lib.lib().capnet_fused_block_weight_words(cc, mid, role), dtype=torch.int32, device=w.device)
+    check(_lib.lib().capnet_fused_block_pack(ptr(w), ptr(out), cc, mid, role, current_stream()), "capnet_fused_block_pack")
+    return out
+
+
+def fused_block_stats(y2, s2, t2, w3img, gamma, beta, running_mean=None, running_var=None, momentum=0.1, eps=1e-5, in_exp=0):
+    """(scale, shift) of bn3 behind conv3(relu(y2 s2 + t2)) without forming conv3's output (capnet_fused_block_stats)."""
+    _need_cuda(y2, s2, t2, w3img, gamma, beta, running_mean, running_var)
+    M, mid = y2.shape
+    work = torch.empty(_lib.lib().capnet_fused_block_stats_floats(M, mid), dtype=torch.float32, device=y2.device)
+    scale = torch.empty(4 * mid, dtype=torch.float32, device=y2.device)
+    shift = torch.empty_like(scale)
+    check(_lib.lib().capnet_fused_block_stats(ptr(y2), ptr(s2), ptr(t2), ptr(w3img), M, mid, in_exp, ptr(gamma), ptr(beta),
+                                              ptr(running_mean), ptr(running_var), momentum, eps, ptr(scale), ptr(shift),
+                                              ptr(work), ptr(err_flag(y2.device)), current_stream()), "capnet_fused_block_stats")
+    return scale, shift
+
+
+def fused_block_forward(y2, s2, t2, w3img, s3, t3, res, w1img, sd=None, td=None, stats=True, e3=0, e1=0):
+    """-> (out [M, 4 MID], y1 [M, MID], part_sum, part_sq) (capnet_fused_block_forward)."""
+    _need_cuda(y2, s2, t2, w3img, s3, t3, res, w1img, sd, td)
+    M, mid = y2.shape
+    dev = y2.device
+    out = torch.empty(M, 4 * mid, dtype=torch.float32, device=dev)
+    y1 = torch.empty(M, mid, dtype=torch.float32, device=dev)
+    tiles = _lib.lib().capnet_fused_block_tiles(M, mid)
+    ps = torch.empty(tiles, mid, dtype=torch.float32, device=dev) if stats else None
+    pq = torch.empty(tiles, mid, dtype=torch.float32, device=dev) if stats else None
+    check(_lib.lib().capnet_fused_block_forward(ptr(y2), ptr(s2), ptr(t2), ptr(w3img), ptr(s3), ptr(t3), ptr(res), ptr(sd),
+                                                ptr(td), ptr(out), ptr(w1img), ptr(y1), ptr(ps), ptr(pq), M, mid, e3, e1,
+                                                ptr(err_flag(dev)), current_stream()), "capnet_fused_block_forward")
+    return out, y1, ps, pq
+
+
 def pack_conv_weight_stem_f16x3(w_oihw):
     """The stem's OIHW weights [64][3][7][7] -> header + the split-f16 image of capnet_conv_stem_fwd_f16x3."""
     _need_cuda(w_oihw)

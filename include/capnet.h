@@ -520,6 +520,33 @@ int capnet_packed_targets(const long long* captions, int T, int steps, const int
 int capnet_pack_tensors(int n, float* const* tensors, const long* numel, float* flat,
                         int direction, float scale, capnet_stream_t stream);
 
+/* ---- a bottleneck's conv3 + bn3 + residual + ReLU + the next block's conv1 without ever forming y3 (csrc/fused_block.hip).
+ * Replaces, between two blocks of one stage of torchvision's resnet152 (Bottleneck.forward, called from
+ * stylenet/model.py:15-18,24): `out = relu(bn3(conv3(relu(bn2(y2)))) + identity)` of block b and `y1 = conv1(out)` of
+ * block b + 1. MID = conv3's input channels (64 / 128 / 256), C = 4 MID its output channels; all tensors NHWC fp32
+ * flattened to [M = B H W][channels].
+ *   capnet_fused_block_pack        role 0: conv3's weights [C][MID] -> its image (+ an fp32 copy, read by the statistics);
+ *                                  role 1: the next conv1's weights [MID][C] -> its image. Sizes: .._weight_words.
+ *   capnet_fused_block_stats       train mode: (scale, shift) of bn3 -- and its running statistics, momentum as torch --
+ *                                  from the second moments of conv3's INPUT: sum_m y3[m,c]^2 = w_c^T (a2^T a2) w_c with
+ *                                  a2 = relu(y2 s2 + t2). `work`: .._stats_floats(M, MID) floats, 16-B aligned.
+ *   capnet_fused_block_forward     writes out [M][C] and y1 [M][MID]; part_sum / part_sq [.._tiles(M, MID)][MID]: per-tile
+ *                                  column sums of y1 for capnet_bn_finalize (null: inference). res = the block's input
+ *                                  (sd = td = null) or its downsample branch's raw output with that BatchNorm's (sd, td).
+ *   e3 / e1: power-of-two prescales of conv3's and conv1's inputs in the f16 planes (capnet_trunk_forward's exponents). */
+size_t capnet_fused_block_weight_words(int C, int MID, int role);
+int capnet_fused_block_pack(const float* w, unsigned* img, int C, int MID, int role, capnet_stream_t stream);
+size_t capnet_fused_block_stats_floats(long M, int MID);
+int capnet_fused_block_stats(const float* y2, const float* s2, const float* t2, const unsigned* w3img, long M, int MID,
+                             int in_exp, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                             float momentum, float eps, float* scale, float* shift, float* work, int* err_flag,
+                             capnet_stream_t stream);
+int capnet_fused_block_tiles(long M, int MID);
+int capnet_fused_block_forward(const float* y2, const float* s2, const float* t2, const unsigned* w3img, const float* s3,
+                               const float* t3, const float* res, const float* sd, const float* td, float* out,
+                               const unsigned* w1img, float* y1, float* part_sum, float* part_sq, long M, int MID, int e3,
+                               int e1, int* err_flag, capnet_stream_t stream);
+
 /* Data-parallel plumbing, the collective (no reference counterpart -- the reference is single-device): an
  * RCCL communicator behind an opaque handle and the step's ONE collective, an in-place SUM all-reduce of the flat fp32
  * gradient buffer, enqueued on the caller's stream (the side stream of capnet.parallel: it overlaps the next trunk

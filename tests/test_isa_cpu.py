@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import isa_inflight_check as chk  # noqa: E402
 
-FILES = ["conv_f16x3.hip", "conv_f32_v2.hip", "lstm_persist.hip", "gemm_dma.hip", "conv3x3_patch.hip", "conv1x1_areg.hip", "gemm_f32.hip"]
+FILES = ["conv_f16x3.hip", "conv_f32_v2.hip", "lstm_persist.hip", "gemm_dma.hip", "conv3x3_patch.hip", "conv1x1_areg.hip", "gemm_f32.hip", "fused_block.hip"]
 
 
 @pytest.fixture(scope="module")
