@@ -442,7 +442,7 @@ def main():
                 fi = lib.capnet_trunk_conv_flops(plan["handle"], i)
                 kind = lib.capnet_trunk_conv_kmajor(plan["handle"], i)
                 algo += fi
-                if kind == 5:
+                if kind in (5, 7, 8):
                     f16x += 3.0 * fi
                     algo_f16 += fi
                 elif kind == 6:      # the stem: K = 147 issued as 22 rows x 8 taps = 176

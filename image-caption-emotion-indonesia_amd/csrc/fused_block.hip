@@ -68,8 +68,8 @@ __device__ __forceinline__ int fb_weight_shift(unsigned absmax_bits) {      // m
 }
 
 // role 0: W3 [C][MID] (conv3, the A operand of phase A): cells [chunk C/32][ks MID/32][blk 2][plane 2][lane 64] of 8 halfs
-//         = W3[32 chunk + 16 blk + (lane & 15)][32 ks + kslot(lane >> 4, j)], followed by a verbatim fp32 copy of W3 (the
-//         statistics' quadratic forms read the weights as they are);
+//         = W3[32 chunk + 16 blk + (lane & 15)][32 ks + kslot(lane >> 4, j)], followed by an fp32 copy of W3 (the
+//         statistics' quadratic forms read the weights as they are; laid out [C / 16][MID][16]);
 // role 1: W1 [MID][C] (the next conv1, the B operand of phase B): cells [chunk C/32][nb MID/16][plane 2][lane 64]
 //         = W1[16 nb + (lane & 15)][32 chunk + kslot(lane >> 4, j)].
 __global__ __launch_bounds__(256) void fb_pack_kernel(const float* __restrict__ w, unsigned* __restrict__ img, int C, int MID,
@@ -107,8 +107,13 @@ __global__ __launch_bounds__(256) void fb_pack_kernel(const float* __restrict__ 
     dst[0] = out[0]; dst[1] = out[1]; dst[2] = out[2]; dst[3] = out[3];
   }
   if (role == 0) {
+    // fp32 copy for the statistics' quadratic forms, 16 channels interleaved: cp[c / 16][k][c % 16] = W3[c][k] (the 16
+    // weights one k of a channel group needs sit in one 64-B line: scalar loads)
     float* cp = reinterpret_cast<float*>(img + kFHdr + (long)C * MID);
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (long)C * MID; i += (long)gridDim.x * blockDim.x) cp[i] = w[i];
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (long)C * MID; i += (long)gridDim.x * blockDim.x) {
+      const int c = (int)(i / MID), k = (int)(i - (long)c * MID);
+      cp[((long)(c >> 4) * MID + k) * 16 + (c & 15)] = w[i];
+    }
   }
 }
 
@@ -116,7 +121,6 @@ __global__ __launch_bounds__(256) void fb_pack_kernel(const float* __restrict__ 
 // statistics of y3 from the second moments of conv3's input
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kGR = 512;                  // rows of a slice
-constexpr int kGStage = 64;               // rows staged per step (8 row groups of 8)
 
 struct GArgs {
   const float* y2; const float* s2; const float* t2;
@@ -128,10 +132,13 @@ struct GArgs {
 // workgroup (slice, pair (bi <= bj) of 64-channel blocks): Gp = a2[rows, bi]^T a2[rows, bj] over the slice's rows; the
 // diagonal pairs also write the column sums of their block. a2 = relu(y2 s2 + t2) 2^e, split into f16 planes while it is
 // staged ([plane][8-row group][channel][8 halfs]: a cell is 8 ROWS of one channel = the k slots of both operands of
-// v_mfma_f32_32x32x16_f16 with k = row); three products, fp32 accumulate. 2 x 2 waves of 32 x 32.
+// v_mfma_f32_32x32x16_f16 with k = row); three products, fp32 accumulate. 2 x 2 waves of 32 x 32. A thread stages 8 rows x
+// 4 channels (eight 16-B loads, 512 contiguous bytes per row and half-wave) into four cells; a step is 64 rows of 128
+// channels (off-diagonal pairs) or 128 rows of 64; rows run TWO steps ahead in two named register sets (the kernel is
+// one memory round trip per step otherwise).
 __global__ __launch_bounds__(256) void fb_gram_kernel(const GArgs g) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * 8 * 128 * 16];      // two stages of 32 KB
-  __shared__ float cs_sh[256];
+  constexpr int kPlane = 8 * 128 * 16, kStageB = 2 * kPlane;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kStageB];      // two steps of 32 KB
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int slice = blockIdx.x / g.pairs, pair = blockIdx.x - slice * g.pairs;
   int bi = 0, bj = 0;
@@ -141,76 +148,80 @@ __global__ __launch_bounds__(256) void fb_gram_kernel(const GArgs g) {
     bj = bi + p;
   }
   const bool diag = bi == bj;
-  const int nch = diag ? 64 : 128;
+  const int nch = diag ? 64 : 128, nrg = diag ? 16 : 8, srows = 8 * nrg;      // channels, row groups and rows of a step
   const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
   const int row0 = slice * kGR;
   const int rows = min(kGR, g.M - row0);
-  const int nst = (rows + kGStage - 1) / kGStage;
+  const int nst = (rows + srows - 1) / srows;
   const float iscale = ldexpf(1.f, g.in_exp);
-  // this thread's channel (fixed) and first row group of a stage
-  const int chl = tid % nch, rg0 = tid / nch, rgs = 256 / nch;       // rgs = 4 (diag) / 2
-  const int chg = (chl < 64 ? bi * 64 + chl : bj * 64 + chl - 64);
-  const float sc = g.s2[chg], sh = g.t2[chg];
-  float colsum = 0.f;
+  const int chq = diag ? (tid & 15) : (tid & 31), rg = diag ? (tid >> 4) : (tid >> 5);
+  const int chl = 4 * chq;                                                     // first of this thread's 4 channels in the step image
+  const int chg = chl < 64 ? bi * 64 + chl : bj * 64 + chl - 64;
+  const f32x4 sc = *reinterpret_cast<const f32x4*>(g.s2 + chg), sh = *reinterpret_cast<const f32x4*>(g.t2 + chg);
+  f32x4 colsum = {0.f, 0.f, 0.f, 0.f};
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  constexpr int kPlane = 8 * 128 * 16, kStageB = 2 * kPlane;
-  float v[4][8];
-  auto fetch = [&](int st) {
+  f32x4 va[8], vb[8];
+  auto fetch = [&](int st, f32x4 (&v)[8]) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int rg = rg0 + q * rgs;
-      if (rg < 8) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int m = row0 + st * kGStage + rg * 8 + e;
-          v[q][e] = g.y2[(long)min(m, g.M - 1) * g.K + chg];
-        }
-      }
+    for (int e = 0; e < 8; ++e) {
+      const int m = row0 + st * srows + rg * 8 + e;
+      v[e] = *reinterpret_cast<const f32x4*>(g.y2 + (long)min(m, g.M - 1) * g.K + chg);
     }
   };
-  auto stage = [&](int st, int buf) {
+  auto stage = [&](int st, int buf, const f32x4 (&v)[8]) {
+    f32x4 x[8];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int rg = rg0 + q * rgs;
-      if (rg < 8) {
-        f32x4 a, b;
+    for (int e = 0; e < 8; ++e) {
+      const int m = row0 + st * srows + rg * 8 + e;
+      const bool ok = m < row0 + rows;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int m = row0 + st * kGStage + rg * 8 + e;
-          float x = fmaxf(fmaf(v[q][e], sc, sh), 0.f) * iscale;
-          x = (m < row0 + rows) ? x : 0.f;
-          colsum += x;
-          if (e < 4) a[e] = x; else b[e - 4] = x;
-        }
-        h4 ha, la, hb, lb;
-        fb_split4(a, ha, la);
-        fb_split4(b, hb, lb);
-        unsigned char* d = lds + buf * kStageB + (rg * 128 + chl) * 16;
-        *reinterpret_cast<h8*>(d) = fb_cat(ha, hb);
-        *reinterpret_cast<h8*>(d + kPlane) = fb_cat(la, lb);
+      for (int c = 0; c < 4; ++c) {
+        const float t = fmaxf(fmaf(v[e][c], sc[c], sh[c]), 0.f) * iscale;
+        x[e][c] = ok ? t : 0.f;
+        colsum[c] += x[e][c];
       }
     }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const f32x4 a = {x[0][c], x[1][c], x[2][c], x[3][c]}, b = {x[4][c], x[5][c], x[6][c], x[7][c]};
+      h4 ha, la, hb, lb;
+      fb_split4(a, ha, la);
+      fb_split4(b, hb, lb);
+      unsigned char* d = lds + buf * kStageB + (rg * nch + chl + c) * 16;
+      *reinterpret_cast<h8*>(d) = fb_cat(ha, hb);
+      *reinterpret_cast<h8*>(d + kPlane) = fb_cat(la, lb);
+    }
   };
-  fetch(0);
-  stage(0, 0);
-  __syncthreads();
-  for (int st = 0; st < nst; ++st) {
-    const int buf = st & 1;
-    if (st + 1 < nst) fetch(st + 1);
+  auto mma = [&](int buf) {
     const unsigned char* ia = lds + buf * kStageB + (wm * 32 + li) * 16;
     const unsigned char* ib = lds + buf * kStageB + ((diag ? 0 : 64) + wn * 32 + li) * 16;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int off = (2 * k + lh) * 128 * 16;
+    for (int k = 0; k < nrg / 2; ++k) {
+      const int off = (2 * k + lh) * nch * 16;
       const h8 ah = *reinterpret_cast<const h8*>(ia + off), al = *reinterpret_cast<const h8*>(ia + off + kPlane);
       const h8 bh = *reinterpret_cast<const h8*>(ib + off), bl = *reinterpret_cast<const h8*>(ib + off + kPlane);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
     }
-    if (st + 1 < nst) stage(st + 1, buf ^ 1);
+  };
+  const int last = nst - 1;
+  fetch(0, va);
+  fetch(last > 0 ? 1 : 0, vb);
+  stage(0, 0, va);
+  fetch(last > 1 ? 2 : last, va);
+  __syncthreads();
+  // step st is in LDS buffer st & 1; the register set of parity (st + 1) & 1 holds step st + 1, the other one step st + 2
+  for (int st = 0; st < nst; st += 2) {
+    if (st + 1 <= last) stage(st + 1, 1, vb);
+    fetch(st + 3 < last ? st + 3 : last, vb);
+    mma(0);
+    __syncthreads();
+    if (st + 1 > last) break;
+    if (st + 2 <= last) stage(st + 2, 0, va);
+    fetch(st + 4 < last ? st + 4 : last, va);
+    mma(1);
     __syncthreads();
   }
   // D[m][n]: m = (r & 3) + 8 (r >> 2) + 4 lh = channel of block bi, n = li = channel of block bj; both operands carried 2^e
@@ -222,15 +233,21 @@ __global__ __launch_bounds__(256) void fb_gram_kernel(const GArgs g) {
     out[m * 64 + wn * 32 + li] = acc[r] * osc;
   }
   if (diag) {
+    f32x4* cs_sh = reinterpret_cast<f32x4*>(lds);              // [16 row groups][16 channel quads]
     cs_sh[tid] = colsum;
     __syncthreads();
-    if (tid < 64) g.cs[(long)slice * g.K + bi * 64 + tid] = ((cs_sh[tid] + cs_sh[tid + 64]) + (cs_sh[tid + 128] + cs_sh[tid + 192])) * ldexpf(1.f, -g.in_exp);
+    if (tid < 16) {
+      f32x4 t = cs_sh[tid];
+#pragma unroll
+      for (int q = 1; q < 16; ++q) t += cs_sh[q * 16 + tid];
+      *reinterpret_cast<f32x4*>(g.cs + (long)slice * g.K + bi * 64 + 4 * tid) = t * ldexpf(1.f, -g.in_exp);
+    }
   }
 }
 
-// G (full, symmetric) and the column sums in double: 8 threads share an entry's slices
-__global__ __launch_bounds__(256) void fb_gram_reduce_kernel(const float* __restrict__ gp, const float* __restrict__ cs, double* __restrict__ G,
-                                                             double* __restrict__ mu, int K, int slices, int pairs) {
+// G (full, symmetric) and the column sums, summed over the slices in double, stored fp32: 8 threads share an entry's slices
+__global__ __launch_bounds__(256) void fb_gram_reduce_kernel(const float* __restrict__ gp, const float* __restrict__ cs, float* __restrict__ G,
+                                                             float* __restrict__ mu, int K, int slices, int pairs) {
   __shared__ double sh[8][33];
   const int e = blockIdx.x * 32 + (threadIdx.x & 31), part = threadIdx.x >> 5;
   const int nG = K * K;
@@ -252,52 +269,64 @@ __global__ __launch_bounds__(256) void fb_gram_reduce_kernel(const float* __rest
   if (part == 0) {
 #pragma unroll
     for (int q = 1; q < 8; ++q) s += sh[q][threadIdx.x & 31];
-    if (e < nG) G[e] = s;
-    else if (e < nG + K) mu[e - nG] = s;
+    if (e < nG) G[e] = (float)s;
+    else if (e < nG + K) mu[e - nG] = (float)s;
   }
 }
 
-constexpr int kQC = 8;                   // channels per workgroup of the quadratic forms
+constexpr int kQC = 16;                  // channels per workgroup of the quadratic forms
 
-// channel c: sum = mu . w_c, sumsq = w_c^T G w_c (double), then bn_finalize_kernel's arithmetic (bn_pool.hip)
-__global__ __launch_bounds__(256) void fb_quad_kernel(const double* __restrict__ G, const double* __restrict__ mu,
-                                                      const float* __restrict__ w /* [C][K] */, int K, int C, double inv_count,
-                                                      double unbias, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                      float* __restrict__ running_mean, float* __restrict__ running_var,
-                                                      float momentum, float eps, float* __restrict__ scale, float* __restrict__ shift,
-                                                      float* __restrict__ batch_mean, float* __restrict__ batch_var, int* __restrict__ err) {
-  __shared__ float wsh[kQC][256];
-  __shared__ double red[2][kQC][4];
-  const int tid = threadIdx.x, c0 = blockIdx.x * kQC;
-  for (int i = tid; i < kQC * K; i += 256) wsh[i / K][i % K] = (c0 + i / K < C) ? w[(long)c0 * K + i] : 0.f;
-  __syncthreads();
-  const int col = tid % K, rpart = tid / K, nparts = 256 / K;
-  double t[kQC];
+// channel c: sum = mu . w_c, sumsq = w_c^T G w_c, then bn_finalize_kernel's arithmetic (bn_pool.hip).
+// A workgroup takes 16 channels: T [16 x K] = W_g [16 x K] . G [K x K] on v_mfma_f32_16x16x4_f32 (exact fp32 fma chains --
+// a sum of K^2 terms of mixed sign carries ~1e-7 sqrt-wise, the grade of the fp32 partial sums the stand-alone statistics
+// carry), one 16-column block of G per wave, both operands straight from global memory with every load of a half in flight at
+// once (the kernel is a chain of memory round trips otherwise: 32 us with a scalar-operand loop, 3 us like this); then
+// sumsq_c = sum_t T[c][t] w_c[t] across lanes and waves. mean / variance / 1/sqrt in double.
+template <int K>
+__global__ __launch_bounds__(K * 4) void fb_quad_kernel(const float* __restrict__ G, const float* __restrict__ mu,
+                                                        const float* __restrict__ w /* [C / 16][K][16] */, int C, double inv_count,
+                                                        double unbias, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                        float momentum, float eps, float* __restrict__ scale, float* __restrict__ shift,
+                                                        float* __restrict__ batch_mean, float* __restrict__ batch_var, int* __restrict__ err) {
+  constexpr int NW = K / 16, S = K / 4, SB = S < 32 ? S : 32;
+  __shared__ float red[2][kQC][NW];
+  const int tid = threadIdx.x, lane = tid & 63, nb = tid >> 6, g4 = lane >> 4, ln = lane & 15, c0 = blockIdx.x * kQC;
+  const float* wq = w + (long)blockIdx.x * K * kQC;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  // A[m = channel ln][k = 4 s + g4] = wq[k][ln];  B[k = 4 s + g4][n = column 16 nb + ln] = G[k][16 nb + ln]
 #pragma unroll
-  for (int c = 0; c < kQC; ++c) t[c] = 0.0;
-  for (int k = rpart; k < K; k += nparts) {
-    const double gv = G[(long)k * K + col];
+  for (int s0 = 0; s0 < S; s0 += SB) {
+    float a[SB], b[SB];
 #pragma unroll
-    for (int c = 0; c < kQC; ++c) t[c] = fma(gv, (double)wsh[c][k], t[c]);
-  }
-  double q[kQC], s[kQC];
-  const double m = rpart == 0 ? mu[col] : 0.0;
-#pragma unroll
-  for (int c = 0; c < kQC; ++c) {
-    q[c] = t[c] * (double)wsh[c][col];
-    s[c] = m * (double)wsh[c][col];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      q[c] += __shfl_xor(q[c], o);
-      s[c] += __shfl_xor(s[c], o);
+    for (int i = 0; i < SB; ++i) {
+      const int k = 4 * (s0 + i) + g4;
+      a[i] = wq[k * kQC + ln];
+      b[i] = G[(long)k * K + 16 * nb + ln];
     }
-    if ((tid & 63) == 0) { red[0][c][tid >> 6] = q[c]; red[1][c][tid >> 6] = s[c]; }
+#pragma unroll
+    for (int i = 0; i < SB; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[i], acc, 0, 0, 0);
+  }
+  // D[r]: channel 4 g4 + r, column 16 nb + ln
+  const int col = 16 * nb + ln;
+  const f32x4 wv = *reinterpret_cast<const f32x4*>(wq + col * kQC + 4 * g4);
+  const float m = mu[col];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float q = acc[r] * wv[r], sm = m * wv[r];
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+      q += __shfl_xor(q, o);
+      sm += __shfl_xor(sm, o);
+    }
+    if (ln == 0) { red[0][4 * g4 + r][nb] = q; red[1][4 * g4 + r][nb] = sm; }
   }
   __syncthreads();
   if (tid < kQC && c0 + tid < C) {
     const int c = c0 + tid;
-    const double qq = (red[0][tid][0] + red[0][tid][1]) + (red[0][tid][2] + red[0][tid][3]);
-    const double ss = (red[1][tid][0] + red[1][tid][1]) + (red[1][tid][2] + red[1][tid][3]);
+    double qq = 0.0, ss = 0.0;
+#pragma unroll
+    for (int v = 0; v < NW; ++v) { qq += (double)red[0][tid][v]; ss += (double)red[1][tid][v]; }
     if (err && !(qq < __builtin_inf())) atomicOr(err, 8);
     const double mean = ss * inv_count;
     double var = qq * inv_count - mean * mean;
@@ -329,6 +358,7 @@ struct FArgs {
   float* out; float* y1; float* part_sum; float* part_sq;
   int M, e3, e1;
   int* err;
+  int dbg;      // timing experiments only (CAPNET_FB_DBG): 1 no weight DMA in the loop, 2 no identity loads / out stores, 4 drain-all waits
 };
 
 template <int N>
@@ -341,7 +371,7 @@ __global__ __launch_bounds__(256, 1) void fb_fused_kernel(const FArgs g) {
   constexpr int NDMA = SLOT / 1024 / 4;               // 1-KB LDS-DMA instructions per wave and phase
   constexpr int L = 2 * RS;                           // identity loads = out stores per wave and chunk
   constexpr int TR = 64 * RS;                         // rows of a tile
-  static_assert(NDMA >= 1 && 4 * NDMA + 2 * L <= 63, "vmcnt range");
+  static_assert(NDMA >= 1 && 4 * NDMA + 2 * L <= 63 && 2 * NDMA + 4 * L <= 63, "vmcnt range");
   __shared__ __attribute__((aligned(16))) unsigned char ring[4 * SLOT];
   __shared__ __attribute__((aligned(16))) float par[4][C];          // s3 2^-(ew3 + e3), t3, sd, td
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, gq = lane >> 4, ln = lane & 15;
@@ -427,32 +457,76 @@ __global__ __launch_bounds__(256, 1) void fb_fused_kernel(const FArgs g) {
   const float is1 = ldexpf(1.f, g.e1);
 
   // one chunk; `id` holds this chunk's identity rows and receives chunk cc + 2's.
-  // vector-memory operations of a chunk in issue order: D1(cc + 1) x NDMA, ST x L, LD(cc + 2) x L, D3(cc + 2) x NDMA
+  // vector-memory operations of a chunk in issue order: D1(cc + 1) x NDMA, D3(cc + 2) x NDMA, ST x L, LD(cc + 2) x L
+  // Fragment reads run one batch (GB groups of two 16-B fragments) ahead of the MFMAs that use them: with one wave per
+  // SIMD nothing else hides an LDS round trip (measured: 6 200 cycles per chunk for 1 536 of MFMAs with hipcc's
+  // read - wait - 3 MFMAs order).
+  constexpr int GB = 4;
+  typedef const __attribute__((address_space(3))) unsigned char* lds_bytes;
+  const lds_bytes ring3 = (lds_bytes)ring;
   auto chunk = [&](int cc, f32x4 (&id)[RS][2]) {
     const int sA = (2 * cc) & 3, sB = (2 * cc + 1) & 3;
-    // ---- phase A: needs D3(cc), the last group of chunk cc - 2; younger than it: all of chunk cc - 1
-    fb_wait_vmcnt<2 * NDMA + 2 * L>();
+    // ---- phase A: needs D3(cc), second group of chunk cc - 2; younger: ST, LD of chunk cc - 2 and all of chunk cc - 1
+    if (g.dbg) fb_wait_vmcnt<0>(); else fb_wait_vmcnt<2 * NDMA + 4 * L>();
     __syncthreads();                  // every wave's share of W3[cc] is in LDS; every wave is through with phase B(cc - 1)
-    dma(w1img, cc + 1 < NCH ? cc + 1 : NCH - 1, (2 * cc + 3) & 3);
+    if (!(g.dbg & 1)) dma(w1img, cc + 1 < NCH ? cc + 1 : NCH - 1, (2 * cc + 3) & 3);
     f32x4 d[RS][2];
 #pragma unroll
     for (int s = 0; s < RS; ++s) { d[s][0] = f32x4{0.f, 0.f, 0.f, 0.f}; d[s][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    const unsigned char* wa = ring + sA * SLOT + lane * 16;
+    {
+      // one base per phase, opaque to the compiler: the fragments at immediate offsets (it folded the slot into a constant
+      // and computed an address per read otherwise)
+      unsigned wa_off = (unsigned)(sA * SLOT + lane * 16);
+      asm volatile("" : "+v"(wa_off));
+      const lds_bytes wa = ring3 + wa_off;
+      constexpr int GA = KS * 2, NBAT = (GA + GB - 1) / GB;          // group = (ks, blk): fragments (group * 2 + plane) KB into the slot
+      h8 f[2][GB][2];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
+      for (int q = 0; q < GB; ++q)
+        if (q < GA) { f[0][q][0] = *(const __attribute__((address_space(3))) h8*)(wa + (q * 2) * 1024); f[0][q][1] = *(const __attribute__((address_space(3))) h8*)(wa + (q * 2 + 1) * 1024); }
 #pragma unroll
-      for (int blk = 0; blk < 2; ++blk) {
-        const h8 wh = *reinterpret_cast<const h8*>(wa + ((ks * 2 + blk) * 2 + 0) * 1024);
-        const h8 wl = *reinterpret_cast<const h8*>(wa + ((ks * 2 + blk) * 2 + 1) * 1024);
+      for (int b = 0; b < NBAT; ++b) {
+        if (b + 1 < NBAT) {
 #pragma unroll
-        for (int s = 0; s < RS; ++s) {
-          d[s][blk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, ah[s][ks], d[s][blk], 0, 0, 0);
-          d[s][blk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, al[s][ks], d[s][blk], 0, 0, 0);
-          d[s][blk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, ah[s][ks], d[s][blk], 0, 0, 0);
+          for (int q = 0; q < GB; ++q) {
+            const int grp = (b + 1) * GB + q;
+            if (grp < GA) {
+              f[(b + 1) & 1][q][0] = *(const __attribute__((address_space(3))) h8*)(wa + (grp * 2) * 1024);
+              f[(b + 1) & 1][q][1] = *(const __attribute__((address_space(3))) h8*)(wa + (grp * 2 + 1) * 1024);
+            }
+          }
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < GB; ++q) {
+          const int grp = b * GB + q, ks = grp >> 1, blk = grp & 1;
+          if (grp < GA) {
+#pragma unroll
+            for (int s = 0; s < RS; ++s) {
+              d[s][blk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f[b & 1][q][1], ah[s][ks], d[s][blk], 0, 0, 0);
+              d[s][blk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f[b & 1][q][0], al[s][ks], d[s][blk], 0, 0, 0);
+              d[s][blk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f[b & 1][q][0], ah[s][ks], d[s][blk], 0, 0, 0);
+            }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
-    // ---- the tail: needs LD(cc) (third group of chunk cc - 2); younger: D3(cc), chunk cc - 1, D1(cc + 1)
-    fb_wait_vmcnt<4 * NDMA + 2 * L>();
+    }
+    // ---- phase B's barrier, its DMA and its first fragments BEFORE the tail, whose VALU work then covers their round trip.
+    // Needs D1(cc) (first group of chunk cc - 1); younger: D3, ST, LD of chunk cc - 1 and D1(cc + 1)
+    if (g.dbg) fb_wait_vmcnt<0>(); else fb_wait_vmcnt<2 * NDMA + 2 * L>();
+    __syncthreads();                  // W1[cc] is in LDS; every wave is through with phase A(cc)
+    if (!(g.dbg & 1)) dma(w3img, cc + 2 < NCH ? cc + 2 : NCH - 1, (2 * cc + 4) & 3);
+    unsigned wb_off = (unsigned)(sB * SLOT + lane * 16);
+    asm volatile("" : "+v"(wb_off));
+    const lds_bytes wb = ring3 + wb_off;
+    constexpr int NBATB = (NB + GB - 1) / GB;                       // group = nb
+    h8 fb[2][GB][2];
+#pragma unroll
+    for (int q = 0; q < GB; ++q) { fb[0][q][0] = *(const __attribute__((address_space(3))) h8*)(wb + (q * 2) * 1024); fb[0][q][1] = *(const __attribute__((address_space(3))) h8*)(wb + (q * 2 + 1) * 1024); }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- the tail: needs LD(cc) (last group of chunk cc - 2); younger: chunk cc - 1, D1(cc + 1), D3(cc + 2)
+    if (g.dbg) fb_wait_vmcnt<0>(); else fb_wait_vmcnt<4 * NDMA + 2 * L>();
     if constexpr (RS == 2) CAPNET_LANDED4(id[0][0], id[0][1], id[1][0], id[1][1]);
     else CAPNET_LANDED2(id[0][0], id[0][1]);
     h8 oh[RS], ol[RS];
@@ -474,28 +548,40 @@ __global__ __launch_bounds__(256, 1) void fb_fused_kernel(const FArgs g) {
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = fmaxf(fmaf(d[s][blk][e], sv[e], tv[e]) + r[e], 0.f);
-        *reinterpret_cast<f32x4*>(g.out + (long)row * C + ch) = o;
+        if (!(g.dbg & 2)) *reinterpret_cast<f32x4*>(g.out + (long)row * C + ch) = o;
         fb_split4(o * is1, hh[blk], ll[blk]);
       }
       oh[s] = fb_cat(hh[0], hh[1]);
       ol[s] = fb_cat(ll[0], ll[1]);
     }
-    fetch_id(cc + 2 < NCH ? cc + 2 : NCH - 1, id);
-    // ---- phase B: needs D1(cc) (first group of chunk cc - 1); younger: ST, LD, D3 of chunk cc - 1, D1, ST, LD of this chunk
-    fb_wait_vmcnt<2 * NDMA + 4 * L>();
-    __syncthreads();                  // W1[cc] is in LDS; every wave is through with phase A(cc)
-    dma(w3img, cc + 2 < NCH ? cc + 2 : NCH - 1, (2 * cc + 4) & 3);
-    const unsigned char* wb = ring + sB * SLOT + lane * 16;
+    if (!(g.dbg & 2)) fetch_id(cc + 2 < NCH ? cc + 2 : NCH - 1, id);
+    // ---- phase B
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-      const h8 wh = *reinterpret_cast<const h8*>(wb + (nb * 2 + 0) * 1024);
-      const h8 wl = *reinterpret_cast<const h8*>(wb + (nb * 2 + 1) * 1024);
+    for (int b = 0; b < NBATB; ++b) {
+      if (b + 1 < NBATB) {
 #pragma unroll
-      for (int s = 0; s < RS; ++s) {
-        acc[s][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ol[s], wh, acc[s][nb], 0, 0, 0);
-        acc[s][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(oh[s], wl, acc[s][nb], 0, 0, 0);
-        acc[s][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(oh[s], wh, acc[s][nb], 0, 0, 0);
+        for (int q = 0; q < GB; ++q) {
+          const int nb = (b + 1) * GB + q;
+          if (nb < NB) {
+            fb[(b + 1) & 1][q][0] = *(const __attribute__((address_space(3))) h8*)(wb + (nb * 2) * 1024);
+            fb[(b + 1) & 1][q][1] = *(const __attribute__((address_space(3))) h8*)(wb + (nb * 2 + 1) * 1024);
+          }
+        }
       }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < GB; ++q) {
+        const int nb = b * GB + q;
+        if (nb < NB) {
+#pragma unroll
+          for (int s = 0; s < RS; ++s) {
+            acc[s][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ol[s], fb[b & 1][q][0], acc[s][nb], 0, 0, 0);
+            acc[s][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(oh[s], fb[b & 1][q][1], acc[s][nb], 0, 0, 0);
+            acc[s][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(oh[s], fb[b & 1][q][0], acc[s][nb], 0, 0, 0);
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
   static_assert(NCH % 2 == 0, "chunks come in pairs (two named register sets)");
@@ -574,10 +660,10 @@ int fused_block_pack(const float* w, unsigned* img, int C, int MID, int role, hi
 
 int fused_block_gram_slices(long M) { return cdiv(M, kGR); }
 int fused_block_gram_pairs(int K) { const int nb = K / 64; return nb * (nb + 1) / 2; }
-// floats of the statistics workspace: partial blocks + column sums (fp32), then G and mu (double), 16-B aligned parts
+// floats of the statistics workspace: partial blocks + column sums, then G and mu (fp32), 16-B aligned parts
 size_t fused_block_stats_floats(long M, int K) {
   const size_t s = fused_block_gram_slices(M), p = fused_block_gram_pairs(K);
-  return s * p * 4096 + ((s * K + 3) / 4 * 4) + 2 * ((size_t)K * K + K) + 8;
+  return s * p * 4096 + ((s * K + 3) / 4 * 4) + ((size_t)K * K + K) + 8;
 }
 
 // (scale, shift) of the BatchNorm behind y3 = relu(y2 s2 + t2) . W3^T (conv3 of a bottleneck), y3 never formed.
@@ -593,22 +679,34 @@ int fused_block_stats(const float* y2, const float* s2, const float* t2, const u
   a.slices = fused_block_gram_slices(M); a.pairs = fused_block_gram_pairs(K);
   a.gp = work;
   a.cs = work + (size_t)a.slices * a.pairs * 4096;
-  double* G = reinterpret_cast<double*>(a.cs + ((size_t)a.slices * K + 3) / 4 * 4);
-  double* mu = G + (size_t)K * K;
+  float* G = a.cs + ((size_t)a.slices * K + 3) / 4 * 4;
+  float* mu = G + (size_t)K * K;
   hipLaunchKernelGGL(fb_gram_kernel, dim3(a.slices * a.pairs), dim3(256), 0, stream, a);
   hipLaunchKernelGGL(fb_gram_reduce_kernel, dim3(cdiv((long)K * K + K, 32)), dim3(256), 0, stream, a.gp, a.cs, G, mu, K, a.slices, a.pairs);
   const double inv = 1.0 / (double)M, unbias = M > 1 ? (double)M / (double)(M - 1) : 1.0;
   const float* wcopy = reinterpret_cast<const float*>(w3img + kFHdr + (size_t)C * MID);
-  hipLaunchKernelGGL(fb_quad_kernel, dim3(cdiv(C, kQC)), dim3(256), 0, stream, G, mu, wcopy, K, C, inv, unbias, gamma, beta,
-                     running_mean, running_var, momentum, eps, scale, shift, batch_mean, batch_var, err);
+  if (K == 256)
+    hipLaunchKernelGGL(fb_quad_kernel<256>, dim3(cdiv(C, kQC)), dim3(K * 4), 0, stream, G, mu, wcopy, C, inv, unbias, gamma, beta,
+                       running_mean, running_var, momentum, eps, scale, shift, batch_mean, batch_var, err);
+  else if (K == 128)
+    hipLaunchKernelGGL(fb_quad_kernel<128>, dim3(cdiv(C, kQC)), dim3(K * 4), 0, stream, G, mu, wcopy, C, inv, unbias, gamma, beta,
+                       running_mean, running_var, momentum, eps, scale, shift, batch_mean, batch_var, err);
+  else
+    hipLaunchKernelGGL(fb_quad_kernel<64>, dim3(cdiv(C, kQC)), dim3(K * 4), 0, stream, G, mu, wcopy, C, inv, unbias, gamma, beta,
+                       running_mean, running_var, momentum, eps, scale, shift, batch_mean, batch_var, err);
   CAPNET_LAUNCH_CHECK();
   return kOk;
 }
 
-int fused_block_tiles(long M, int MID) {
+// 16-row strips per wave (a tile is 64 RS rows). One wave per SIMD issues its non-MFMA instructions in the shadow of its own
+// MFMAs only: with 32 rows per wave there are two MFMAs per fragment read and half the scalar / barrier overhead per row.
+static int fb_rs(int MID) {
+  const char* e = getenv("CAPNET_FB_RS");
+  if (e && (e[0] == '1' || e[0] == '2')) return e[0] - '0';
   (void)MID;
-  return cdiv(M, 64);
+  return 2;
 }
+int fused_block_tiles(long M, int MID) { return cdiv(M, 64 * fb_rs(MID)); }
 
 // out [M][4 MID] = relu(bn3(relu(y2 s2 + t2) . W3^T) + res (sd + td)) and y1 [M][MID] = out . W1^T, statistics partials
 // [fused_block_tiles][MID]; part_sum / part_sq null: none (inference), outputs checked for non-finite values instead.
@@ -623,10 +721,17 @@ int fused_block_forward(const float* y2, const float* s2, const float* t2, const
   FArgs a;
   a.y2 = y2; a.s2 = s2; a.t2 = t2; a.w3 = w3img; a.w1 = w1img; a.s3 = s3; a.t3 = t3; a.res = res; a.sd = sd; a.td = td;
   a.out = out; a.y1 = y1; a.part_sum = part_sum; a.part_sq = part_sq; a.M = (int)M; a.e3 = e3; a.e1 = e1; a.err = err;
+  { const char* e = getenv("CAPNET_FB_DBG"); a.dbg = e ? atoi(e) : 0; }
   const dim3 grid(fused_block_tiles(M, MID)), block(256);
-  if (MID == 256) CAPNET_LAUNCH_TIMED((fb_fused_kernel<256, 1>), grid, block, stream, a);
-  else if (MID == 128) CAPNET_LAUNCH_TIMED((fb_fused_kernel<128, 1>), grid, block, stream, a);
-  else CAPNET_LAUNCH_TIMED((fb_fused_kernel<64, 1>), grid, block, stream, a);
+  if (fb_rs(MID) == 2) {
+    if (MID == 256) CAPNET_LAUNCH_TIMED((fb_fused_kernel<256, 2>), grid, block, stream, a);
+    else if (MID == 128) CAPNET_LAUNCH_TIMED((fb_fused_kernel<128, 2>), grid, block, stream, a);
+    else CAPNET_LAUNCH_TIMED((fb_fused_kernel<64, 2>), grid, block, stream, a);
+  } else {
+    if (MID == 256) CAPNET_LAUNCH_TIMED((fb_fused_kernel<256, 1>), grid, block, stream, a);
+    else if (MID == 128) CAPNET_LAUNCH_TIMED((fb_fused_kernel<128, 1>), grid, block, stream, a);
+    else CAPNET_LAUNCH_TIMED((fb_fused_kernel<64, 1>), grid, block, stream, a);
+  }
   CAPNET_LAUNCH_CHECK();
   return kOk;
 }

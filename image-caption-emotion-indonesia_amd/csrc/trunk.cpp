@@ -34,13 +34,16 @@ struct TrunkConv {
   bool h3;     // Cin % 64 == 0, 1x1 or 3x3: three f16 MFMA products of 2-way split operands (conv_f16x3.hip and its siblings)
   int tile_n;  // tile width the split-f16 weight image was laid out for
   bool stem_h3 = false;   // the 7x7 / 2 stem on the same arithmetic, NCHW image in (conv_stem.hip)
+  // fused_block.hip: conv3 of a block whose statistics come from the Gram matrix of its input and whose product is formed
+  // inside the next block's conv1 launch (fused3), and that conv1 (fused1). Their weight images are fused_block_pack's.
+  bool fused3 = false, fused1 = false;
 };
 
 struct Trunk {
   int B, H, W;
   std::vector<TrunkConv> convs;  // torchvision parameter order
   // workspace layout (float offsets)
-  size_t off_x[2], off_y1, off_y2, off_y3, off_d, off_part, off_slab, off_ss, total_floats;
+  size_t off_x[2], off_y1, off_y2, off_y3, off_d, off_part, off_slab, off_gram, off_ss, total_floats;
   std::vector<size_t> ss_off;  // per conv: offset of [scale | shift] (2*Cout floats)
   std::vector<size_t> bs_off;  // per conv: offset of [batch mean | unbiased batch var] (2*Cout floats)
   int final_side;
@@ -57,6 +60,9 @@ struct Trunk {
   // CAPNET_AREG=1 conv3 of stages 1-3 on the A-in-registers kernel (conv1x1_areg.hip) instead of the tiled one: built for
   // VERDICT r2 #4, measured slower in the pipelined step, kept as an option
   bool use_patch = true, fuse_tails = true, use_areg = false;
+  // CAPNET_NO_FUSED_BLOCK=1: conv3 materialises y3 everywhere (round 3's data flow); CAPNET_FUSED_STAGES=<mask> (bit L =
+  // stage L + 1) picks the stages whose inner block boundaries run on fused_block.hip (default: see trunk_create)
+  int fused_stages = 0;
   bool timing = false;
   int timing_every = 1;   // ... on every N-th pass (an event pair is a bubble in the stream: 310 per pass cost 2.5 % images/s)
   long pass_no = 0;
@@ -135,7 +141,11 @@ int trunk_create(int B, int H, int W, Trunk** out) {
   int inplanes = 64;
   const int blocks[4] = {3, 8, 36, 3};
   const int planes[4] = {64, 128, 256, 512};
-  size_t max_x = (size_t)h * w * 64, max_y1 = 0, max_y2 = 0, max_y3 = 0, max_d = 0;
+  {
+    const char* fs = getenv("CAPNET_FUSED_STAGES");
+    t->fused_stages = (!use_h3 || !t->fuse_tails || !no_folded || env_on("CAPNET_NO_FUSED_BLOCK")) ? 0 : (fs ? atoi(fs) & 7 : 7);
+  }
+  size_t max_x = (size_t)h * w * 64, max_y1 = 0, max_y2 = 0, max_y3 = 0, max_d = 0, max_gram = 0, max_fpart = 0;
   for (int L = 0; L < 4; ++L) {
     for (int b = 0; b < blocks[L]; ++b) {
       const int stride = (b == 0 && L > 0) ? 2 : 1;
@@ -143,6 +153,17 @@ int trunk_create(int B, int H, int W, Trunk** out) {
       TrunkConv c1 = add(inplanes, p, 1, 1, 0, h, w, true, !(L == 0 && b == 0));
       TrunkConv c2 = add(p, p, 3, stride, 1, h, w);
       TrunkConv c3 = add(p, p * 4, 1, 1, 0, c2.OH, c2.OW);
+      // the boundary (b - 1 -> b) inside a stage: the previous block's conv3 (three or four entries back) and this conv1
+      if (b > 0 && L < 3 && ((t->fused_stages >> L) & 1) && c1.h3 && fused_block_shape_ok((long)B * h * w, p)) {
+        const size_t i1 = t->convs.size() - 3, i3p = i1 - (b == 1 ? 2 : 1);
+        if (t->convs[i3p].h3 && t->convs[i3p].k == 1 && t->convs[i3p].Cout == inplanes && t->convs[i3p].Cin == p) {
+          t->convs[i1].fused1 = true;
+          t->convs[i3p].fused3 = true;
+          t->convs[i1].tile_n = 0;
+          max_gram = std::max(max_gram, fused_block_stats_floats((long)B * h * w, p));
+          max_fpart = std::max(max_fpart, (size_t)fused_block_tiles((long)B * h * w, p) * p);
+        }
+      }
       max_y1 = std::max(max_y1, (size_t)c1.OH * c1.OW * c1.Cout);
       max_y2 = std::max(max_y2, (size_t)c2.OH * c2.OW * c2.Cout);
       max_y3 = std::max(max_y3, (size_t)c3.OH * c3.OW * c3.Cout);
@@ -175,11 +196,13 @@ int trunk_create(int B, int H, int W, Trunk** out) {
     if (c.h3) max_part = std::max(max_part, (size_t)conv1x1_tiles_m(M) * c.Cout);
     if (c.stem_h3) max_part = std::max(max_part, (size_t)conv_stem_f16x3_part_rows(B, c.H, c.W) * c.Cout);
   }
+  max_part = std::max(max_part, max_fpart);
   t->off_part = take(2 * max_part);
   size_t max_slab = 0;
   for (auto& c : t->convs)
     if (c.kmajor) max_slab = std::max(max_slab, conv_v2_slab_floats(B * c.OH * c.OW, c.Cout, c.Kw, 0));
   t->off_slab = take(max_slab + 64);
+  t->off_gram = take(max_gram + 64);
   t->off_ss = off;
   for (auto& c : t->convs) t->ss_off.push_back(take(2 * (size_t)c.Cout));
   for (auto& c : t->convs) t->bs_off.push_back(take(2 * (size_t)c.Cout));
@@ -257,7 +280,7 @@ int trunk_conv_shape(const Trunk* t, int i, int* cout, int* cin, int* k, int* st
 
 int trunk_conv_kmajor(const Trunk* t, int i) {
   if (i < 0 || i >= (int)t->convs.size()) return 0;
-  return t->convs[i].stem_h3 ? 6 : t->convs[i].h3 ? 5 : (t->convs[i].kmajor ? 1 : 0);
+  return t->convs[i].fused3 ? 7 : t->convs[i].fused1 ? 8 : t->convs[i].stem_h3 ? 6 : t->convs[i].h3 ? 5 : (t->convs[i].kmajor ? 1 : 0);
 }
 
 int trunk_conv_tile_n(const Trunk* t, int i) {
@@ -437,12 +460,73 @@ int conv_bn(const Ctx& c, int i, const float* x, long sxb, long sxh, long sxw, l
   return bn_eval_scale_shift(c.gamma[i], c.beta[i], c.rmean[i], c.rvar[i], c.eps, d.Cout,
                              c.scale(i), c.shift(i), c.s);
 }
+// ---- a block boundary on fused_block.hip --------------------------------------------------------------------------
+// conv3 (i3) of block b is never launched: its BatchNorm's (scale, shift) come from the Gram matrix of its input y2 ...
+int fused_stats_bn(const Ctx& c, int i3, const float* y2, const float* s2, const float* t2) {
+  const TrunkConv& d = c.t->convs[i3];
+  const long M = (long)c.t->B * d.OH * d.OW;
+  if (!c.train) return kOk;          // inference: every (scale, shift) is already there (eval_ready)
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (c.t->timing_now) {
+    const int rt = timing_begin(c.t, false, c.s, &e0, &e1);
+    if (rt) return rt;
+  }
+  const bool defer = c.train == 2;
+  const int rc = fused_block_stats(y2, s2, t2, reinterpret_cast<const unsigned*>(c.w[i3]), M, d.Cin, c.in_exp(i3), c.gamma[i3],
+                                   c.beta[i3], defer ? nullptr : c.rmean[i3], defer ? nullptr : c.rvar[i3], c.momentum, c.eps,
+                                   c.scale(i3), c.shift(i3), defer ? c.bmean(i3) : nullptr, defer ? c.bvar(i3) : nullptr,
+                                   c.ws + c.t->off_gram, c.err, c.s);
+  if (rc) return rc;
+  // (the statistics' launches are conv time without algorithmic flops: the product itself is timed with the fused launch)
+  if (c.t->timing_now) return timing_end(c.t, false, c.s, e0, e1, 0.0);
+  return kOk;
+}
+// ... and its product, the block's tail and conv1 (i1) of block b + 1 are ONE launch
+struct FusedTail {
+  int i3;
+  const float* y2; const float* s2; const float* t2;
+  const float* res; const float* sd; const float* td;
+  float* out;
+};
+int fused_conv1_bn(const Ctx& c, int i1, const FusedTail& f, float* y1) {
+  const TrunkConv& d = c.t->convs[i1];
+  const TrunkConv& d3 = c.t->convs[f.i3];
+  const long M = (long)c.t->B * d.OH * d.OW;
+  const int prows = fused_block_tiles(M, d.Cout);
+  float* psum = c.ws + c.t->off_part;
+  float* psq = psum + (size_t)prows * d.Cout;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (c.t->timing_now) {
+    const int rt = timing_begin(c.t, true, c.s, &e0, &e1);
+    if (rt) return rt;
+  }
+  const int rc = fused_block_forward(f.y2, f.s2, f.t2, reinterpret_cast<const unsigned*>(c.w[f.i3]), c.scale(f.i3), c.shift(f.i3),
+                                     f.res, f.sd, f.td, f.out, reinterpret_cast<const unsigned*>(c.w[i1]), y1,
+                                     c.train ? psum : nullptr, c.train ? psq : nullptr, M, d.Cout, c.in_exp(f.i3), c.in_exp(i1),
+                                     c.err, c.s);
+  if (c.t->timing_now) {
+    if (rc) launch_events() = LaunchEvents{};
+    else {
+      const int rt = timing_end(c.t, true, c.s, e0, e1, 2.0 * (double)M * d.Cout * d.Cin + 2.0 * (double)M * d3.Cout * d3.Cin);
+      if (rt) return rt;
+    }
+  }
+  if (rc) return rc;
+  if (c.train == 2)
+    return bn_finalize(psum, psq, prows, d.Cout, M, c.gamma[i1], c.beta[i1], nullptr, nullptr, c.momentum, c.eps, c.scale(i1),
+                       c.shift(i1), c.s, c.bmean(i1), c.bvar(i1), c.err);
+  if (c.train)
+    return bn_finalize(psum, psq, prows, d.Cout, M, c.gamma[i1], c.beta[i1], c.rmean[i1], c.rvar[i1], c.momentum, c.eps,
+                       c.scale(i1), c.shift(i1), c.s, nullptr, nullptr, c.err);
+  return kOk;
+}
+
 // conv i with the BatchNorm that follows it folded into the epilogue (inference)
 int conv_folded(const Ctx& c, int i, const float* x, const float* res, int relu, float* y) {
   const TrunkConv& d = c.t->convs[i];
   const long M = (long)c.t->B * d.OH * d.OW;
   const long sw = d.Cin, sh = (long)d.W * d.Cin, sb = (long)d.H * d.W * d.Cin;
-  CAPNET_REQUIRE(d.tile_n != 256, "trunk: conv %d was planned for the wide tail kernel; CAPNET_EVAL_FOLDED=1 must be set before the plan is made", i);
+  CAPNET_REQUIRE(d.tile_n != 256 && !d.fused3 && !d.fused1, "trunk: conv %d was planned for the wide tail kernel or for fused_block.hip; CAPNET_EVAL_FOLDED=1 must be set before the plan is made", i);
   CAPNET_REQUIRE(d.h3 || (d.kmajor && conv_v2_eligible(x, sb, sh, sw, 1, c.t->B, d.Cin, d.Cout, nullptr, nullptr)),
                  "trunk: conv %d is not eligible for the folded-BN kernel", i);
   hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -617,7 +701,8 @@ int trunk_forward(Trunk* t, const float* images_nchw, const float* const* w_pack
   }
   int cur = 0;
   BlockTail tail{};
-  bool have_tail = false;
+  FusedTail ftail{};
+  bool have_tail = false, have_ftail = false;
   const int blocks[4] = {3, 8, 36, 3};
   for (int L = 0; L < 4; ++L) {
     for (int b = 0; b < blocks[L]; ++b) {
@@ -634,16 +719,42 @@ int trunk_forward(Trunk* t, const float* images_nchw, const float* const* w_pack
       };
       long sb, sh, sw;
       nhwc(c1, &sb, &sh, &sw);
-      rc = conv_bn(c, i1, x, sb, sh, sw, 1, nullptr, nullptr, 0, Y1, have_tail ? &tail : nullptr);
+      if (have_ftail) {
+        // the previous block's conv3 product, its tail (-> x = X[cur]) and this conv1: one launch (fused_block.hip)
+        CAPNET_REQUIRE(c1.fused1 && (c.train || c.eval_ready), "trunk: conv %d is not the fused boundary the plan made", i1);
+        rc = fused_conv1_bn(c, i1, ftail, Y1);
+        have_ftail = false;
+      } else {
+        CAPNET_REQUIRE(!c1.fused1, "trunk: conv %d was planned for fused_block.hip", i1);
+        rc = conv_bn(c, i1, x, sb, sh, sw, 1, nullptr, nullptr, 0, Y1, have_tail ? &tail : nullptr);
+      }
       have_tail = false;
       if (rc) return rc;
       nhwc(c2, &sb, &sh, &sw);
       rc = conv_bn(c, i2, Y1, sb, sh, sw, 1, c.scale(i1), c.shift(i1), 1, Y2);
       if (rc) return rc;
+      const long rows = (long)B * c3.OH * c3.OW;
+      if (c3.fused3 && (c.train || c.eval_ready)) {
+        // y3 is never formed: statistics from y2's second moments now, the product inside the next block's conv1 launch
+        rc = fused_stats_bn(c, i3, Y2, c.scale(i2), c.shift(i2));
+        if (rc) return rc;
+        if (id >= 0) {
+          const TrunkConv& cd = t->convs[id];
+          nhwc(cd, &sb, &sh, &sw);
+          rc = conv_bn(c, id, x, sb, sh, sw, 1, nullptr, nullptr, 0, D);
+          if (rc) return rc;
+          ftail = FusedTail{i3, Y2, c.scale(i2), c.shift(i2), D, c.scale(id), c.shift(id), out};
+        } else {
+          ftail = FusedTail{i3, Y2, c.scale(i2), c.shift(i2), x, nullptr, nullptr, out};
+        }
+        have_ftail = true;
+        cur ^= 1;
+        continue;
+      }
+      CAPNET_REQUIRE(!c3.fused3, "trunk: conv %d was planned for fused_block.hip (the folded inference trunk must be chosen before the plan is made)", i3);
       nhwc(c3, &sb, &sh, &sw);
       rc = conv_bn(c, i3, Y2, sb, sh, sw, 1, c.scale(i2), c.shift(i2), 1, Y3);
       if (rc) return rc;
-      const long rows = (long)B * c3.OH * c3.OW;
       if (id >= 0) {
         const TrunkConv& cd = t->convs[id];
         nhwc(cd, &sb, &sh, &sw);

@@ -184,9 +184,11 @@ class _TrunkRunner:
                 if tuple(c.weight.shape) != (cout, cin, k, k) or c.stride != stride:
                     raise CapnetError("conv %d: module shape %s does not match the plan" %
                                       (i, tuple(c.weight.shape)))
-                # 0 rows, 1 K-major (the f32-MFMA kernels), 5 split f16, 6 the stem's split f16
+                # 0 rows, 1 K-major (the f32-MFMA kernels), 5 split f16, 6 the stem's split f16, 7 / 8 fused_block.hip
                 kind = L.capnet_trunk_conv_kmajor(plan["handle"], i)
-                if kind == 6:
+                if kind in (7, 8):    # a block boundary on fused_block.hip: 7 = its conv3, 8 = the next block's conv1
+                    packed.append(ops.pack_fused_block_weight(c.weight.detach(), kind - 7))
+                elif kind == 6:
                     packed.append(ops.pack_conv_weight_stem_f16x3(c.weight.detach()))
                 elif kind == 5:
                     packed.append(ops.pack_conv_weight_f16x3(c.weight.detach(), L.capnet_trunk_conv_tile_n(plan["handle"], i)))

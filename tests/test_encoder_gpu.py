@@ -168,7 +168,8 @@ def _trunk_run(dev, monkeypatch, st, imgs, env):
     """A fresh encoder planned under the given environment switches (read by capnet_trunk_create): plan kinds,
     train-mode pooled features, one running mean afterwards, inference features."""
     L = capnet._lib.lib()
-    for k in ("CAPNET_NO_H3", "CAPNET_NO_STEM_H3", "CAPNET_NO_P3", "CAPNET_NO_TAIL_FUSION", "CAPNET_AREG", "CAPNET_NO_WIDE_TAIL", "CAPNET_WIDE_P3"):
+    for k in ("CAPNET_NO_H3", "CAPNET_NO_STEM_H3", "CAPNET_NO_P3", "CAPNET_NO_TAIL_FUSION", "CAPNET_AREG", "CAPNET_NO_WIDE_TAIL", "CAPNET_WIDE_P3",
+              "CAPNET_NO_FUSED_BLOCK"):
         monkeypatch.delenv(k, raising=False)
     for k in env:
         monkeypatch.setenv(k, "1")
@@ -185,7 +186,15 @@ def _trunk_run(dev, monkeypatch, st, imgs, env):
     return kinds, pooled, rm, ev
 
 
-@pytest.mark.parametrize("switch", ["CAPNET_NO_H3", "CAPNET_NO_STEM_H3", "CAPNET_NO_P3", "CAPNET_NO_TAIL_FUSION", "CAPNET_AREG", "CAPNET_NO_WIDE_TAIL", "CAPNET_WIDE_P3"])
+SPLIT = (5, 7, 8)      # plan kinds on the split-f16 arithmetic: 5 conv_f16x3 / patch / tail kernels, 7 / 8 a block boundary on fused_block.hip
+
+
+def _n_split(kinds):
+    return sum(kinds.count(k) for k in SPLIT)
+
+
+@pytest.mark.parametrize("switch", ["CAPNET_NO_H3", "CAPNET_NO_STEM_H3", "CAPNET_NO_P3", "CAPNET_NO_TAIL_FUSION", "CAPNET_AREG", "CAPNET_NO_WIDE_TAIL", "CAPNET_WIDE_P3",
+                                    "CAPNET_NO_FUSED_BLOCK"])
 def test_every_trunk_switch_is_a_working_configuration(dev, monkeypatch, switch):
     """Each environment switch the library still reads selects other kernels for part of the trunk (the f32-MFMA
     family for everything / for the stem, the implicit-GEMM kernel for the stride-1 3x3 convolutions, stand-alone
@@ -199,15 +208,17 @@ def test_every_trunk_switch_is_a_working_configuration(dev, monkeypatch, switch)
     k0, p0, rm0, e0 = _trunk_run(dev, monkeypatch, st, imgs, [])
     wide0 = _trunk_run.wide
     k1, p1, rm1, e1 = _trunk_run(dev, monkeypatch, st, imgs, [switch])
-    assert k0.count(5) == 154 and k0[0] == 6
+    assert _n_split(k0) == 154 and k0[0] == 6 and k0.count(7) == k0.count(8) == 2 + 7 + 35    # the inner boundaries of stages 1-3
+    if switch in ("CAPNET_NO_FUSED_BLOCK", "CAPNET_NO_TAIL_FUSION"):
+        assert k1.count(7) == k1.count(8) == 0 and k1.count(5) == 154
     if switch == "CAPNET_NO_WIDE_TAIL":
-        assert wide0 >= 35 and _trunk_run.wide == 0
+        assert wide0 >= 1 and _trunk_run.wide == 0
     if switch == "CAPNET_WIDE_P3":
         assert _trunk_run.wide > wide0
     if switch == "CAPNET_NO_H3":
-        assert k1.count(5) == 0 and k1.count(6) == 0
+        assert _n_split(k1) == 0 and k1.count(6) == 0
     if switch == "CAPNET_NO_STEM_H3":
-        assert k1[0] in (0, 1) and k1.count(5) == 154
+        assert k1[0] in (0, 1) and _n_split(k1) == 154
     errs = rel_err(p1, p0), rel_err(rm1, rm0), rel_err(e1, e0)
     print("%s vs default trunk: train features %.2e, running mean %.2e, eval features %.2e" % ((switch,) + errs))
     assert errs[0] < TOL and errs[1] < 1e-4 and errs[2] < 2e-4
@@ -232,8 +243,8 @@ def test_split_f16_trunk_is_as_close_to_fp64_as_the_f32_trunk(dev, monkeypatch):
     k32, p32, _, _ = _trunk_run(dev, monkeypatch, st, imgs, ["CAPNET_NO_H3"])
     kh, ph, _, _ = _trunk_run(dev, monkeypatch, st, imgs, [])
     e32, eh = rel_err(p32, want), rel_err(ph, want)
-    print("train features vs fp64 at B=8: f32 MFMA %.2e, split f16 %.2e (layers on f16: %d of 155)" % (e32, eh, kh.count(5) + kh.count(6)))
-    assert k32.count(5) == 0 and kh.count(5) == 154
+    print("train features vs fp64 at B=8: f32 MFMA %.2e, split f16 %.2e (layers on f16: %d of 155)" % (e32, eh, _n_split(kh) + kh.count(6)))
+    assert _n_split(k32) == 0 and _n_split(kh) == 154
     assert eh < 1.5 * e32 + 1e-5
 
 
