@@ -23,6 +23,7 @@
 // phases ahead, one barrier per phase; the identity rows come two chunks ahead by hand-issued loads (counted vmcnt;
 // tools/isa_inflight_check.py checks the discipline on the shipped ISA).
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 #include "mfma_core.h"
@@ -364,14 +365,18 @@ struct FArgs {
 template <int N>
 __device__ __forceinline__ void fb_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int MID, int RS>
-__global__ __launch_bounds__(256, 1) void fb_fused_kernel(const FArgs g) {
+// NW waves of RS 16-row strips each. NW = 4: one wave per SIMD (up to 512 registers: RS = 2 fits); NW = 8: two waves per
+// SIMD at <= 256 registers -- a lone wave issues its own loads, waits and tail arithmetic BETWEEN its MFMAs (SQ counters,
+// 4 waves x 32 rows: matrix pipe busy 40 % of the wave's time, 40 % issue stalls, 24 % waits), a second wave fills those gaps.
+template <int MID, int RS, int NW>
+__global__ __launch_bounds__(64 * NW, NW / 4) void fb_fused_kernel(const FArgs g) {
   constexpr int C = 4 * MID, KS = MID / 32, NB = MID / 16, NCH = C / 32;
   constexpr int SLOT = MID * 128;                     // bytes of one chunk image (either role)
-  constexpr int NDMA = SLOT / 1024 / 4;               // 1-KB LDS-DMA instructions per wave and phase
+  constexpr int NDMA = SLOT / 1024 / NW;              // 1-KB LDS-DMA instructions per wave and phase
   constexpr int L = 2 * RS;                           // identity loads = out stores per wave and chunk
-  constexpr int TR = 64 * RS;                         // rows of a tile
-  static_assert(NDMA >= 1 && 4 * NDMA + 2 * L <= 63 && 2 * NDMA + 4 * L <= 63, "vmcnt range");
+  constexpr int TR = 16 * RS * NW;                    // rows of a tile
+  constexpr int NT = 64 * NW;                         // threads
+  static_assert(NDMA >= 1 && 4 * NDMA + 2 * L <= 63, "vmcnt range");
   __shared__ __attribute__((aligned(16))) unsigned char ring[4 * SLOT];
   __shared__ __attribute__((aligned(16))) float par[4][C];          // s3 2^-(ew3 + e3), t3, sd, td
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, gq = lane >> 4, ln = lane & 15;
@@ -383,7 +388,7 @@ __global__ __launch_bounds__(256, 1) void fb_fused_kernel(const FArgs g) {
   const float* const w1img = reinterpret_cast<const float*>(g.w1 + kFHdr);
 
   // LDS-DMA of chunk `cc` of an image into ring slot `slot`: wave w moves pieces [w NDMA, (w + 1) NDMA)
-  auto dma = [&](const float* img, int cc, int slot) {
+  auto dma = [&](const float* img, int cc, int slot) __attribute__((always_inline)) {
     const float* src = img + (long)cc * (SLOT / 4);
 #pragma unroll
     for (int q = 0; q < NDMA; ++q)
@@ -397,22 +402,21 @@ __global__ __launch_bounds__(256, 1) void fb_fused_kernel(const FArgs g) {
     idoff[s] = (unsigned)(((long)row * C + 4 * gq) * 4);
   }
   f32x4 idA[RS][2], idB[RS][2];
-  auto fetch_id = [&](int cc, f32x4 (&id)[RS][2]) {
+  auto fetch_id = [&](int cc, f32x4 (&id)[RS][2]) __attribute__((always_inline)) {
 #pragma unroll
     for (int s = 0; s < RS; ++s)
 #pragma unroll
       for (int blk = 0; blk < 2; ++blk) gload16(id[s][blk], g.res, idoff[s] + (unsigned)((32 * cc + 16 * blk) * 4));
   };
 
-  // ---- prologue: the first three phases' weights, the first two chunks' identity rows, the parameters, a2
+  // ---- prologue: the first two phases' weights, the first two chunks' identity rows, the parameters, a2
   dma(w3img, 0, 0);
   dma(w1img, 0, 1);
-  dma(w3img, NCH > 1 ? 1 : 0, 2);
   fetch_id(0, idA);
   fetch_id(NCH > 1 ? 1 : 0, idB);
   {
     const float x3 = ldexpf(1.f, -((int)g.w3[0] + g.e3));
-    for (int i = tid; i < C; i += 256) {
+    for (int i = tid; i < C; i += NT) {
       par[0][i] = g.s3[i] * x3;
       par[1][i] = g.t3[i];
       par[2][i] = fold_res ? g.sd[i] : 1.f;
@@ -456,76 +460,72 @@ __global__ __launch_bounds__(256, 1) void fb_fused_kernel(const FArgs g) {
     for (int nb = 0; nb < NB; ++nb) acc[s][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
   const float is1 = ldexpf(1.f, g.e1);
 
-  // one chunk; `id` holds this chunk's identity rows and receives chunk cc + 2's.
-  // vector-memory operations of a chunk in issue order: D1(cc + 1) x NDMA, D3(cc + 2) x NDMA, ST x L, LD(cc + 2) x L
-  // Fragment reads run one batch (GB groups of two 16-B fragments) ahead of the MFMAs that use them: with one wave per
-  // SIMD nothing else hides an LDS round trip (measured: 6 200 cycles per chunk for 1 536 of MFMAs with hipcc's
-  // read - wait - 3 MFMAs order).
-  constexpr int GB = 4;
+  // The loop runs over PHASES: phase 2 c = A(c) (the y3 chunk), phase 2 c + 1 = B(c) (tail + conv1 chunk); phase p reads ring
+  // slot p % 4. Iteration k: every wave has made sure its share of phase k's weights landed, barrier, every wave issues
+  // its share of phase k + 2's (into the slot of phase k - 2, free since this barrier), then waves 0-3 run phase k and --
+  // with eight waves -- waves 4-7 run phase k - 1: the two waves of a SIMD are ONE PHASE APART, so that one's tail
+  // arithmetic and waits lie beside the other's MFMAs instead of beside its tail (both in lockstep: 90 us on the 14 x 14
+  // maps, no better than a lone wave of 32 rows).
+  // Vector-memory operations of a wave, in issue order, per iteration: D x NDMA, and in an iteration that runs a B phase
+  // behind them ST x L, LD x L. The same stream for both groups, one iteration apart.
+  //   before barrier k: D(k), issued in iteration k - 2; younger than it: one A and one B iteration      -> NDMA + 2 L
+  //   the tail of B(c): LD(c), issued by B(c - 2), four iterations back; younger: D, D ST LD, D, D        -> 4 NDMA + 2 L
+  constexpr int GB = NW == 8 ? 2 : 4;
   typedef const __attribute__((address_space(3))) unsigned char* lds_bytes;
   const lds_bytes ring3 = (lds_bytes)ring;
-  auto chunk = [&](int cc, f32x4 (&id)[RS][2]) {
-    const int sA = (2 * cc) & 3, sB = (2 * cc + 1) & 3;
-    // ---- phase A: needs D3(cc), second group of chunk cc - 2; younger: ST, LD of chunk cc - 2 and all of chunk cc - 1
-    if (g.dbg) fb_wait_vmcnt<0>(); else fb_wait_vmcnt<2 * NDMA + 4 * L>();
-    __syncthreads();                  // every wave's share of W3[cc] is in LDS; every wave is through with phase B(cc - 1)
-    if (!(g.dbg & 1)) dma(w1img, cc + 1 < NCH ? cc + 1 : NCH - 1, (2 * cc + 3) & 3);
-    f32x4 d[RS][2];
+  f32x4 d[RS][2];
+  auto phase_a = [&](int cc) __attribute__((always_inline)) {
 #pragma unroll
     for (int s = 0; s < RS; ++s) { d[s][0] = f32x4{0.f, 0.f, 0.f, 0.f}; d[s][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    {
-      // one base per phase, opaque to the compiler: the fragments at immediate offsets (it folded the slot into a constant
-      // and computed an address per read otherwise)
-      unsigned wa_off = (unsigned)(sA * SLOT + lane * 16);
-      asm volatile("" : "+v"(wa_off));
-      const lds_bytes wa = ring3 + wa_off;
-      constexpr int GA = KS * 2, NBAT = (GA + GB - 1) / GB;          // group = (ks, blk): fragments (group * 2 + plane) KB into the slot
-      h8 f[2][GB][2];
+    // one base per phase, opaque to the compiler: the fragments at immediate offsets (it folded the slot into a constant
+    // and computed an address per read otherwise)
+    unsigned wa_off = (unsigned)(((2 * cc) & 3) * SLOT + lane * 16);
+    asm volatile("" : "+v"(wa_off));
+    const lds_bytes wa = ring3 + wa_off;
+    constexpr int GA = KS * 2, NBAT = (GA + GB - 1) / GB;          // group = (ks, blk): fragments (group * 2 + plane) KB into the slot
+    h8 f[2][GB][2];
 #pragma unroll
-      for (int q = 0; q < GB; ++q)
-        if (q < GA) { f[0][q][0] = *(const __attribute__((address_space(3))) h8*)(wa + (q * 2) * 1024); f[0][q][1] = *(const __attribute__((address_space(3))) h8*)(wa + (q * 2 + 1) * 1024); }
+    for (int q = 0; q < GB; ++q)
+      if (q < GA) { f[0][q][0] = *(const __attribute__((address_space(3))) h8*)(wa + (q * 2) * 1024); f[0][q][1] = *(const __attribute__((address_space(3))) h8*)(wa + (q * 2 + 1) * 1024); }
 #pragma unroll
-      for (int b = 0; b < NBAT; ++b) {
-        if (b + 1 < NBAT) {
-#pragma unroll
-          for (int q = 0; q < GB; ++q) {
-            const int grp = (b + 1) * GB + q;
-            if (grp < GA) {
-              f[(b + 1) & 1][q][0] = *(const __attribute__((address_space(3))) h8*)(wa + (grp * 2) * 1024);
-              f[(b + 1) & 1][q][1] = *(const __attribute__((address_space(3))) h8*)(wa + (grp * 2 + 1) * 1024);
-            }
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
+    for (int b = 0; b < NBAT; ++b) {
+      if (b + 1 < NBAT) {
 #pragma unroll
         for (int q = 0; q < GB; ++q) {
-          const int grp = b * GB + q, ks = grp >> 1, blk = grp & 1;
+          const int grp = (b + 1) * GB + q;
           if (grp < GA) {
-#pragma unroll
-            for (int s = 0; s < RS; ++s) {
-              d[s][blk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f[b & 1][q][1], ah[s][ks], d[s][blk], 0, 0, 0);
-              d[s][blk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f[b & 1][q][0], al[s][ks], d[s][blk], 0, 0, 0);
-              d[s][blk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f[b & 1][q][0], ah[s][ks], d[s][blk], 0, 0, 0);
-            }
+            f[(b + 1) & 1][q][0] = *(const __attribute__((address_space(3))) h8*)(wa + (grp * 2) * 1024);
+            f[(b + 1) & 1][q][1] = *(const __attribute__((address_space(3))) h8*)(wa + (grp * 2 + 1) * 1024);
           }
         }
-        __builtin_amdgcn_sched_barrier(0);
       }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < GB; ++q) {
+        const int grp = b * GB + q, ks = grp >> 1, blk = grp & 1;
+        if (grp < GA) {
+#pragma unroll
+          for (int s = 0; s < RS; ++s) {
+            d[s][blk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f[b & 1][q][1], ah[s][ks], d[s][blk], 0, 0, 0);
+            d[s][blk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f[b & 1][q][0], al[s][ks], d[s][blk], 0, 0, 0);
+            d[s][blk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f[b & 1][q][0], ah[s][ks], d[s][blk], 0, 0, 0);
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
-    // ---- phase B's barrier, its DMA and its first fragments BEFORE the tail, whose VALU work then covers their round trip.
-    // Needs D1(cc) (first group of chunk cc - 1); younger: D3, ST, LD of chunk cc - 1 and D1(cc + 1)
-    if (g.dbg) fb_wait_vmcnt<0>(); else fb_wait_vmcnt<2 * NDMA + 2 * L>();
-    __syncthreads();                  // W1[cc] is in LDS; every wave is through with phase A(cc)
-    if (!(g.dbg & 1)) dma(w3img, cc + 2 < NCH ? cc + 2 : NCH - 1, (2 * cc + 4) & 3);
-    unsigned wb_off = (unsigned)(sB * SLOT + lane * 16);
+  };
+  // `id` holds chunk cc's identity rows and receives chunk cc + 2's
+  auto phase_b = [&](int cc, f32x4 (&id)[RS][2]) __attribute__((always_inline)) {
+    unsigned wb_off = (unsigned)(((2 * cc + 1) & 3) * SLOT + lane * 16);
     asm volatile("" : "+v"(wb_off));
     const lds_bytes wb = ring3 + wb_off;
     constexpr int NBATB = (NB + GB - 1) / GB;                       // group = nb
     h8 fb[2][GB][2];
+    // the first fragments BEFORE the tail, whose VALU work then covers their round trip
 #pragma unroll
     for (int q = 0; q < GB; ++q) { fb[0][q][0] = *(const __attribute__((address_space(3))) h8*)(wb + (q * 2) * 1024); fb[0][q][1] = *(const __attribute__((address_space(3))) h8*)(wb + (q * 2 + 1) * 1024); }
     __builtin_amdgcn_sched_barrier(0);
-    // ---- the tail: needs LD(cc) (last group of chunk cc - 2); younger: chunk cc - 1, D1(cc + 1), D3(cc + 2)
     if (g.dbg) fb_wait_vmcnt<0>(); else fb_wait_vmcnt<4 * NDMA + 2 * L>();
     if constexpr (RS == 2) CAPNET_LANDED4(id[0][0], id[0][1], id[1][0], id[1][1]);
     else CAPNET_LANDED2(id[0][0], id[0][1]);
@@ -533,7 +533,7 @@ __global__ __launch_bounds__(256, 1) void fb_fused_kernel(const FArgs g) {
 #pragma unroll
     for (int s = 0; s < RS; ++s) {
       // rows past M repeat row M - 1 bit for bit (a2 and the identity were fetched from it): their stores go to that row
-      // as well -- unconditionally, the counted waits rely on every wave issuing exactly L stores per chunk
+      // as well -- unconditionally, the counted waits rely on every wave issuing exactly L stores per B phase
       const int row = min(tile0 + (wave * RS + s) * 16 + ln, g.M - 1);
       h4 hh[2], ll[2];
 #pragma unroll
@@ -555,7 +555,6 @@ __global__ __launch_bounds__(256, 1) void fb_fused_kernel(const FArgs g) {
       ol[s] = fb_cat(ll[0], ll[1]);
     }
     if (!(g.dbg & 2)) fetch_id(cc + 2 < NCH ? cc + 2 : NCH - 1, id);
-    // ---- phase B
 #pragma unroll
     for (int b = 0; b < NBATB; ++b) {
       if (b + 1 < NBATB) {
@@ -584,19 +583,53 @@ __global__ __launch_bounds__(256, 1) void fb_fused_kernel(const FArgs g) {
       __builtin_amdgcn_sched_barrier(0);
     }
   };
+  // the head of iteration k: phase k's weights are in LDS behind the barrier; phase k + 2's are requested
+  auto head = [&](int k) __attribute__((always_inline)) {
+    // (the counted wait assumes the steady stream behind D(k); the first iterations of the lagging group have run no B
+    //  phase yet -- fewer operations are younger than D(k) than the count allows for -- so the first four drain instead)
+    if (g.dbg || k < 4) fb_wait_vmcnt<0>(); else fb_wait_vmcnt<NDMA + 2 * L>();
+    __syncthreads();
+    if (!(g.dbg & 1)) {
+      const int p = k + 2 < 2 * NCH ? k + 2 : 2 * NCH - 2 + (k & 1);        // past the end: a last phase of the same kind, again
+      dma((p & 1) ? w1img : w3img, p >> 1, (k + 2) & 3);
+    }
+  };
   static_assert(NCH % 2 == 0, "chunks come in pairs (two named register sets)");
-  for (int cc = 0; cc < NCH; cc += 2) {
-    chunk(cc, idA);
-    chunk(cc + 1, idB);
-  }
-  fb_wait_vmcnt<0>();                 // the clamped DMAs and loads past the end: nothing may be in flight when the LDS is re-used / handed on
-  CAPNET_LANDED4(idA[0][0], idA[0][1], idB[0][0], idB[0][1]);
-  if constexpr (RS == 2) CAPNET_LANDED4(idA[1][0], idA[1][1], idB[1][0], idB[1][1]);
+  // One instantiation of the loop per group (LAG a constant): with the group a run-time condition inside one loop the
+  // compiler merged the two paths' hand-loaded registers with copies made while the loads were in flight
+  // (tools/isa_inflight_check.py: 486 findings) and spilled.
+  auto run = [&](auto lag_c) __attribute__((always_inline)) {
+    constexpr int LAG = decltype(lag_c)::value;
+    for (int k = 0; k < 2 * NCH; k += 4) {
+      const int c0 = k >> 1;                       // chunks c0 (even: idA) and c0 + 1 (odd: idB)
+      head(k);
+      if constexpr (LAG == 0) phase_a(c0);
+      else { if (c0 > 0) phase_b(c0 - 1, idB); }
+      head(k + 1);
+      if constexpr (LAG == 0) phase_b(c0, idA);
+      else phase_a(c0);
+      head(k + 2);
+      if constexpr (LAG == 0) phase_a(c0 + 1);
+      else phase_b(c0, idA);
+      head(k + 3);
+      if constexpr (LAG == 0) phase_b(c0 + 1, idB);
+      else phase_a(c0 + 1);
+    }
+    if constexpr (NW == 8) {
+      head(2 * NCH);
+      if constexpr (LAG != 0) phase_b(NCH - 1, idB);
+    }
+    fb_wait_vmcnt<0>();               // the clamped DMAs and loads past the end: nothing may be in flight when the LDS is re-used / handed on
+    CAPNET_LANDED4(idA[0][0], idA[0][1], idB[0][0], idB[0][1]);
+    if constexpr (RS == 2) CAPNET_LANDED4(idA[1][0], idA[1][1], idB[1][0], idB[1][1]);
+  };
+  if (NW == 4 || wave_u < 4) run(std::integral_constant<int, 0>{});
+  else run(std::integral_constant<int, 1>{});
   __syncthreads();
 
   // ---- epilogue: y1 = acc 2^-(ew1 + e1); column statistics of the rows below M
   const float osc = ldexpf(1.f, -((int)g.w1[0] + g.e1));
-  float (*const scratch)[4][MID] = reinterpret_cast<float (*)[4][MID]>(ring);       // [sum | sumsq][wave][col]
+  float (*const scratch)[NW][MID] = reinterpret_cast<float (*)[NW][MID]>(ring);     // [sum | sumsq][wave][col]
   float bad = 0.f;
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
@@ -626,9 +659,12 @@ __global__ __launch_bounds__(256, 1) void fb_fused_kernel(const FArgs g) {
     return;
   }
   __syncthreads();
-  for (int c = tid; c < MID; c += 256) {
-    g.part_sum[(long)blockIdx.x * MID + c] = (scratch[0][0][c] + scratch[0][1][c]) + (scratch[0][2][c] + scratch[0][3][c]);
-    g.part_sq[(long)blockIdx.x * MID + c] = (scratch[1][0][c] + scratch[1][1][c]) + (scratch[1][2][c] + scratch[1][3][c]);
+  for (int c = tid; c < MID; c += NT) {
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { a += scratch[0][w][c]; b += scratch[1][w][c]; }
+    g.part_sum[(long)blockIdx.x * MID + c] = a;
+    g.part_sq[(long)blockIdx.x * MID + c] = b;
   }
 }
 
@@ -698,15 +734,20 @@ int fused_block_stats(const float* y2, const float* s2, const float* t2, const u
   return kOk;
 }
 
-// 16-row strips per wave (a tile is 64 RS rows). One wave per SIMD issues its non-MFMA instructions in the shadow of its own
-// MFMAs only: with 32 rows per wave there are two MFMAs per fragment read and half the scalar / barrier overhead per row.
-static int fb_rs(int MID) {
-  const char* e = getenv("CAPNET_FB_RS");
-  if (e && (e[0] == '1' || e[0] == '2')) return e[0] - '0';
+// Tile shape: CAPNET_FB_RS / CAPNET_FB_NW (A/B switches) or the default -- 8 waves of one strip (128 rows, two waves per SIMD).
+static void fb_shape(int MID, int* rs, int* nw) {
   (void)MID;
-  return 2;
+  const char* e = getenv("CAPNET_FB_RS");
+  const char* w = getenv("CAPNET_FB_NW");
+  *nw = (w && w[0] == '4') ? 4 : 8;
+  *rs = (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : (*nw == 8 ? 1 : 2);
+  if (*nw == 8) *rs = 1;
 }
-int fused_block_tiles(long M, int MID) { return cdiv(M, 64 * fb_rs(MID)); }
+int fused_block_tiles(long M, int MID) {
+  int rs, nw;
+  fb_shape(MID, &rs, &nw);
+  return cdiv(M, 16 * rs * nw);
+}
 
 // out [M][4 MID] = relu(bn3(relu(y2 s2 + t2) . W3^T) + res (sd + td)) and y1 [M][MID] = out . W1^T, statistics partials
 // [fused_block_tiles][MID]; part_sum / part_sq null: none (inference), outputs checked for non-finite values instead.
@@ -722,15 +763,22 @@ int fused_block_forward(const float* y2, const float* s2, const float* t2, const
   a.y2 = y2; a.s2 = s2; a.t2 = t2; a.w3 = w3img; a.w1 = w1img; a.s3 = s3; a.t3 = t3; a.res = res; a.sd = sd; a.td = td;
   a.out = out; a.y1 = y1; a.part_sum = part_sum; a.part_sq = part_sq; a.M = (int)M; a.e3 = e3; a.e1 = e1; a.err = err;
   { const char* e = getenv("CAPNET_FB_DBG"); a.dbg = e ? atoi(e) : 0; }
-  const dim3 grid(fused_block_tiles(M, MID)), block(256);
-  if (fb_rs(MID) == 2) {
-    if (MID == 256) CAPNET_LAUNCH_TIMED((fb_fused_kernel<256, 2>), grid, block, stream, a);
-    else if (MID == 128) CAPNET_LAUNCH_TIMED((fb_fused_kernel<128, 2>), grid, block, stream, a);
-    else CAPNET_LAUNCH_TIMED((fb_fused_kernel<64, 2>), grid, block, stream, a);
+  const dim3 grid(fused_block_tiles(M, MID));
+  int rs, nw;
+  fb_shape(MID, &rs, &nw);
+  const dim3 block(64 * nw);
+  if (nw == 8) {
+    if (MID == 256) CAPNET_LAUNCH_TIMED((fb_fused_kernel<256, 1, 8>), grid, block, stream, a);
+    else if (MID == 128) CAPNET_LAUNCH_TIMED((fb_fused_kernel<128, 1, 8>), grid, block, stream, a);
+    else CAPNET_LAUNCH_TIMED((fb_fused_kernel<64, 1, 8>), grid, block, stream, a);
+  } else if (rs == 2) {
+    if (MID == 256) CAPNET_LAUNCH_TIMED((fb_fused_kernel<256, 2, 4>), grid, block, stream, a);
+    else if (MID == 128) CAPNET_LAUNCH_TIMED((fb_fused_kernel<128, 2, 4>), grid, block, stream, a);
+    else CAPNET_LAUNCH_TIMED((fb_fused_kernel<64, 2, 4>), grid, block, stream, a);
   } else {
-    if (MID == 256) CAPNET_LAUNCH_TIMED((fb_fused_kernel<256, 1>), grid, block, stream, a);
-    else if (MID == 128) CAPNET_LAUNCH_TIMED((fb_fused_kernel<128, 1>), grid, block, stream, a);
-    else CAPNET_LAUNCH_TIMED((fb_fused_kernel<64, 1>), grid, block, stream, a);
+    if (MID == 256) CAPNET_LAUNCH_TIMED((fb_fused_kernel<256, 1, 4>), grid, block, stream, a);
+    else if (MID == 128) CAPNET_LAUNCH_TIMED((fb_fused_kernel<128, 1, 4>), grid, block, stream, a);
+    else CAPNET_LAUNCH_TIMED((fb_fused_kernel<64, 1, 4>), grid, block, stream, a);
   }
   CAPNET_LAUNCH_CHECK();
   return kOk;
