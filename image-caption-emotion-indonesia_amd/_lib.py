@@ -30,6 +30,7 @@ SIGNATURES = {
     "capnet_crop_flip_normalize": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _i, _f, _f, _vp]),
     "capnet_topk_correct": (_i, [_vp, _l, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "capnet_beam_topk": (_i, [_vp, _l, _i, _i, _vp, _i, _vp, _vp, _vp]),
+    "capnet_beam_topk_batched": (_i, [_vp, _l, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "capnet_att_step_fwd": (_i, [_vp, _vp, _vp, _vp, _l, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i,
                                  _vp, _vp, _l, _vp, _vp]),
     "capnet_trunk_create": (_i, [_i, _i, _i, C.POINTER(_vp)]),

@@ -418,6 +418,10 @@ size_t capnet_att_saved_ints(const int* dims) { return att_saved_ints(to_adims(d
 size_t capnet_att_fwd_scratch_floats(const int* dims) { return att_fwd_scratch_floats(to_adims(dims)); }
 size_t capnet_att_bwd_scratch_floats(const int* dims) { return att_bwd_scratch_floats(to_adims(dims)); }
 
+int capnet_beam_topk_batched(const float* logits, long ld, int V, const float* prev_scores, const int* meta, int n,
+                             float* top_scores, long long* top_index, capnet_stream_t stream) {
+  return beam_topk_batched(logits, ld, V, prev_scores, meta, n, top_scores, top_index, S(stream));
+}
 int capnet_beam_topk(const float* logits, long ld, int rows, int V, const float* prev_scores, int k,
                      float* top_scores, long long* top_index, capnet_stream_t stream) {
   return beam_topk(logits, ld, rows, V, prev_scores, k, top_scores, top_index, S(stream));

@@ -198,6 +198,8 @@ int lstm_pointwise_bwd(const float* gates, long ldg, const float* c, const float
 int gather_prev_rows(const float* src, const int* idx, const float* first, const int* sample,
                      float* out, int rows, int C, hipStream_t stream);
 int argmax_rows(const float* x, int rows, int ld, int V, int* out, hipStream_t stream);
+int beam_topk_batched(const float* logits, long ld, int V, const float* prev, const int* meta, int n, float* out_scores,
+                      long long* out_index, hipStream_t stream);
 int beam_topk(const float* logits, long ld, int rows, int V, const float* prev, int k,
               float* out_scores, long long* out_index, hipStream_t stream);
 int gather_rows(const float* src, const int* idx, float* out, int rows, int C, hipStream_t stream);

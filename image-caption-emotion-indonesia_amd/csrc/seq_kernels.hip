@@ -359,9 +359,10 @@ __device__ __forceinline__ void beam_better(float v, long i, float& bv, long& bi
   if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
 }
 
-__global__ __launch_bounds__(kBeamThreads) void beam_topk_kernel(
-    const float* __restrict__ logits, long ld, int rows, int V, const float* __restrict__ prev,
-    int k, float* __restrict__ out_scores, long long* __restrict__ out_index) {
+// the expansion of ONE image's beams (a whole workgroup)
+__device__ __forceinline__ void beam_topk_body(const float* __restrict__ logits, long ld, int rows, int V,
+                                               const float* __restrict__ prev, int k, float* __restrict__ out_scores,
+                                               long long* __restrict__ out_index) {
   __shared__ float s_red[kBeamThreads / 64];
   __shared__ long s_idx[kBeamThreads / 64];
   __shared__ float s_lse[kBeamMax];
@@ -428,6 +429,24 @@ __global__ __launch_bounds__(kBeamThreads) void beam_topk_kernel(
   }
 }
 
+__global__ __launch_bounds__(kBeamThreads) void beam_topk_kernel(
+    const float* __restrict__ logits, long ld, int rows, int V, const float* __restrict__ prev,
+    int k, float* __restrict__ out_scores, long long* __restrict__ out_index) {
+  beam_topk_body(logits, ld, rows, V, prev, k, out_scores, out_index);
+}
+
+// many images at once (the test-set evaluator, stylenet/evaluator.py:63-120, decodes a whole batch per step): workgroup
+// i expands image i's beams -- rows meta[3 i] .. + meta[3 i + 1] of the logits, its meta[3 i + 2] best; flat indices are
+// local to the image (row within the image * V + word); images with k = 0 (finished) are skipped
+__global__ __launch_bounds__(kBeamThreads) void beam_topk_batched_kernel(
+    const float* __restrict__ logits, long ld, int V, const float* __restrict__ prev, const int* __restrict__ meta,
+    float* __restrict__ out_scores, long long* __restrict__ out_index) {
+  const int row0 = meta[3 * blockIdx.x], rows = meta[3 * blockIdx.x + 1], k = meta[3 * blockIdx.x + 2];
+  if (k <= 0 || rows <= 0) return;
+  beam_topk_body(logits + (long)row0 * ld, ld, rows, V, prev + row0, k, out_scores + (long)blockIdx.x * kBeamMax,
+                 out_index + (long)blockIdx.x * kBeamMax);
+}
+
 int beam_topk(const float* logits, long ld, int rows, int V, const float* prev, int k,
               float* out_scores, long long* out_index, hipStream_t stream) {
   CAPNET_REQUIRE(logits && prev && out_scores && out_index, "beam_topk: null argument");
@@ -436,6 +455,18 @@ int beam_topk(const float* logits, long ld, int rows, int V, const float* prev, 
                  "beam_topk: rows=%d k=%d V=%d (rows, k <= %d; k <= rows*V)", rows, k, V, kBeamMax);
   hipLaunchKernelGGL(beam_topk_kernel, dim3(1), dim3(kBeamThreads), 0, stream, logits, ld, rows, V,
                      prev, k, out_scores, out_index);
+  CAPNET_LAUNCH_CHECK();
+  return kOk;
+}
+
+// meta: DEVICE array [n][3] = (first row, rows that compete, k) per image, rows and k <= 16 (the caller checks: the values
+// live on the device); outputs [n][16]
+int beam_topk_batched(const float* logits, long ld, int V, const float* prev, const int* meta, int n, float* out_scores,
+                      long long* out_index, hipStream_t stream) {
+  CAPNET_REQUIRE(logits && prev && meta && out_scores && out_index && n >= 0 && V >= 1 && ld >= V, "beam_topk_batched: bad argument");
+  if (n == 0) return kOk;
+  hipLaunchKernelGGL(beam_topk_batched_kernel, dim3(n), dim3(kBeamThreads), 0, stream, logits, ld, V, prev, meta, out_scores,
+                     out_index);
   CAPNET_LAUNCH_CHECK();
   return kOk;
 }

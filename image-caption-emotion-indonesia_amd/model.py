@@ -602,3 +602,21 @@ class DecoderFactoredLSTM(nn.Module):
             zeros = torch.zeros(k, self.hidden_size, dtype=torch.float32, device=dev)
             return beam_search(step_fn, (zeros, zeros.clone()), self.vocab_size, start_token,
                                end_token, k, self.max_seq_length, dev)
+
+    def sample_batch(self, features, start_token, end_token, k=5, factual_limit=-1, mode='factual'):
+        """sample() for every row of `features` at once (capnet.beam.beam_search_batched): what the reference's test-set
+        evaluator does image by image (stylenet/evaluator.py:76-84). Returns a list of token lists, each equal to
+        sample(features[i:i+1], ...)[0].tolist()."""
+        from .beam import beam_search_batched
+        dev = self.B.weight.device
+        self._S(mode)
+        n = features.size(0)
+
+        def step_fn(prev_words, state):
+            hidden, (h, c) = self.forward_step(self.B(prev_words), state, mode=mode)
+            return self.C(hidden), (h, c)
+
+        with torch.no_grad():
+            zeros = torch.zeros(n * k, self.hidden_size, dtype=torch.float32, device=dev)
+            return beam_search_batched(step_fn, (zeros, zeros.clone()), n, self.vocab_size, start_token, end_token, k,
+                                       self.max_seq_length, dev)

@@ -216,6 +216,40 @@ class DecoderFactoredLSTMAtt(nn.Module):
             return beam_search(step_fn, (h0, c0), self.vocab_size, start_token, end_token, k,
                                self.max_seq_length, dev)
 
+    def sample_batch(self, features, start_token, end_token, k=5, factual_limit=-1, mode='factual'):
+        """sample() for every image of `features` ([n, S, S, C] or [n, P, C]) at once: the reference's evaluator
+        (stylenet/evaluator.py:63-120) decodes its test images one sample() call at a time; here all live beams of all
+        images take their decoder step together (capnet.beam.beam_search_batched). encoder_att(features) once per image;
+        a beam's rows of the map are gathered by its image index. Returns a list of token lists."""
+        from .beam import beam_search_batched
+        dev = self.B.weight.device
+        attention, _ = self._mode_modules(mode)
+        E, A, Cdim = self.embed_size, self.attention_size, features.size(-1)
+        n = features.size(0)
+        with torch.no_grad():
+            feat = features.reshape(n, -1, Cdim).to(dev).contiguous()
+            P = feat.size(1)
+            att1 = attention.encoder_att(feat.reshape(n * P, Cdim)).reshape(n, P, A).contiguous()
+            h0, c0 = self.init_hidden_state(feat)
+            img = torch.arange(n, device=dev).repeat_interleave(k)
+            h0, c0 = h0.index_select(0, img).contiguous(), c0.index_select(0, img).contiguous()
+            wz = torch.cat([attention.decoder_att.weight, self.f_beta.weight], 0).contiguous()
+            bz = torch.cat([attention.decoder_att.bias, self.f_beta.bias], 0).contiguous()
+
+            def step_fn(prev_words, state):
+                h, c, im = state
+                s_rows = h.shape[0]
+                z = ops.linear(h, wz, bz).contiguous()
+                xa = torch.empty((s_rows, E + Cdim), dtype=torch.float32, device=dev)
+                xa[:, :E] = self.B(prev_words)
+                ops.attention_step(att1.index_select(0, im), feat.index_select(0, im), z, A, attention.full_att.weight,
+                                   attention.full_att.bias, xa=xa, xa_col=E)
+                hidden, (h, c) = self.forward_step(xa, (h, c), mode=mode)
+                return self.C(hidden), (h, c, im)
+
+            return beam_search_batched(step_fn, (h0, c0, img), n, self.vocab_size, start_token, end_token, k,
+                                       self.max_seq_length, dev)
+
     def forward(self,
                 captions,
                 lengths,

@@ -101,3 +101,18 @@ class DecoderRNN(nn.Module):
             zeros = torch.zeros(k, self.hidden_size, dtype=torch.float32, device=dev)
             return beam_search(step_fn, (zeros, zeros.clone()), self.vocab_size, start_token,
                                end_token, k, self.max_seq_length, dev)
+
+    def sample_batch(self, features, start_token, end_token, k=5):
+        """sample() for every row of `features` at once (capnet.beam.beam_search_batched)."""
+        from .beam import beam_search_batched
+        dev = self.embed.weight.device
+        n = features.size(0)
+
+        def step_fn(prev_words, state):
+            hidden, (h, c) = self.forward_step(self.embed(prev_words), state)
+            return self.linear(hidden), (h, c)
+
+        with torch.no_grad():
+            zeros = torch.zeros(n * k, self.hidden_size, dtype=torch.float32, device=dev)
+            return beam_search_batched(step_fn, (zeros, zeros.clone()), n, self.vocab_size, start_token, end_token, k,
+                                       self.max_seq_length, dev)

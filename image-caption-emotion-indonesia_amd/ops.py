@@ -190,6 +190,21 @@ def beam_topk(logits, prev_scores, rows, k):
     return scores, index
 
 
+def beam_topk_batched(logits, prev_scores, meta):
+    """capnet_beam_topk_batched: meta int32 [n, 3] on the device = (first row, competing rows, k) per image.
+    Returns (scores [n, 16] float32, flat_index [n, 16] int64) on the device; only the first k entries of a row are set."""
+    _need_cuda(logits, prev_scores, meta)
+    logits, prev_scores = _c(logits), _c(prev_scores)
+    if meta.dtype != torch.int32 or meta.dim() != 2 or meta.shape[1] != 3 or not meta.is_contiguous():
+        raise CapnetError("beam_topk_batched: meta must be a contiguous int32 [n, 3] tensor")
+    n = meta.shape[0]
+    scores = torch.empty((n, 16), dtype=torch.float32, device=logits.device)
+    index = torch.empty((n, 16), dtype=torch.int64, device=logits.device)
+    check(_lib.lib().capnet_beam_topk_batched(ptr(logits), logits.shape[1], logits.shape[1], ptr(prev_scores), ptr(meta), n,
+                                              ptr(scores), ptr(index), current_stream()), "capnet_beam_topk_batched")
+    return scores, index
+
+
 def attention_step(att1, feat, z, A, w_full, b_full, xa=None, xa_col=0):
     """One attention step for s rows (no autograd; Attention.forward / sample()).
     att1 [s, P, A] = encoder_att(features); feat [s, P, C]; z [s, A + C] = [decoder_att(h) |

@@ -417,3 +417,41 @@ def val_emotion(encoder, decoder, vocab, criterion, data_loaders, tags, device=N
            for j in range(len(tags))]
     return (res[-1][0] if res else 0.0, [r[1] for r in res], [r[2] for r in res],
             [r[3] for r in res])
+
+
+def evaluate(encoder, decoder, vocab, data_loader, mode='factual', k=5, device=None, verbose=False):
+    """The test-set evaluator, stylenet/evaluator.py:55-120: encoder + decoder in eval mode, every test image decoded by
+    beam search, corpus BLEU-1..4 with the reference's four weight tuples (references and hypotheses as the reference
+    builds them: the captions' and the sampled ids as they are, <start> / <end> included). The reference calls
+    decoder.sample() per image; here a loader batch is decoded at once (decoder.sample_batch: B x k rows per step) --
+    the same sequences (tests/test_sample_gpu.py). Returns (bleu_1, bleu_2, bleu_3, bleu_4)."""
+    decoder.eval()
+    encoder.eval()
+    device = device or next(decoder.parameters()).device
+    start, end = vocab.word2idx['<start>'], vocab.word2idx['<end>']
+    kw = {} if mode is None else {"mode": mode}
+    references, hypotheses = [], []
+    for images, captions, lengths, all_captions in data_loader:
+        with torch.no_grad():
+            features = encoder(images.to(device))
+        seqs = decoder.sample_batch(features, start_token=start, end_token=end, k=k, **kw)
+        for sampled_ids, caps in zip(seqs, all_captions):
+            caps = [[int(w) for w in (c.tolist() if hasattr(c, "tolist") else c)] for c in caps]
+            references.append(caps)
+            hypotheses.append([int(w) for w in sampled_ids])
+            if verbose:
+                for name, ids in (("ref", caps[0]), ("pred", sampled_ids)):
+                    words = []
+                    for word_id in ids:
+                        words.append(vocab.idx2word[word_id])
+                        if words[-1] == '<end>':
+                            break
+                    print(name, ' '.join(words))
+    assert len(references) == len(hypotheses)
+    ops.check_device_errors()
+    out = tuple(corpus_bleu(references, hypotheses, weights=w)
+                for w in ((1, 0, 0, 0), (0.5, 0.5, 0, 0), (0.33, 0.33, 0.33, 0), (0.25, 0.25, 0.25, 0.25)))
+    if verbose:
+        for i, b in enumerate(out):
+            print('BLEU-%d' % (i + 1), b)
+    return out

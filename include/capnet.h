@@ -82,6 +82,12 @@ int capnet_argmax_rows(const float* x, int rows, int ld, int V, int* out, capnet
  * rows, k <= 16. The reference passes rows = 1 on the first step (all beams identical). */
 int capnet_beam_topk(const float* logits, long ld, int rows, int V, const float* prev_scores, int k,
                      float* top_scores, long long* top_index, capnet_stream_t stream);
+/* The same expansion for n images in one launch (the test-set evaluator, stylenet/evaluator.py:63-120, decodes every image
+ * of a batch with sample(); here all of them advance together): meta is a DEVICE array [n][3] = (first row of the image's
+ * beams in logits / prev_scores, rows that compete, k); outputs [n][16], flat indices local to the image. Images whose
+ * k is 0 (every beam finished) are skipped. rows, k <= 16. */
+int capnet_beam_topk_batched(const float* logits, long ld, int V, const float* prev_scores, const int* meta, int n,
+                             float* top_scores, long long* top_index, capnet_stream_t stream);
 
 /* ---- ResNet-152 trunk -------------------------------------------------------------------
  * torchvision resnet152 children[:-1] (pooled [B][2048]) or [:-2] (NHWC map [B][S][S][2048]),

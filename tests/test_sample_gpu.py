@@ -98,3 +98,92 @@ def test_attention_forward_single_step_matches_oracle(dev):
     mean = feat.mean(dim=1)
     assert (h0.cpu() - D._lin(params, "init_h", mean)).abs().max().item() < 1e-5
     assert (c0.cpu() - D._lin(params, "init_c", mean)).abs().max().item() < 1e-5
+
+
+# ---- the batched beam search of the test-set evaluator (stylenet/evaluator.py:63-120) ---------------------------------
+def test_beam_topk_batched_matches_the_single_image_kernel(dev):
+    g = torch.Generator().manual_seed(11)
+    V = 777
+    rows = [5, 1, 3, 0, 4]            # live beams per image (image 3 has finished)
+    ks = [5, 1, 2, 0, 4]
+    first = [0, 0, 0, 0, 1]           # image 4 is at its first step: only its row 0 competes
+    logits = (torch.randn(sum(rows), V, generator=g) * 3.0).to(dev)
+    prev = torch.randn(sum(rows), generator=g).to(dev)
+    meta, r0 = [], 0
+    for r, k, f in zip(rows, ks, first):
+        meta.append((r0, (1 if f else r) if r else 0, k))
+        r0 += r
+    sc, ix = ops.beam_topk_batched(logits, prev, torch.tensor(meta, dtype=torch.int32, device=dev))
+    for i, (r0, r, k) in enumerate(meta):
+        if k == 0:
+            continue
+        s1, i1 = ops.beam_topk(logits[r0:r0 + max(r, 1)], prev[r0:r0 + max(r, 1)], r, k)
+        assert ix[i, :k].tolist() == i1.tolist() and torch.equal(sc[i, :k], s1)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_sample_batch_equals_sample_per_image(dev, name):
+    """decoder.sample_batch (all images' beams advance together) returns, image by image, what decoder.sample returns --
+    which tests above pin to the reference's own sequences."""
+    c, params = _case(name)
+    kind = str(c["kind"])
+    start, end = [int(v) for v in Z["start_end"]]
+    dims = [int(v) for v in c["dims"]]
+    E, H, F, V, k, maxlen = dims[:6]
+    if kind == "factored":
+        dec = DecoderFactoredLSTM(E, H, F, V, 1, dropout=0.0, max_seq_length=maxlen)
+    elif kind == "nic":
+        dec = DecoderRNN(E, H, V, 1, dropout=0.0, max_seq_length=maxlen)
+    else:
+        dec = DecoderFactoredLSTMAtt(dims[6], E, H, F, V, 1, feature_size=dims[7], dropout=0.0, max_seq_length=maxlen)
+    dec.load_state_dict(params)
+    dec.to(dev).eval()
+    kw = {} if kind == "nic" else {"mode": str(c["mode"])}
+    if kind == "att":
+        base = t(c["features"]).to(dev)
+        g = torch.Generator().manual_seed(3)
+        feats = torch.cat([base] + [base * (0.5 + torch.rand(1, generator=g).item()) + 0.3 * torch.randn(base.shape, generator=g).to(dev)
+                                    for _ in range(4)], 0)
+    else:
+        feats = torch.zeros(3, E, device=dev)
+    got = dec.sample_batch(feats, start, end, k=k, **kw)
+    want = [dec.sample(feats[i:i + 1], start, end, k=k, **kw)[0].tolist() for i in range(feats.shape[0])]
+    assert got == want
+    assert got[0] == c["seq"].tolist()[0]
+    ops.check_device_errors()
+
+
+def test_evaluate_reports_the_four_bleu_scores(dev):
+    """capnet.train.evaluate == decoder.sample per image + corpus BLEU with the reference's four weight tuples."""
+    from capnet.metrics import corpus_bleu
+    from capnet.train import evaluate
+    c, params = _case("att_factual_k5")
+    dims = [int(v) for v in c["dims"]]
+    E, H, F, V, k, maxlen, A, Cf = dims
+    dec = DecoderFactoredLSTMAtt(A, E, H, F, V, 1, feature_size=Cf, dropout=0.0, max_seq_length=maxlen)
+    dec.load_state_dict(params)
+    dec.to(dev).eval()
+    start, end = [int(v) for v in Z["start_end"]]
+
+    class Vocab:
+        word2idx = {"<start>": start, "<end>": end}
+        idx2word = {i: ("<end>" if i == end else "<start>" if i == start else "w%d" % i) for i in range(V)}
+
+    class Enc(torch.nn.Module):
+        def forward(self, images):
+            return images                      # the "images" of this loader ARE feature maps
+    g = torch.Generator().manual_seed(8)
+    base = t(c["features"])
+    batches = []
+    for b in range(2):
+        feats = torch.cat([base * (0.6 + 0.2 * i + b) + 0.2 * torch.randn(base.shape, generator=g) for i in range(3)], 0)
+        caps = [[torch.tensor([start] + torch.randint(3, V, (4,), generator=g).tolist() + [end]) for _ in range(2)] for _ in range(3)]
+        batches.append((feats, None, None, caps))
+    got = evaluate(Enc(), dec, Vocab(), batches, mode="factual", k=k)
+    refs, hyps = [], []
+    for feats, _, _, caps in batches:
+        for i in range(3):
+            hyps.append(dec.sample(feats[i:i + 1].to(dev), start, end, k=k, mode="factual")[0].tolist())
+            refs.append([cc.tolist() for cc in caps[i]])
+    want = tuple(corpus_bleu(refs, hyps, weights=w) for w in ((1, 0, 0, 0), (0.5, 0.5, 0, 0), (0.33, 0.33, 0.33, 0), (0.25,) * 4))
+    assert got == want and len(got) == 4 and all(0.0 <= b <= 1.0 for b in got)
