@@ -144,3 +144,56 @@ def test_stacked_train_step_runs_and_learns(dev):
     ops.check_device_errors()
     print("stacked train steps:", [round(x, 3) for x in losses])
     assert all(torch.isfinite(torch.tensor(losses))) and min(losses[2:]) < losses[0]
+
+
+def test_eight_clamp_adam_steps_match_the_cpu_restatement(dev):
+    """round 3's log of this shape (3 layers, factored 1024, lr 1e-3) showed losses
+    6.21, 6.04, 5.00, 5.70, 19.54, 11.42, 8.37, 6.88 and the test was relaxed. Model or engine? Here the SAME eight steps
+    -- same initial weights (seed 3 state), the scheduled-sampling masks of random.seed(3), dropout 0, element-wise clamp
+    0.5 + Adam 1e-3 -- run through the engine on the GPU and through oracle.decoders_ref.stacked_factored_lstm_forward
+    + oracle.step_ref on the CPU, and every loss must agree to 1e-4 relative (the north star's bound) for as long as the
+    two trajectories can be compared at all: an excursion of the un-tanh'd h = o c stack at this learning rate amplifies
+    rounding differences, so steps behind a loss above 2 ln V are held to 5 %.
+    PERF-ONLY / PARITY UNPINNED semantics; what this pins is the engine to its restatement."""
+    import math
+    from capnet.optim import Adam
+    from capnet.utils import clip_gradient
+    from oracle import step_ref as S
+    B, V, layers, steps = 8, 500, 3, 8
+    dec = StackedFactoredLSTM(300, 512, 1024, V, layers, dropout=0.0)
+    p = synthetic.decoder_state(dec.state_dict(), seed=3)
+    dec.load_state_dict(p)
+    dec.to(dev).train()
+    _, caps, lens = synthetic.make_batch(B, V, seed=1)
+    feats = torch.randn(B, 300, generator=torch.Generator().manual_seed(3))
+    random.seed(3)
+    tfs = [[random.random() < 0.8 for _ in range(max(lens))] for _ in range(steps)]
+    opt = Adam(dec.parameters(), lr=1e-3)
+    targets = ops.packed_targets(caps.to(dev), lens)
+    gpu = []
+    for it in range(steps):
+        out = dec(caps.to(dev), lens, feats.to(dev), tf_mask=tfs[it])
+        loss = ops.cross_entropy(out, targets)
+        dec.zero_grad()
+        loss.backward()
+        clip_gradient(opt, 0.5)
+        opt.step()
+        gpu.append(loss.item())
+    ops.check_device_errors()
+    torch.set_num_threads(16)
+    pr = {k: v.clone() for k, v in p.items()}
+    oref = S.AdamRef(lr=1e-3)
+    cpu = []
+    for it in range(steps):
+        loss, grads, _, _ = S.decoder_loss_and_grads(D.stacked_factored_lstm_forward, pr, caps, lens, feats, tfs[it],
+                                                     mode="factual", num_layers=layers)
+        S.clip_gradient_(grads.values(), 0.5)
+        oref.step(pr, grads)
+        cpu.append(loss.item())
+    print("stacked 3 x 1024, eight steps: gpu", [round(x, 4) for x in gpu], "cpu", [round(x, 4) for x in cpu])
+    wild = False
+    for a, b in zip(gpu, cpu):
+        tol = 5e-2 if wild else 1e-4
+        assert abs(a - b) <= tol * abs(b), (gpu, cpu)
+        wild = wild or b > 2 * math.log(V)
+    assert min(cpu[1:]) < cpu[0]
