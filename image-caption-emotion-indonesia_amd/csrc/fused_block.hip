@@ -121,149 +121,170 @@ __global__ __launch_bounds__(256) void fb_pack_kernel(const float* __restrict__ 
 // ---------------------------------------------------------------------------------------------------------------------
 // statistics of y3 from the second moments of conv3's input
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int kGR = 512;                  // rows of a slice
+// rows of a slice (one workgroup): 256 where a slice's partial result is several blocks (K >= 128), 512 for K = 64
+static inline int fb_gram_rows(int K) { return K == 64 ? 512 : 256; }
 
 struct GArgs {
   const float* y2; const float* s2; const float* t2;
   float* gp;            // [slices][pairs][64][64]
   float* cs;            // [slices][K]
-  int M, K, in_exp, slices, pairs;
+  int M, K, in_exp, slices, pairs, slice_rows;
 };
 
-// workgroup (slice, pair (bi <= bj) of 64-channel blocks): Gp = a2[rows, bi]^T a2[rows, bj] over the slice's rows; the
-// diagonal pairs also write the column sums of their block. a2 = relu(y2 s2 + t2) 2^e, split into f16 planes while it is
-// staged ([plane][8-row group][channel][8 halfs]: a cell is 8 ROWS of one channel = the k slots of both operands of
-// v_mfma_f32_32x32x16_f16 with k = row); three products, fp32 accumulate. 2 x 2 waves of 32 x 32. A thread stages 8 rows x
-// 4 channels (eight 16-B loads, 512 contiguous bytes per row and half-wave) into four cells; a step is 64 rows of 128
-// channels (off-diagonal pairs) or 128 rows of 64; rows run TWO steps ahead in two named register sets (the kernel is
-// one memory round trip per step otherwise).
+// A workgroup takes a slice of rows and ALL channels: it stages a step of rows ONCE -- a2 = relu(y2 s2 + t2) 2^e split
+// into f16 planes, image [plane][8-row group][channel][8 halfs]: a cell is 8 ROWS of one channel = the k slots of both
+// operands of v_mfma_f32_32x32x16_f16 with k = row -- and forms every pair (bi <= bj) of 64-channel blocks of
+// G = a2^T a2 from it (three products, fp32 accumulate; 2 x 2 waves, a 32 x 32 quadrant of each pair per wave:
+// K / 64 (K / 64 + 1) / 2 accumulators). Round 4's first form gave each pair its own workgroup and re-staged the rows per
+// pair: 26 VALU instructions per MFMA and 250 workgroups of 16 us where this is 49 of about the same length. A thread
+// stages 8 rows x 4 channels per item (eight 16-B loads); the next step's rows are requested before this step's MFMAs.
+template <int K>
 __global__ __launch_bounds__(256) void fb_gram_kernel(const GArgs g) {
-  constexpr int kPlane = 8 * 128 * 16, kStageB = 2 * kPlane;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kStageB];      // two steps of 32 KB
+  constexpr int NBLK = K / 64, NPAIR = NBLK * (NBLK + 1) / 2;
+  constexpr int SR = K == 64 ? 128 : 64, NRG = SR / 8;               // rows and 8-row groups of a step
+  constexpr int NCQ = K / 4, NIT = NCQ * NRG / 256;                  // 4-channel groups; items per thread and step
+  constexpr int kPlane = NRG * K * 16;
+  static_assert(NIT >= 1 && NCQ * NRG == NIT * 256, "staging items");
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kPlane];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int slice = blockIdx.x / g.pairs, pair = blockIdx.x - slice * g.pairs;
-  int bi = 0, bj = 0;
-  {
-    int p = pair, nb = g.K / 64;
-    while (p >= nb - bi) { p -= nb - bi; ++bi; }
-    bj = bi + p;
-  }
-  const bool diag = bi == bj;
-  const int nch = diag ? 64 : 128, nrg = diag ? 16 : 8, srows = 8 * nrg;      // channels, row groups and rows of a step
   const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
-  const int row0 = slice * kGR;
-  const int rows = min(kGR, g.M - row0);
-  const int nst = (rows + srows - 1) / srows;
+  const int slice = blockIdx.x, row0 = slice * g.slice_rows;
+  const int rows = min(g.slice_rows, g.M - row0);
+  const int nst = (rows + SR - 1) / SR;
   const float iscale = ldexpf(1.f, g.in_exp);
-  const int chq = diag ? (tid & 15) : (tid & 31), rg = diag ? (tid >> 4) : (tid >> 5);
-  const int chl = 4 * chq;                                                     // first of this thread's 4 channels in the step image
-  const int chg = chl < 64 ? bi * 64 + chl : bj * 64 + chl - 64;
-  const f32x4 sc = *reinterpret_cast<const f32x4*>(g.s2 + chg), sh = *reinterpret_cast<const f32x4*>(g.t2 + chg);
+  const int chq = tid % NCQ, rgb = tid / NCQ;                         // item q: row group rgb + q (256 / NCQ)
+  const f32x4 sc = *reinterpret_cast<const f32x4*>(g.s2 + 4 * chq), sh = *reinterpret_cast<const f32x4*>(g.t2 + 4 * chq);
   f32x4 colsum = {0.f, 0.f, 0.f, 0.f};
-  f32x16 acc;
+  f32x16 acc[NPAIR];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  f32x4 va[8], vb[8];
-  auto fetch = [&](int st, f32x4 (&v)[8]) {
+  for (int p = 0; p < NPAIR; ++p)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int m = row0 + st * srows + rg * 8 + e;
-      v[e] = *reinterpret_cast<const f32x4*>(g.y2 + (long)min(m, g.M - 1) * g.K + chg);
-    }
+    for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+  f32x4 v[NIT][8];
+  auto fetch = [&](int st) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < NIT; ++q)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int m = row0 + st * SR + (rgb + q * (256 / NCQ)) * 8 + e;
+        v[q][e] = *reinterpret_cast<const f32x4*>(g.y2 + (long)min(m, g.M - 1) * K + 4 * chq);
+      }
   };
-  auto stage = [&](int st, int buf, const f32x4 (&v)[8]) {
-    f32x4 x[8];
+  auto stage = [&](int st) __attribute__((always_inline)) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int m = row0 + st * srows + rg * 8 + e;
-      const bool ok = m < row0 + rows;
+    for (int q = 0; q < NIT; ++q) {
+      const int rg = rgb + q * (256 / NCQ);
+      f32x4 x[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const bool ok = row0 + st * SR + rg * 8 + e < row0 + rows;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float t = fmaxf(fmaf(v[q][e][c], sc[c], sh[c]), 0.f) * iscale;
+          x[e][c] = ok ? t : 0.f;
+          colsum[c] += x[e][c];
+        }
+      }
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        const float t = fmaxf(fmaf(v[e][c], sc[c], sh[c]), 0.f) * iscale;
-        x[e][c] = ok ? t : 0.f;
-        colsum[c] += x[e][c];
+        const f32x4 a = {x[0][c], x[1][c], x[2][c], x[3][c]}, b = {x[4][c], x[5][c], x[6][c], x[7][c]};
+        h4 ha, la, hb, lb;
+        fb_split4(a, ha, la);
+        fb_split4(b, hb, lb);
+        unsigned char* d = lds + (rg * K + 4 * chq + c) * 16;
+        *reinterpret_cast<h8*>(d) = fb_cat(ha, hb);
+        *reinterpret_cast<h8*>(d + kPlane) = fb_cat(la, lb);
       }
     }
+  };
+  auto mma = [&]() __attribute__((always_inline)) {
+#pragma unroll 2
+    for (int k = 0; k < NRG / 2; ++k) {
+      const unsigned char* base = lds + ((2 * k + lh) * K + li) * 16;
+      h8 ah[NBLK], al[NBLK], bh[NBLK], bl[NBLK];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const f32x4 a = {x[0][c], x[1][c], x[2][c], x[3][c]}, b = {x[4][c], x[5][c], x[6][c], x[7][c]};
-      h4 ha, la, hb, lb;
-      fb_split4(a, ha, la);
-      fb_split4(b, hb, lb);
-      unsigned char* d = lds + buf * kStageB + (rg * nch + chl + c) * 16;
-      *reinterpret_cast<h8*>(d) = fb_cat(ha, hb);
-      *reinterpret_cast<h8*>(d + kPlane) = fb_cat(la, lb);
+      for (int b = 0; b < NBLK; ++b) {
+        ah[b] = *reinterpret_cast<const h8*>(base + (b * 64 + wm * 32) * 16);
+        al[b] = *reinterpret_cast<const h8*>(base + (b * 64 + wm * 32) * 16 + kPlane);
+        bh[b] = *reinterpret_cast<const h8*>(base + (b * 64 + wn * 32) * 16);
+        bl[b] = *reinterpret_cast<const h8*>(base + (b * 64 + wn * 32) * 16 + kPlane);
+      }
+      int p = 0;
+#pragma unroll
+      for (int bi = 0; bi < NBLK; ++bi)
+#pragma unroll
+        for (int bj = bi; bj < NBLK; ++bj, ++p) {
+          acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[bi], bh[bj], acc[p], 0, 0, 0);
+          acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[bi], bl[bj], acc[p], 0, 0, 0);
+          acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[bi], bh[bj], acc[p], 0, 0, 0);
+        }
     }
   };
-  auto mma = [&](int buf) {
-    const unsigned char* ia = lds + buf * kStageB + (wm * 32 + li) * 16;
-    const unsigned char* ib = lds + buf * kStageB + ((diag ? 0 : 64) + wn * 32 + li) * 16;
-    for (int k = 0; k < nrg / 2; ++k) {
-      const int off = (2 * k + lh) * nch * 16;
-      const h8 ah = *reinterpret_cast<const h8*>(ia + off), al = *reinterpret_cast<const h8*>(ia + off + kPlane);
-      const h8 bh = *reinterpret_cast<const h8*>(ib + off), bl = *reinterpret_cast<const h8*>(ib + off + kPlane);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
-    }
-  };
-  const int last = nst - 1;
-  fetch(0, va);
-  fetch(last > 0 ? 1 : 0, vb);
-  stage(0, 0, va);
-  fetch(last > 1 ? 2 : last, va);
-  __syncthreads();
-  // step st is in LDS buffer st & 1; the register set of parity (st + 1) & 1 holds step st + 1, the other one step st + 2
-  for (int st = 0; st < nst; st += 2) {
-    if (st + 1 <= last) stage(st + 1, 1, vb);
-    fetch(st + 3 < last ? st + 3 : last, vb);
-    mma(0);
+  fetch(0);
+  for (int st = 0; st < nst; ++st) {
+    stage(st);
     __syncthreads();
-    if (st + 1 > last) break;
-    if (st + 2 <= last) stage(st + 2, 0, va);
-    fetch(st + 4 < last ? st + 4 : last, va);
-    mma(1);
+    fetch(st + 1 < nst ? st + 1 : st);               // (past the end: the last step's rows again, never staged)
+    mma();
     __syncthreads();
   }
   // D[m][n]: m = (r & 3) + 8 (r >> 2) + 4 lh = channel of block bi, n = li = channel of block bj; both operands carried 2^e
   const float osc = ldexpf(1.f, -2 * g.in_exp);
-  float* out = g.gp + ((long)slice * g.pairs + pair) * 4096;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int m = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-    out[m * 64 + wn * 32 + li] = acc[r] * osc;
-  }
-  if (diag) {
-    f32x4* cs_sh = reinterpret_cast<f32x4*>(lds);              // [16 row groups][16 channel quads]
-    cs_sh[tid] = colsum;
-    __syncthreads();
-    if (tid < 16) {
-      f32x4 t = cs_sh[tid];
+  for (int p = 0; p < NPAIR; ++p) {
+    float* out = g.gp + ((long)slice * NPAIR + p) * 4096;
 #pragma unroll
-      for (int q = 1; q < 16; ++q) t += cs_sh[q * 16 + tid];
-      *reinterpret_cast<f32x4*>(g.cs + (long)slice * g.K + bi * 64 + 4 * tid) = t * ldexpf(1.f, -g.in_exp);
+    for (int r = 0; r < 16; ++r) {
+      const int m = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      out[m * 64 + wn * 32 + li] = acc[p][r] * osc;
     }
+  }
+  f32x4* cs_sh = reinterpret_cast<f32x4*>(lds);                // [256 / NCQ row-group lanes][NCQ channel quads]
+  cs_sh[tid] = colsum;
+  __syncthreads();
+  if (tid < NCQ) {
+    f32x4 t = cs_sh[tid];
+#pragma unroll
+    for (int q = 1; q < 256 / NCQ; ++q) t += cs_sh[q * NCQ + tid];
+    *reinterpret_cast<f32x4*>(g.cs + (long)slice * K + 4 * tid) = t * ldexpf(1.f, -g.in_exp);
   }
 }
 
-// G (full, symmetric) and the column sums, summed over the slices in double, stored fp32: 8 threads share an entry's slices
+// G (full, symmetric) and the column sums, summed over the slices in double, stored fp32: 8 threads share an entry's
+// slices, each with eight independent loads in flight per round. (Measured alternatives, K = 64 / 128 / 256: a plain loop
+// 7.4 / 6.5 / 12.9 us; 128 entries per workgroup with 32 loads per thread 20 / 22 / 15 us -- the partial blocks of one
+// entry lie 16-160 KB apart, more loads per thread only adds pages per thread; this form 4.8 / 9.9 / 13.5 us.)
 __global__ __launch_bounds__(256) void fb_gram_reduce_kernel(const float* __restrict__ gp, const float* __restrict__ cs, float* __restrict__ G,
                                                              float* __restrict__ mu, int K, int slices, int pairs) {
   __shared__ double sh[8][33];
   const int e = blockIdx.x * 32 + (threadIdx.x & 31), part = threadIdx.x >> 5;
   const int nG = K * K;
-  double s = 0.0;
+  const float* p = nullptr;
+  long stride = 0;
   if (e < nG) {
     int r = e / K, c = e - r * K;
     int bi = r >> 6, bj = c >> 6, m = r & 63, n = c & 63;
     if (bi > bj) { int t = bi; bi = bj; bj = t; t = m; m = n; n = t; }
     const int nb = K / 64;
     const int pair = bi * nb - bi * (bi - 1) / 2 + (bj - bi);
-    const float* p = gp + (long)pair * 4096 + m * 64 + n;
-    for (int sl = part; sl < slices; sl += 8) s += (double)p[(long)sl * pairs * 4096];
+    p = gp + (long)pair * 4096 + m * 64 + n;
+    stride = (long)pairs * 4096;
   } else if (e < nG + K) {
-    const int k = e - nG;
-    for (int sl = part; sl < slices; sl += 8) s += (double)cs[(long)sl * K + k];
+    p = cs + (e - nG);
+    stride = K;
+  }
+  double s = 0.0;
+  if (p) {
+    for (int s0 = part; s0 < slices; s0 += 64) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int sl = s0 + 8 * u;
+        v[u] = p[(long)(sl < slices ? sl : part) * stride];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += (s0 + 8 * u < slices) ? (double)v[u] : 0.0;
+    }
   }
   sh[part][threadIdx.x & 31] = s;
   __syncthreads();
@@ -694,11 +715,11 @@ int fused_block_pack(const float* w, unsigned* img, int C, int MID, int role, hi
   return kOk;
 }
 
-int fused_block_gram_slices(long M) { return cdiv(M, kGR); }
+int fused_block_gram_slices(long M, int K) { return cdiv(M, fb_gram_rows(K)); }
 int fused_block_gram_pairs(int K) { const int nb = K / 64; return nb * (nb + 1) / 2; }
 // floats of the statistics workspace: partial blocks + column sums, then G and mu (fp32), 16-B aligned parts
 size_t fused_block_stats_floats(long M, int K) {
-  const size_t s = fused_block_gram_slices(M), p = fused_block_gram_pairs(K);
+  const size_t s = fused_block_gram_slices(M, K), p = fused_block_gram_pairs(K);
   return s * p * 4096 + ((s * K + 3) / 4 * 4) + ((size_t)K * K + K) + 8;
 }
 
@@ -712,12 +733,14 @@ int fused_block_stats(const float* y2, const float* s2, const float* t2, const u
   const int K = MID, C = 4 * MID;
   GArgs a;
   a.y2 = y2; a.s2 = s2; a.t2 = t2; a.M = (int)M; a.K = K; a.in_exp = in_exp;
-  a.slices = fused_block_gram_slices(M); a.pairs = fused_block_gram_pairs(K);
+  a.slices = fused_block_gram_slices(M, K); a.pairs = fused_block_gram_pairs(K); a.slice_rows = fb_gram_rows(K);
   a.gp = work;
   a.cs = work + (size_t)a.slices * a.pairs * 4096;
   float* G = a.cs + ((size_t)a.slices * K + 3) / 4 * 4;
   float* mu = G + (size_t)K * K;
-  hipLaunchKernelGGL(fb_gram_kernel, dim3(a.slices * a.pairs), dim3(256), 0, stream, a);
+  if (K == 256) hipLaunchKernelGGL(fb_gram_kernel<256>, dim3(a.slices), dim3(256), 0, stream, a);
+  else if (K == 128) hipLaunchKernelGGL(fb_gram_kernel<128>, dim3(a.slices), dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL(fb_gram_kernel<64>, dim3(a.slices), dim3(256), 0, stream, a);
   hipLaunchKernelGGL(fb_gram_reduce_kernel, dim3(cdiv((long)K * K + K, 32)), dim3(256), 0, stream, a.gp, a.cs, G, mu, K, a.slices, a.pairs);
   const double inv = 1.0 / (double)M, unbias = M > 1 ? (double)M / (double)(M - 1) : 1.0;
   const float* wcopy = reinterpret_cast<const float*>(w3img + kFHdr + (size_t)C * MID);

@@ -1,1 +1,2 @@
-for d in 0 1 2 3 4 7; do echo "== NW8 dbg $d"; CAPNET_FB_NW=8 CAPNET_FB_DBG=$d timeout -k 10 120 python tools/fused_block_bench.py 2>&1 | grep "stage 14"; done
+timeout -k 10 120 python tools/fused_block_bench.py 2>&1 | grep stage
+cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d /root/repo/gpurun_out/fbb_prof -o fbb -- python3 /root/repo/tools/fused_block_bench.py > /dev/null 2>&1
