@@ -380,7 +380,6 @@ struct FArgs {
   float* out; float* y1; float* part_sum; float* part_sq;
   int M, e3, e1;
   int* err;
-  int dbg;      // timing experiments only (CAPNET_FB_DBG): 1 no weight DMA in the loop, 2 no identity loads / out stores, 4 drain-all waits
 };
 
 template <int N>
@@ -547,7 +546,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void fb_fused_kernel(const FArgs g
 #pragma unroll
     for (int q = 0; q < GB; ++q) { fb[0][q][0] = *(const __attribute__((address_space(3))) h8*)(wb + (q * 2) * 1024); fb[0][q][1] = *(const __attribute__((address_space(3))) h8*)(wb + (q * 2 + 1) * 1024); }
     __builtin_amdgcn_sched_barrier(0);
-    if (g.dbg) fb_wait_vmcnt<0>(); else fb_wait_vmcnt<4 * NDMA + 2 * L>();
+    fb_wait_vmcnt<4 * NDMA + 2 * L>();
     if constexpr (RS == 2) CAPNET_LANDED4(id[0][0], id[0][1], id[1][0], id[1][1]);
     else CAPNET_LANDED2(id[0][0], id[0][1]);
     h8 oh[RS], ol[RS];
@@ -569,13 +568,13 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void fb_fused_kernel(const FArgs g
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = fmaxf(fmaf(d[s][blk][e], sv[e], tv[e]) + r[e], 0.f);
-        if (!(g.dbg & 2)) *reinterpret_cast<f32x4*>(g.out + (long)row * C + ch) = o;
+        *reinterpret_cast<f32x4*>(g.out + (long)row * C + ch) = o;
         fb_split4(o * is1, hh[blk], ll[blk]);
       }
       oh[s] = fb_cat(hh[0], hh[1]);
       ol[s] = fb_cat(ll[0], ll[1]);
     }
-    if (!(g.dbg & 2)) fetch_id(cc + 2 < NCH ? cc + 2 : NCH - 1, id);
+    fetch_id(cc + 2 < NCH ? cc + 2 : NCH - 1, id);
 #pragma unroll
     for (int b = 0; b < NBATB; ++b) {
       if (b + 1 < NBATB) {
@@ -608,12 +607,10 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void fb_fused_kernel(const FArgs g
   auto head = [&](int k) __attribute__((always_inline)) {
     // (the counted wait assumes the steady stream behind D(k); the first iterations of the lagging group have run no B
     //  phase yet -- fewer operations are younger than D(k) than the count allows for -- so the first four drain instead)
-    if (g.dbg || k < 4) fb_wait_vmcnt<0>(); else fb_wait_vmcnt<NDMA + 2 * L>();
+    if (k < 4) fb_wait_vmcnt<0>(); else fb_wait_vmcnt<NDMA + 2 * L>();
     __syncthreads();
-    if (!(g.dbg & 1)) {
-      const int p = k + 2 < 2 * NCH ? k + 2 : 2 * NCH - 2 + (k & 1);        // past the end: a last phase of the same kind, again
-      dma((p & 1) ? w1img : w3img, p >> 1, (k + 2) & 3);
-    }
+    const int p = k + 2 < 2 * NCH ? k + 2 : 2 * NCH - 2 + (k & 1);          // past the end: a last phase of the same kind, again
+    dma((p & 1) ? w1img : w3img, p >> 1, (k + 2) & 3);
   };
   static_assert(NCH % 2 == 0, "chunks come in pairs (two named register sets)");
   // One instantiation of the loop per group (LAG a constant): with the group a run-time condition inside one loop the
@@ -785,7 +782,6 @@ int fused_block_forward(const float* y2, const float* s2, const float* t2, const
   FArgs a;
   a.y2 = y2; a.s2 = s2; a.t2 = t2; a.w3 = w3img; a.w1 = w1img; a.s3 = s3; a.t3 = t3; a.res = res; a.sd = sd; a.td = td;
   a.out = out; a.y1 = y1; a.part_sum = part_sum; a.part_sq = part_sq; a.M = (int)M; a.e3 = e3; a.e1 = e1; a.err = err;
-  { const char* e = getenv("CAPNET_FB_DBG"); a.dbg = e ? atoi(e) : 0; }
   const dim3 grid(fused_block_tiles(M, MID));
   int rs, nw;
   fb_shape(MID, &rs, &nw);
