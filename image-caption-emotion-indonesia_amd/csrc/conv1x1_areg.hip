@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void conv1x1_areg_kernel(const RArgs g) {
   // ---- weights: a granule = KG k-steps x 4 pieces (plane, k16 group) of 1 KB, LDS image [k-step][piece][1 KB]. Wave w
   // moves pieces w KG .. w KG + KG - 1 by LDS-DMA (no registers for data in flight), two granules ahead of the MFMAs:
   // a granule lasts ~1 500 cycles, a fetch from L2 ~2 000 under load -- through registers, half a granule ahead, every
-  // granule waited twice for its weights (61 us on the 14 x 14 maps; tools/areg_bench.py).
+  // granule waited twice for its weights (61 us on the 14 x 14 maps; tools/probes/areg_bench.py).
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const unsigned lds_b0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)bbuf);
   auto dma_b = [&](int nb, int buf) {

@@ -3,11 +3,11 @@
 // 22..23 significant bits), and
 //     x y 2^(s+s')  =  h h' + (h l' + l h')          [ + l l' below 2^-22 |x y| ],
 // each an exact f16 x f16 product accumulated in fp32 by v_mfma_f32_32x32x16_f16 (which keeps f16
-// subnormals: tools/native/mfma_f16_denorm.hip). Against the split into three bf16 pieces
+// subnormals: tools/probes/native/mfma_f16_denorm.hip). Against the split into three bf16 pieces
 // (conv_bf16x6.hip: six products) this halves the matrix work, moves 4 instead of 6 bytes per element through
 // LDS and needs 5 instead of 11 VALU per pair for the split. Measured rms error against fp64 on the trunk's
 // shapes (tests/test_kernels_gpu.py): at or below the f32-MFMA kernels' -- the fp32 accumulation of K
-// products, not the 2^-23 of the operands, sets it (numpy model of all three: tools/split_error.py).
+// products, not the 2^-23 of the operands, sets it (numpy model of all three: tools/probes/split_error.py).
 //
 // Scales. Weights: 2^ew chosen per tensor at pack time so that max |w| 2^ew lies in [2^13, 2^14) (stored in
 // the image's header): their residuals are normal f16 numbers. Activations are split as they are: the

@@ -1,6 +1,6 @@
 // Implicit-GEMM convolution, second generation: built around one measured fact about gfx950 --
 // v_mfma_f32_32x32x2_f32 runs on the SAME pipe as the f32 VALU (a co-resident wave's VALU work
-// adds to MFMA time instead of hiding under it; tools/native/coexec.hip measures 2.31 ms MFMA
+// adds to MFMA time instead of hiding under it; tools/probes/native/coexec.hip measures 2.31 ms MFMA
 // + 0.88 ms VALU = 3.01 ms together). So the k-loop is written to issue almost no VALU:
 //   * weights are pre-packed K-MAJOR ([Kw][Cout]) and streamed straight into LDS by LDS-DMA
 //     (global_load_lds_dwordx4): no VGPRs, no ds_write, no address arithmetic in the loop;
@@ -466,7 +466,7 @@ static void tile_dims(int tile, int* BM, int* BN) {
   *BN = tile == 128 ? 128 : 64;
 }
 
-// Tile choice for the K-major kernel. Measured model (tools/conv_bench.py, B sweep): with n
+// Tile choice for the K-major kernel. Measured model (tools/probes/conv_bench.py, B sweep): with n
 // tiles per CU a k-tile step costs max(n * c / 0.8, c / 0.47) cycles, c = MFMA cycles of one
 // tile's k-tile per SIMD (512 / 1024 / 2048 for 64x64 / 128x64 / 128x128): a lone workgroup per
 // CU is latency-bound at ~47 % of the matrix pipe, several share it at ~80 %. n comes from the

@@ -10,7 +10,7 @@
 // (stylenet/model.py:193-194), whose operands have the same shape.
 //
 // Why a second GEMM core. On gfx950 the f32-input MFMA executes on the vector datapath: every VALU
-// instruction a wave issues is time the matrix pipe does not get (tools/native/coexec.hip).
+// instruction a wave issues is time the matrix pipe does not get (tools/probes/native/coexec.hip).
 // The K-major conv kernel (conv_f32_v2.hip) stages A through registers (8 ds_write_b32 + address
 // VALU per k-tile) and reads fragments with one ds_read_b32 per MFMA operand. Here:
 //   * A and B tiles (128 x 32 and BN x 32 floats per k-tile) go global -> LDS by

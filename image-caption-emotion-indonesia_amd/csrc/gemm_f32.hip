@@ -501,7 +501,7 @@ static bool try_rows16(bool tb, int M, int N, int K, const float* A, long lda, c
   // (load round trip + staging + MFMAs: ~2.2 us each); K cut into `splits` costs the hand-off once (~3.5 us + 0.25 us
   // per slab the last workgroup has to fetch). Fitted to a sweep over `sub` on the six step shapes of a 12-image
   // attention batch (12 x {4608,8192,512} x 512: no split, 7.7-7.9 us against 10.6-11.4 for skinny + reduce;
-  // 12 x 2048 x 2348: 2 chunks x 5 splits, 12.1 against 15.7; tools/rows16_bench.py).
+  // 12 x 2048 x 2348: 2 chunks x 5 splits, 12.1 against 15.7; tools/probes/rows16_bench.py).
   const int tiles_n = cdiv(N, 64), chunks = cdiv(K, kR16KC);
   int sub = chunks, splits = 1;
   float best = 2.2f * chunks;

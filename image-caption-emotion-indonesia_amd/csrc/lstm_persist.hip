@@ -71,7 +71,7 @@ struct PersistArgs {
   float* hiddens;
   int* ctl;
   int* err_flag;
-  unsigned long long* stamps;   // diagnostics only (tools/persist_phases.py), else nullptr
+  unsigned long long* stamps;   // diagnostics only (tools/probes/persist_phases.py), else nullptr
   int t0, t1, cfg, seg;
   int off[kMaxSteps + 1];
   short b[kMaxSteps];
@@ -101,7 +101,7 @@ __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" :
 // residuals of weights down to 2^-22 are normal f16 numbers (|w| < 2^(15 - kWExp) = 32 is the domain; beyond it the
 // f16 piece is inf and the loss is NaN, nothing is silent); h is split as it is (|h| < 65 504; its residual is a
 // subnormal f16 below |h| = 0.12, i.e. an absolute error of 2^-25 per element, fp32's own rounding at |h| = 0.5 --
-// subnormal operands run at full rate, tools/native/mfma_f16_denorm.hip).
+// subnormal operands run at full rate, tools/probes/native/mfma_f16_denorm.hip).
 // 48 MFMAs of 16 cycles per wave and step where the f32 4x4x1 form issued 256 of 8..10 (round 2).
 //
 // Operand map: the MFMA computes out^T -- A = W (lane l holds gate column n = l & 15 of a 16-column block), B = h
@@ -206,7 +206,7 @@ __device__ __forceinline__ float fast_tanh(float x) {
   return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
 }
 
-// DIAG: s_memtime stamps (tools/persist_phases.py); the product instantiation has none
+// DIAG: s_memtime stamps (tools/probes/persist_phases.py); the product instantiation has none
 template <bool DIAG>
 __global__ __launch_bounds__(256) void lstm_persist_kernel(const PersistArgs a) {
   constexpr int H = kPH;

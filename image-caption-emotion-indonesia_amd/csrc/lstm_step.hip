@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void lstm_step_fused_kernel(
   //        bit 8 tanh_out, bit 9 two row halves
   const int gi = cfg & 3, gf = (cfg >> 2) & 3, go = (cfg >> 4) & 3, gg = (cfg >> 6) & 3;
   const int tanh_out = (cfg >> 8) & 1, mh_shift = (cfg >> 9) & 1;
-  // stamps != nullptr only in the diagnostic build path (tools/step_phases.py): five s_memtime
+  // stamps != nullptr only in the diagnostic build path (tools/probes/step_phases.py): five s_memtime
   // readings per workgroup, written to a buffer nothing else reads
   unsigned long long ts[5];
   if (stamps) ts[0] = __builtin_amdgcn_s_memtime();

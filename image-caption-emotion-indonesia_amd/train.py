@@ -121,7 +121,7 @@ class TrunkPipeline(object):
         the following batches instead of leaving it idle;
       * `depth` (default 3) trunk passes are in flight: while one sits in a launch-bound bubble
         (bn_finalize, tail fix-ups: tiny kernels between the convolutions) the convolutions of
-        another one run (tools/trunk_overlap_probe.py: 17.0 -> 15.2-16.0 ms per pass with two;
+        another one run (tools/probes/trunk_overlap_probe.py: 17.0 -> 15.2-16.0 ms per pass with two;
         measured step time 18.9 / 16.1 / 15.7 / 16.8 ms at depth 1 / 2 / 3 / 4).
 
         pipe = TrunkPipeline(encoder, decoder, optimizer, criterion, grad_clip)

@@ -266,7 +266,7 @@ def test_attention_train_steps_match_the_cpu_oracle(dev, trunk, steps, tol):
         f_beta / factored parameter). Not more steps: at 12 images the train-mode BatchNorm chain
         leaves the two fp32 trunks ~1e-4 apart, and the loss, blind to the features at step 0
         (6e-6), follows them more closely with every update (2e-5 at step 1, 2e-4 at step 2; the
-        decoder itself is exact: tools/att_grad_check.py, same features -> loss 1e-8, grads 2e-6).
+        decoder itself is exact: tools/probes/att_grad_check.py, same features -> loss 1e-8, grads 2e-6).
     trunk="shared": the CPU decoder is fed the GPU trunk's features, which isolates
         train_step_att + decoder + optimiser over four steps, held to 2e-5."""
     from oracle.resnet152_ref import EncoderCNNAttRef

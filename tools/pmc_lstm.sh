@@ -6,8 +6,8 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/pmc_lstm
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o f -- python3 $ROOT/tools/persist_24.py > $OUT/fetch.log 2>&1 || exit 1
-timeout -k 10 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o w -- python3 $ROOT/tools/persist_24.py > $OUT/write.log 2>&1 || exit 1
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o f -- python3 $ROOT/tools/probes/persist_24.py > $OUT/fetch.log 2>&1 || exit 1
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o w -- python3 $ROOT/tools/probes/persist_24.py > $OUT/write.log 2>&1 || exit 1
 python3 - $OUT <<'P' > $ROOT/gpurun_out/pmc_lstm.json
 import csv, glob, json, os, sys
 def tot(d, c):
@@ -20,6 +20,6 @@ nf, f = tot("fetch", "FETCH_SIZE"); nw, w = tot("write", "WRITE_SIZE")
 per_launch = (2.0 * f / max(nf, 1) + w / max(nw, 1)) * 1024.0
 print(json.dumps({"lstm_persist_pmc_launches": nf, "lstm_persist_bytes_per_launch_24_steps": round(per_launch),
                   "lstm_persist_bytes_per_step": round(per_launch / 24),
-                  "lstm_persist_note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) -- python3 tools/persist_24.py; FETCH_SIZE doubled"}, indent=1))
+                  "lstm_persist_note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) -- python3 tools/probes/persist_24.py; FETCH_SIZE doubled"}, indent=1))
 P
 cat $ROOT/gpurun_out/pmc_lstm.json

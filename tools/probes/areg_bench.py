@@ -1,8 +1,8 @@
 """conv3 of the bottlenecks (stride-1 1x1, folded input) at B = 64: A-in-registers kernel (csrc/conv1x1_areg.hip) against the
 tiled split-f16 kernel (csrc/conv_f16x3.hip), alone on the chip and beside a stream of stage-3 3x3 convolutions.
-    python tools/areg_bench.py"""
+    python tools/probes/areg_bench.py"""
 import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import capnet
 from capnet import ops
 from capnet._lib import check, lib, ptr, current_stream

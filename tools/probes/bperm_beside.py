@@ -1,11 +1,11 @@
 """Register-only wave reductions (ds_bpermute vs DPP) beside a conv kernel: does the conv kernel disturb them?
-    python tools/bperm_beside.py [h3|none]"""
+    python tools/probes/bperm_beside.py [h3|none]"""
 import ctypes as C, os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import capnet
 from capnet._lib import check, lib, ptr
 dev = torch.device("cuda:0"); L = lib()
-P = C.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "build", "libbperm_probe.so"))
+P = C.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "build", "libbperm_probe.so"))
 P.launch_probe.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
 KIND = sys.argv[1] if len(sys.argv) > 1 else "h3"
 Bc, H, Cin, Cout = 64, 28, 512, 128

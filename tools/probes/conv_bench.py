@@ -1,5 +1,5 @@
 """Micro-benchmark of the implicit-GEMM conv kernel on the ResNet-152 layer shapes (B=64).
-    python tools/conv_bench.py [--tile CODE] [--iters N] [--shapes s3c1,s3c2,...]
+    python tools/probes/conv_bench.py [--tile CODE] [--iters N] [--shapes s3c1,s3c2,...]
 Prints TFLOP/s per shape; run under rocprofv3 --pmc for counters."""
 import argparse
 import os
@@ -7,7 +7,7 @@ import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import capnet  # noqa: E402
 from capnet import ops  # noqa: E402
 from capnet._lib import check, current_stream, lib, ptr  # noqa: E402

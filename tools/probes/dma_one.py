@@ -1,6 +1,6 @@
 """One trunk 1x1 shape through both 1x1 kernels (for counter passes)."""
 import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import capnet
 from capnet import ops
 from capnet._lib import check, current_stream, lib, ptr

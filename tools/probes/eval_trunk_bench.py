@@ -1,7 +1,7 @@
-"""Inference trunk pass (encoder.eval()) at B = 64: ms per pass.   python tools/eval_trunk_bench.py
+"""Inference trunk pass (encoder.eval()) at B = 64: ms per pass.   python tools/probes/eval_trunk_bench.py
 CAPNET_EVAL_FOLDED=1: BatchNorms applied in the convolutions' epilogues (the previous inference path)."""
 import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import capnet
 from capnet import synthetic
 from capnet.model import EncoderCNN

@@ -1,11 +1,11 @@
 """Times csrc/fused_block.hip's launches alone on the trunk's stage shapes (batch 64) beside the launches they replace:
-conv3 (conv_f16x3_kernel) + bn_finalize + tail/conv1 (conv1x1_tail_kernel).   python tools/fused_block_bench.py"""
+conv3 (conv_f16x3_kernel) + bn_finalize + tail/conv1 (conv1x1_tail_kernel).   python tools/probes/fused_block_bench.py"""
 import os
 import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import capnet  # noqa: E402,F401
 from capnet import ops  # noqa: E402
 from capnet._lib import check, current_stream, lib, ptr  # noqa: E402

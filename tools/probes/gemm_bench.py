@@ -1,11 +1,11 @@
 """Micro-benchmark of the plain GEMM kernel on the decoder's all-rows shapes (N = 1037 packed rows).
-    python tools/gemm_bench.py"""
+    python tools/probes/gemm_bench.py"""
 import os
 import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import capnet  # noqa: E402
 from capnet._lib import check, current_stream, lib, ptr  # noqa: E402
 

@@ -1,7 +1,7 @@
 """Throughput of the LDS-DMA NT core (csrc/gemm_dma.hip) on the trunk's 1x1 shapes and the vocabulary
 projection, next to the kernels it replaces."""
 import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import capnet
 from capnet import ops
 from capnet._lib import check, current_stream, lib, ptr

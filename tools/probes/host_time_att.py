@@ -1,7 +1,7 @@
 """Diagnostic: host-side time of one attention train step, by phase (no GPU sync inside)."""
 import os, sys, time, random, cProfile, pstats
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import capnet
 from capnet import synthetic, model_att
 from capnet.optim import Adam

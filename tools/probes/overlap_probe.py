@@ -3,7 +3,7 @@ stream B: a dependent chain of fused LSTM steps (tiny, latency-bound). Prints A 
 A and B together."""
 import os, sys, time
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import capnet
 from capnet import synthetic
 from capnet._lib import lib, check, current_stream

@@ -1,7 +1,7 @@
 """The trunk's stride-1 3x3 shapes at B = 64: patch-in-LDS kernel against the implicit-GEMM split-f16 kernel.
-    python tools/patch_bench.py"""
+    python tools/probes/patch_bench.py"""
 import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import capnet
 from capnet import ops
 from capnet._lib import check, lib, ptr, current_stream

@@ -1,6 +1,6 @@
 #!/bin/bash
 # SQ counters of one conv_bench run, one rocprofv3 pass per counter group (kernel-trace only).
-#   bash tools/pmc_sq.sh <tag> <conv_bench args...>   ->  gpurun_out/sq_<tag>.txt
+#   bash tools/probes/pmc_sq.sh <tag> <conv_bench args...>   ->  gpurun_out/sq_<tag>.txt
 set -o pipefail
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=$1; shift
@@ -15,7 +15,7 @@ for grp in "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_U
            "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM"; do
   i=$((i+1))
   timeout -k 10 200 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/g$i -o p -- \
-    python3 $ROOT/tools/conv_bench.py "$@" > $OUT/g$i.log 2>&1 || { tail -5 $OUT/g$i.log; exit 1; }
+    python3 $ROOT/tools/probes/conv_bench.py "$@" > $OUT/g$i.log 2>&1 || { tail -5 $OUT/g$i.log; exit 1; }
 done
 python3 - $OUT <<'P' > $ROOT/gpurun_out/sq_$TAG.txt
 import csv, glob, sys, os

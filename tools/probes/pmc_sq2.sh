@@ -1,6 +1,6 @@
 #!/bin/bash
 # SQ counters of any script, one rocprofv3 pass per counter group (kernel-trace only).
-#   bash tools/pmc_sq2.sh <tag> <kernel-name-substring> <script.py> [args...]  ->  gpurun_out/sq_<tag>.txt
+#   bash tools/probes/pmc_sq2.sh <tag> <kernel-name-substring> <script.py> [args...]  ->  gpurun_out/sq_<tag>.txt
 set -o pipefail
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=$1; FILT=$2; shift 2

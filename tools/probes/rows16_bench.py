@@ -1,8 +1,8 @@
 """gemm_rows16_kernel (csrc/gemm_f32.hip) on the step products of a 12-image attention batch, against the two-launch
 path (skinny kernel + slab reduce): us per call in a back-to-back loop, same box.
-    python tools/rows16_bench.py"""
+    python tools/probes/rows16_bench.py"""
 import os, subprocess, sys, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 SHAPES = [(12, 4608, 512, 1), (12, 2048, 2348, 1), (12, 512, 4608, 0), (12, 2348, 2048, 0), (12, 8192, 512, 1), (12, 512, 512, 1)]
 if len(sys.argv) > 1 and sys.argv[1] == "child":
     import torch, capnet

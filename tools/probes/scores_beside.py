@@ -1,11 +1,11 @@
 """att_scores_fwd_kernel with its per-lane partial sums kept, beside a conv kernel: which lanes, which values go wrong?
-    python tools/scores_beside.py [h3|none]"""
+    python tools/probes/scores_beside.py [h3|none]"""
 import ctypes as C, os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import capnet
 from capnet._lib import check, lib, ptr
 dev = torch.device("cuda:0"); L = lib()
-Pl = C.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "build", "libbperm_probe.so"))
+Pl = C.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "build", "libbperm_probe.so"))
 Pl.launch_scores_probe.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
 KIND = sys.argv[1] if len(sys.argv) > 1 else "h3"
 Bc, H, Cin, Cout = 64, 28, 512, 128

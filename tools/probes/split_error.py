@@ -1,7 +1,7 @@
 """numpy model of the split-operand dot products (fp32 accumulation over k16 groups, as the MFMA does): rms error against
 fp64 of the fp32 fma chain, the 3-way bf16 split (six products, csrc/conv_bf16x6.hip), the 2-way f16 split (three products,
 csrc/conv_f16x3.hip) with and without power-of-two prescaling and with f16 subnormals flushed.
-    python tools/split_error.py"""
+    python tools/probes/split_error.py"""
 import numpy as np
 rng = np.random.default_rng(0)
 def bf16(x):

@@ -1,7 +1,7 @@
 """The stem convolution alone at B = 64, 224 x 224: split-f16 kernel against the generic f32 gather kernel.
-    python tools/stem_bench.py"""
+    python tools/probes/stem_bench.py"""
 import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import capnet
 from capnet import ops
 from capnet._lib import check, lib, ptr, current_stream

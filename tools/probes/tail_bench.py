@@ -1,7 +1,7 @@
 """A block's tail fused into the next conv1 (capnet_conv1x1_fwd_tail) alone on the chip at B = 64, against the two
-launches it replaces (capnet_bn_add_relu + capnet_conv1x1_fwd_f16x3).   python tools/tail_bench.py"""
+launches it replaces (capnet_bn_add_relu + capnet_conv1x1_fwd_f16x3).   python tools/probes/tail_bench.py"""
 import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import capnet
 from capnet import ops
 from capnet._lib import check, lib, ptr, current_stream

@@ -1,8 +1,8 @@
 """Trunk-only throughput with D passes in flight on D streams (what TrunkPipeline does, without any decoder): ms per pass
-at B = 64. The full train step cannot be faster than this.   python tools/trunk_depth_probe.py"""
+at B = 64. The full train step cannot be faster than this.   python tools/probes/trunk_depth_probe.py"""
 import os, sys, time
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import capnet
 from capnet import synthetic
 from capnet.model import EncoderCNN

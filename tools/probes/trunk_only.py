@@ -1,7 +1,7 @@
 """Time of the ResNet-152 trunk alone (train-mode BN, B=64), for comparison with the pipelined step."""
 import os, sys, time
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import capnet
 from capnet import synthetic
 from capnet.model import EncoderCNN

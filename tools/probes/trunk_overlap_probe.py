@@ -1,7 +1,7 @@
 """Diagnostic: two independent ResNet-152 trunk passes (train-mode BN, B=64) on two streams vs back to back."""
 import os, sys, time
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import capnet
 from capnet import synthetic
 from capnet.model import EncoderCNN
