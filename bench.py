@@ -454,16 +454,14 @@ def main():
             peak_equiv = algo / t_peak
             per_s = achieved / algo          # TFLOP/s per algorithmic flop of a pass
             roofline = {"bound": "mfma",
-                        "kernel": "the trunk's 155 conv launches, all on three v_mfma_f32_32x32x16_f16 products of 2-way "
-                                  "split fp32 operands per multiply (fp32-grade results): conv_f16x3_kernel (the 50 conv3, the 4 "
-                                  "downsample convs, the first conv1 and the 3 strided 3x3 ones, implicit GEMM over (tap, "
-                                  "channel)), conv1x1_tail_kernel "
-                                  "(the 49 conv1 that absorb the previous block's bn_add_relu tail: its three passes over the "
-                                  "block output are inside these launches' time; CAPNET_NO_TAIL_FUSION=1 separates them), "
-                                  "conv3x3_patch_kernel (the 47 stride-1 3x3 convs, input patch resident in LDS; "
-                                  "CAPNET_NO_P3=1 puts them back on conv_f16x3_kernel) and "
-                                  "conv_stem_f16x3_kernel (K = 147 issued as 176) for the 7x7 stem; "
-                                  "CAPNET_NO_STEM_H3=1 puts the stem, CAPNET_NO_H3=1 everything on the f32-MFMA kernels",
+                        "kernel": "the trunk's 155 convolutions, all on three f16 MFMA products of 2-way split fp32 operands per "
+                                  "multiply (fp32-grade results): fb_fused_kernel (the 44 block boundaries inside stages 1-3: conv3 + "
+                                  "bn3 + residual + ReLU + the next conv1 in one launch that never forms y3; its BatchNorm statistics "
+                                  "come from the Gram matrix of conv3's input -- fb_gram / fb_gram_reduce / fb_quad launches, timed here "
+                                  "with zero flops; CAPNET_NO_FUSED_BLOCK=1 restores the y3 data flow), conv3x3_patch_kernel (the 47 "
+                                  "stride-1 3x3 convs), conv_f16x3_kernel (strided 3x3, downsample, first conv1, conv3 at stage "
+                                  "transitions / stage 4), conv1x1_tail_kernel (the 5 conv1 that absorb a materialised tail), "
+                                  "conv_stem_f16x3_kernel (K = 147 issued as 176); CAPNET_NO_H3=1 puts everything on the f32-MFMA kernels",
                         "flops": "ALGORITHMIC: 2*M*Cout*KH*KW*Cin of the direct sum (SURVEY 8d: 23.02 GFLOP per image)",
                         "peak_is": "algorithmic flops / (time the f32 matrix pipe needs for what is issued on it at "
                                    "157.3 TFLOP/s + time the 16-bit matrix pipe needs for its share at 2500 TFLOP/s): "

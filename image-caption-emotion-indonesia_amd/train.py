@@ -434,7 +434,11 @@ def evaluate(encoder, decoder, vocab, data_loader, mode='factual', k=5, device=N
     for images, captions, lengths, all_captions in data_loader:
         with torch.no_grad():
             features = encoder(images.to(device))
-        seqs = decoder.sample_batch(features, start_token=start, end_token=end, k=k, **kw)
+        if hasattr(decoder, "sample_batch"):
+            seqs = decoder.sample_batch(features, start_token=start, end_token=end, k=k, **kw)
+        else:       # (nic DecoderRNNAtt: image by image, as the reference does)
+            seqs = [decoder.sample(features[i:i + 1], start_token=start, end_token=end, k=k, **kw)[0].tolist()
+                    for i in range(features.size(0))]
         for sampled_ids, caps in zip(seqs, all_captions):
             caps = [[int(w) for w in (c.tolist() if hasattr(c, "tolist") else c)] for c in caps]
             references.append(caps)

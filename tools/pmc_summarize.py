@@ -41,8 +41,12 @@ def main():
         for k, v in sorted(fetch.items(), key=lambda kv: -(2 * kv[1][1] + write.get(kv[0], [0, 0])[1]))[:14]:
             print("%s,%d,%.0f,%.0f" % (k.replace(",", ";"), v[0], v[1], write.get(k, [0, 0])[1]))
         return
-    convk = ("conv_f32", "conv_f16x3_kernel", "conv3x3_patch_kernel", "conv_stem_f16x3_kernel", "conv1x1_tail_kernel", "conv1x1_areg_kernel")
-    conv = lambda n: any(k in n for k in convk) or "conv_tail_fixup" in n
+    # round 4: a block boundary on fused_block.hip is two "launches" of the bench's roofline as well -- the statistics group
+    # (fb_gram_kernel counted, its reduce / quadratic-form launches only add their bytes) in conv3's place and the fused
+    # launch in the next conv1's
+    convk = ("conv_f32", "conv_f16x3_kernel", "conv3x3_patch_kernel", "conv_stem_f16x3_kernel", "conv1x1_tail_kernel", "conv1x1_areg_kernel",
+             "fb_fused_kernel", "fb_gram_kernel")
+    conv = lambda n: any(k in n for k in convk) or "conv_tail_fixup" in n or "fb_gram_reduce_kernel" in n or "fb_quad_kernel" in n
     launches = sum(v[0] for k, v in fetch.items() if any(c in k for c in convk))   # fix-ups belong to a conv
     fetch_kb = sum(v[1] for k, v in fetch.items() if conv(k))
     write_kb = sum(v[1] for k, v in write.items() if conv(k))
@@ -58,6 +62,12 @@ def main():
     st = lambda n: "conv_stem_f16x3_kernel" in n
     st_n = sum(v[0] for k, v in fetch.items() if st(k))
     st_bytes = (2.0 * sum(v[1] for k, v in fetch.items() if st(k)) + sum(v[1] for k, v in write.items() if st(k))) * 1024.0
+    fu = lambda n: "fb_fused_kernel" in n
+    fu_n = sum(v[0] for k, v in fetch.items() if fu(k))
+    fu_bytes = (2.0 * sum(v[1] for k, v in fetch.items() if fu(k)) + sum(v[1] for k, v in write.items() if fu(k))) * 1024.0
+    gs = lambda n: "fb_gram_kernel" in n or "fb_gram_reduce_kernel" in n or "fb_quad_kernel" in n
+    gs_n = sum(v[0] for k, v in fetch.items() if "fb_gram_kernel" in k)
+    gs_bytes = (2.0 * sum(v[1] for k, v in fetch.items() if gs(k)) + sum(v[1] for k, v in write.items() if gs(k))) * 1024.0
     lp = lambda n: "lstm_persist_kernel" in n
     lp_n = sum(v[0] for k, v in fetch.items() if lp(k))
     lp_bytes = (2.0 * sum(v[1] for k, v in fetch.items() if lp(k)) + sum(v[1] for k, v in write.items() if lp(k))) * 1024.0
@@ -82,6 +92,13 @@ def main():
         "patch3x3_bytes_per_launch": round(p3_bytes / max(p3_n, 1)),
         "tail_conv1_launches": tl_n,
         "tail_conv1_bytes_per_launch": round(tl_bytes / max(tl_n, 1)),
+        "fused_boundary_launches": fu_n,
+        "fused_boundary_bytes_per_launch": round(fu_bytes / max(fu_n, 1)),
+        "boundary_statistics_groups": gs_n,
+        "boundary_statistics_bytes_per_group": round(gs_bytes / max(gs_n, 1)),
+        # the 44 inner boundaries of stages 1-3 no longer write and re-read y3 (2 x 2 434 MB per pass at B = 64) nor re-read
+        # the block output for conv1: what remains per boundary is y2 twice, identity, out, y1
+        "algorithmic_bytes_per_launch_with_fused_boundaries": round((232e6 + 2 * 90e6 * 64 + 2 * 3288e6 - 2 * 2434e6 + 44 * 0) / 155),
         "stem_launches": st_n,
         "stem_bytes_per_launch": round(st_bytes / max(st_n, 1)),
         "lstm_persist_launches": lp_n,
