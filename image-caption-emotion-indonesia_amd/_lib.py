@@ -100,6 +100,10 @@ SIGNATURES = {
                                 _vp]),
     "capnet_seq_backward": (_i, [_ip, _ip, _vp, _vp, _vp, _vp, _vp, C.POINTER(_vp), C.c_float,
                                  C.c_ulonglong, _i, _vp]),
+    "capnet_seq_forward_stacked": (_i, [_ip, _i, _ip, _vp, _vp, _vp, _vp, C.POINTER(_vp), _vp, _vp, C.c_float, C.c_ulonglong, _i,
+                                        C.POINTER(_vp), C.POINTER(_vp), _vp, C.POINTER(_vp), _vp, _vp]),
+    "capnet_seq_backward_stacked": (_i, [_ip, _i, _ip, _vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _vp, C.POINTER(_vp),
+                                         C.POINTER(_vp), C.c_float, C.c_ulonglong, _i, _vp]),
     "capnet_att_saved_floats": (_sz, [_ip]),
     "capnet_att_saved_ints": (_sz, [_ip]),
     "capnet_att_fwd_scratch_floats": (_sz, [_ip]),

@@ -388,6 +388,47 @@ int capnet_seq_backward(const int* dims, const int* batch_sizes, const float* d_
                       dropout_p, seed, training, S(stream));
 }
 
+static void to_weights(const float* const* weights, SeqWeights& w) {
+  for (int g = 0; g < 4; ++g) {
+    w.Vw[g] = weights[0 + g];  w.Vb[g] = weights[4 + g];
+    w.Sw[g] = weights[8 + g];  w.Sb[g] = weights[12 + g];
+    w.Uw[g] = weights[16 + g]; w.Ub[g] = weights[20 + g];
+    w.Ww[g] = weights[24 + g]; w.Wb[g] = weights[28 + g];
+  }
+}
+
+int capnet_seq_forward_stacked(const int* dims, int nlayers, const int* batch_sizes, const unsigned char* tf_mask,
+                               const long long* captions, const float* features, const float* emb,
+                               const float* const* weights, const float* Cw, const float* Cb, float dropout_p,
+                               unsigned long long seed, int training, float* const* saved, int* const* saved_i,
+                               float* scratch, float* const* hiddens, int* err_flag, capnet_stream_t stream) {
+  CAPNET_REQUIRE(dims && weights && nlayers >= 1 && nlayers <= 8, "seq_forward_stacked: null dims / weights or layers %d", nlayers);
+  const SeqDims d = to_dims(dims);
+  CAPNET_REQUIRE(d.cell == kCellFactored, "seq_forward_stacked: the factored cell only");
+  SeqWeights w[8];
+  for (int l = 0; l < nlayers; ++l) {
+    for (int i = 0; i < 32; ++i) CAPNET_REQUIRE(weights[32 * l + i], "seq_forward_stacked: weight %d of layer %d is null", i, l);
+    to_weights(weights + 32 * l, w[l]);
+  }
+  return seq_forward_stacked(d, nlayers, batch_sizes, tf_mask, captions, features, emb, w, Cw, Cb, dropout_p, seed, training,
+                             saved, saved_i, scratch, hiddens, err_flag, S(stream));
+}
+
+int capnet_seq_backward_stacked(const int* dims, int nlayers, const int* batch_sizes, const float* d_hiddens,
+                                const float* const* hiddens, const float* const* saved, const int* const* saved_i,
+                                float* scratch, float* const* dh_work, float* const* grads, float dropout_p,
+                                unsigned long long seed, int training, capnet_stream_t stream) {
+  CAPNET_REQUIRE(dims && grads && nlayers >= 1 && nlayers <= 8, "seq_backward_stacked: null dims / grads or layers %d", nlayers);
+  SeqGrads g[8];
+  for (int l = 0; l < nlayers; ++l) {
+    float* const* q = grads + 9 * l;
+    g[l].dVcat = q[0]; g[l].dbV = q[1]; g[l].dScat = q[2]; g[l].dbS = q[3]; g[l].dUcat = q[4];
+    g[l].dbUW = q[5]; g[l].dWcat = q[6]; g[l].dEmb = q[7]; g[l].dFeat = q[8];
+  }
+  return seq_backward_stacked(to_dims(dims), nlayers, batch_sizes, d_hiddens, hiddens, saved, saved_i, scratch, dh_work, g,
+                              dropout_p, seed, training, S(stream));
+}
+
 static AttDims to_adims(const int* d) {
   AttDims r;
   r.B = d[0]; r.T = d[1]; r.steps = d[2]; r.N = d[3]; r.E = d[4]; r.F = d[5]; r.H = d[6];

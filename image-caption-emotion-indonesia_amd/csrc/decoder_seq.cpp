@@ -144,38 +144,25 @@ size_t seq_bwd_scratch_floats(const SeqDims& d) {
   return n;
 }
 
-int seq_forward(const SeqDims& d, const int* batch_sizes, const unsigned char* tf_mask,
-                const long long* captions, const float* features, const float* emb,
-                const SeqWeights& w, const float* Cw, const float* Cb, float dropout_p,
-                unsigned long long seed, int training, float* saved, int* saved_i, float* scratch,
-                float* hiddens, int* err_flag, hipStream_t s) {
-  RC(check_dims(d, batch_sizes));
-  CAPNET_REQUIRE(tf_mask && captions && emb && saved && saved_i && scratch && hiddens && err_flag,
-                 "seq_forward: null argument");
-  CAPNET_REQUIRE(!d.has_features || features, "seq_forward: features missing");
-  CAPNET_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "seq_forward: dropout p=%f", dropout_p);
-  const Layout L = make_layout(d);
-  const int E = d.E, F = d.F, H = d.H, N = d.N;
+namespace {
+// one layer of the (possibly stacked) recurrence: its dims (E = its input width), saved buffers and output rows
+struct LayerCtx {
+  SeqDims d;
+  Layout L;
+  float* sv;
+  int* svi;
+  float* hid;
+  bool fused_step = false, persist = false;
+  int segment = 0;
+};
+
+// gate-concatenated weight copies, the fused-step fragment image and the persistent kernel's image
+int pack_layer(LayerCtx& c, const SeqWeights& w, const int* batch_sizes, hipStream_t s) {
+  const SeqDims& d = c.d;
+  const Layout& L = c.L;
+  float* sv = c.sv;
+  const int E = d.E, F = d.F, H = d.H;
   const GateOrder go = gate_order(d.cell);
-  bool any_free = false;
-  for (int t = 1; t < d.steps; ++t) any_free |= !tf_mask[t];
-  CAPNET_REQUIRE(!any_free || (Cw && Cb), "seq_forward: output projection needed for free-running steps");
-
-  // ---- row bookkeeping, built on device from kernel arguments (no copy, no sync)
-  CAPNET_REQUIRE(d.steps <= kMaxSteps, "seq_forward: %d steps > %d", d.steps, kMaxSteps);
-  std::vector<int> off(d.steps + 1, 0);
-  for (int t = 0; t < d.steps; ++t) off[t + 1] = off[t] + batch_sizes[t];
-  {
-    SeqMeta m;
-    m.N = N; m.steps = d.steps; m.has_features = d.has_features;
-    for (int t = 0; t <= d.steps; ++t) m.off[t] = off[t];
-    for (int t = 0; t < d.steps; ++t) m.tf[t] = tf_mask[t] ? 1 : 0;
-    RC(build_rows(m, saved_i + L.row_sample, saved_i + L.row_col, saved_i + L.row_token,
-                  saved_i + L.prev_row, s));
-  }
-
-  // ---- pack weights
-  float* sv = saved;
   if (d.cell == kCellFactored) {
     // gate-concatenated copies of the 4x6 per-gate tensors: one multi-tensor launch per group
     auto concat4 = [&](const float* const* src, size_t n, float* dst) -> int {
@@ -196,63 +183,41 @@ int seq_forward(const SeqDims& d, const int* batch_sizes, const unsigned char* t
     RC(copy_d2d(sv + L.Wcat, w.Ww[0], (size_t)4 * H * H, s));
     RC(vec_add(w.Vb[0], w.Wb[0], sv + L.bUW, 4 * H, s));
   }
-
-  bool fused_step = H % 16 == 0 && lstm_step_fused_supported(batch_sizes[0], H);
-  if (fused_step) RC(lstm_pack_wfrag(sv + L.Wcat, sv + L.Wfrag, H, go.gi, go.gf, go.go, go.gg, s));
+  c.fused_step = H % 16 == 0 && lstm_step_fused_supported(batch_sizes[0], H);
+  if (c.fused_step) RC(lstm_pack_wfrag(sv + L.Wcat, sv + L.Wfrag, H, go.gi, go.gf, go.go, go.gg, s));
   // runs of teacher-forced steps go to ONE launch of the persistent kernel (csrc/lstm_persist.hip)
-  const bool persist = lstm_persist_supported(batch_sizes[0], H);
-  if (persist) {
+  c.persist = lstm_persist_supported(batch_sizes[0], H);
+  if (c.persist) {
     RC(lstm_persist_pack(sv + L.Wcat, sv + L.Wp, go.gi, go.gf, go.go, go.gg, s));
-    CAPNET_HIP_CHECK(hipMemsetAsync(saved_i + L.ctl, 0, lstm_persist_ctl_ints() * sizeof(int), s));
+    CAPNET_HIP_CHECK(hipMemsetAsync(c.svi + L.ctl, 0, lstm_persist_ctl_ints() * sizeof(int), s));
   }
-  int segment = 0;
+  c.segment = 0;
+  return kOk;
+}
 
-  // ---- inputs + input chain for every row whose input is known up front
-  CAPNET_HIP_CHECK(hipMemsetAsync(sv + L.X, 0, (size_t)N * E * sizeof(float), s));
-  RC(gather_inputs(captions, d.T, features, emb, E, d.V, saved_i + L.row_sample,
-                   saved_i + L.row_col, saved_i + L.row_token, sv + L.X, E, 0, N, dropout_p, seed,
-                   training && dropout_p > 0.f, 0, err_flag, s));
-  float* skws = scratch + (size_t)d.B * d.V + 64;
-  int* skctr = reinterpret_cast<int*>(skws + kSplitKWs);
-  CAPNET_HIP_CHECK(hipMemsetAsync(skctr, 0, kSplitKCounters * sizeof(int), s));
-  RC(input_chain(d, L, sv, 0, N, skws, kSplitKWs, s, skctr));
-
-  // ---- recurrence
-  for (int t = 0; t < d.steps; ++t) {
-    const int b = batch_sizes[t], r0 = off[t];
-    if (t > 0) {
-      const float* h_prev = hiddens + (size_t)off[t - 1] * H;
-      if (!tf_mask[t]) {
-        // predicted = argmax(C h_{t-1}) for the b surviving rows; then this step's input chain
-        RC(sgemm_splitk(false, true, b, d.V, H, h_prev, H, Cw, H, scratch, d.V, Cb, 0, skws,
-                        kSplitKWs, s, skctr, kSplitKCounters));
-        RC(argmax_rows(scratch, b, d.V, d.V, saved_i + L.row_token + r0, s));
-        RC(gather_inputs(captions, d.T, features, emb, E, d.V, saved_i + L.row_sample,
-                         saved_i + L.row_col, saved_i + L.row_token, sv + L.X, E, r0, r0 + b,
-                         dropout_p, seed, 0, 1, err_flag, s));
-        RC(input_chain(d, L, sv, r0, r0 + b, skws, kSplitKWs, s, skctr));
-      }
-    }
-    if (persist) {
-      // steps t .. t1-1: t's input is ready, the following ones are teacher forced
-      int t1 = t + 1;
-      while (t1 < d.steps && tf_mask[t1]) ++t1;
-      const bool single_fused = t1 == t + 1 && t > 0 && fused_step;   // one free-running step: no weights to keep
-      if (!single_fused) {
-        RC(lstm_persist_run(sv + L.Wp, sv + L.G, sv + L.Cst, hiddens, off.data(), batch_sizes, t, t1, H,
-                            go.gi, go.gf, go.go, go.gg, go.tanh_out, ++segment, saved_i + L.ctl,
-                            err_flag, s, nullptr));
-        t = t1 - 1;
-        continue;
-      }
-    }
-    if (t > 0) {
-      const float* h_prev = hiddens + (size_t)off[t - 1] * H;
-      if (fused_step) {
+// steps [t, t1) of one layer: step t's gate pre-activations (without the recurrent product) are in G, the following
+// steps are teacher forced. One persistent launch where the kernel takes the size, else step by step.
+int recur(LayerCtx& c, const std::vector<int>& off, const int* batch_sizes, int t, int t1, float* skws, int* skctr,
+          int* err_flag, hipStream_t s) {
+  const SeqDims& d = c.d;
+  const Layout& L = c.L;
+  float* sv = c.sv;
+  const int H = d.H;
+  const GateOrder go = gate_order(d.cell);
+  const bool single_fused = t1 == t + 1 && t > 0 && c.fused_step;   // one free-running step: no weights to keep
+  if (c.persist && !single_fused) {
+    return lstm_persist_run(sv + L.Wp, sv + L.G, sv + L.Cst, c.hid, off.data(), batch_sizes, t, t1, H, go.gi, go.gf, go.go,
+                            go.gg, go.tanh_out, ++c.segment, c.svi + L.ctl, err_flag, s, nullptr);
+  }
+  for (int u = t; u < t1; ++u) {
+    const int b = batch_sizes[u], r0 = off[u];
+    if (u > 0) {
+      const float* h_prev = c.hid + (size_t)off[u - 1] * H;
+      if (c.fused_step) {
         // gates += h_{t-1} . Wcat^T, activations and the c/h update in one launch
         RC(lstm_step_fused(h_prev, sv + L.Wfrag, sv + L.G + (size_t)r0 * 4 * H, 4 * H,
-                           sv + L.Cst + (size_t)off[t - 1] * H, sv + L.Cst + (size_t)r0 * H,
-                           hiddens + (size_t)r0 * H, b, H, go.gi, go.gf, go.go, go.gg, go.tanh_out, s));
+                           sv + L.Cst + (size_t)off[u - 1] * H, sv + L.Cst + (size_t)r0 * H,
+                           c.hid + (size_t)r0 * H, b, H, go.gi, go.gf, go.go, go.gg, go.tanh_out, s));
         continue;
       }
       // G[rows] += h_{t-1} . Wcat^T
@@ -260,19 +225,126 @@ int seq_forward(const SeqDims& d, const int* batch_sizes, const unsigned char* t
                       sv + L.G + (size_t)r0 * 4 * H, 4 * H, nullptr, 1, skws, kSplitKWs, s, skctr, kSplitKCounters));
     }
     RC(lstm_pointwise_fwd(sv + L.G + (size_t)r0 * 4 * H, 4 * H,
-                          t > 0 ? sv + L.Cst + (size_t)off[t - 1] * H : nullptr,
-                          sv + L.Cst + (size_t)r0 * H, hiddens + (size_t)r0 * H, b, H, go.gi, go.gf,
+                          u > 0 ? sv + L.Cst + (size_t)off[u - 1] * H : nullptr,
+                          sv + L.Cst + (size_t)r0 * H, c.hid + (size_t)r0 * H, b, H, go.gi, go.gf,
                           go.go, go.gg, go.tanh_out, s));
   }
   return kOk;
 }
 
-int seq_backward(const SeqDims& d, const int* batch_sizes, const float* dH, const float* hiddens,
-                 const float* saved, const int* saved_i, float* scratch, const SeqGrads& g,
-                 float dropout_p, unsigned long long seed, int training, hipStream_t s) {
+SeqDims upper_dims(const SeqDims& d0) {
+  SeqDims d = d0;
+  d.E = d0.H;               // a layer above the first reads the hidden state of the layer below
+  d.has_features = 0;
+  return d;
+}
+}  // namespace
+
+SeqDims seq_upper_dims(const SeqDims& d0) { return upper_dims(d0); }
+
+// nlayers stacked cells (capnet.stacked: SURVEY App. A-1's semantics, PERF-ONLY / PARITY UNPINNED -- the reference ignores
+// num_layers, stylenet/model.py:37): layer 0 is seq_forward's cell on [feature, dropout(B(w))...]; layer l > 0 is the same
+// cell on dropout(hidden of layer l - 1) at the same step; the top layer's hidden feeds C on free-running steps.
+// Runs of teacher-forced steps outside, layers inside: a run's rows go up the stack before the next run starts (a
+// free-running step's input needs the TOP layer's previous hidden state).
+int seq_forward_stacked(const SeqDims& d0, int nlayers, const int* batch_sizes, const unsigned char* tf_mask,
+                        const long long* captions, const float* features, const float* emb, const SeqWeights* w,
+                        const float* Cw, const float* Cb, float dropout_p, unsigned long long seed, int training,
+                        float* const* saved, int* const* saved_i, float* scratch, float* const* hiddens, int* err_flag,
+                        hipStream_t s) {
+  RC(check_dims(d0, batch_sizes));
+  CAPNET_REQUIRE(nlayers >= 1 && nlayers <= 8 && w && saved && saved_i && hiddens, "seq_forward_stacked: bad argument");
+  CAPNET_REQUIRE(tf_mask && captions && emb && scratch && err_flag, "seq_forward: null argument");
+  CAPNET_REQUIRE(!d0.has_features || features, "seq_forward: features missing");
+  CAPNET_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "seq_forward: dropout p=%f", dropout_p);
+  CAPNET_REQUIRE(nlayers == 1 || d0.cell == kCellFactored, "seq_forward_stacked: stacked layers are the factored cell's");
+  const int E = d0.E, N = d0.N, H = d0.H;
+  bool any_free = false;
+  for (int t = 1; t < d0.steps; ++t) any_free |= !tf_mask[t];
+  CAPNET_REQUIRE(!any_free || (Cw && Cb), "seq_forward: output projection needed for free-running steps");
+  CAPNET_REQUIRE(d0.steps <= kMaxSteps, "seq_forward: %d steps > %d", d0.steps, kMaxSteps);
+  std::vector<int> off(d0.steps + 1, 0);
+  for (int t = 0; t < d0.steps; ++t) off[t + 1] = off[t] + batch_sizes[t];
+
+  std::vector<LayerCtx> lay(nlayers);
+  for (int l = 0; l < nlayers; ++l) {
+    CAPNET_REQUIRE(saved[l] && saved_i[l] && hiddens[l], "seq_forward: null buffer of layer %d", l);
+    lay[l].d = l == 0 ? d0 : upper_dims(d0);
+    lay[l].L = make_layout(lay[l].d);
+    lay[l].sv = saved[l]; lay[l].svi = saved_i[l]; lay[l].hid = hiddens[l];
+    // ---- row bookkeeping, built on device from kernel arguments (no copy, no sync)
+    SeqMeta m;
+    m.N = N; m.steps = d0.steps; m.has_features = d0.has_features;
+    for (int t = 0; t <= d0.steps; ++t) m.off[t] = off[t];
+    for (int t = 0; t < d0.steps; ++t) m.tf[t] = tf_mask[t] ? 1 : 0;
+    RC(build_rows(m, lay[l].svi + lay[l].L.row_sample, lay[l].svi + lay[l].L.row_col, lay[l].svi + lay[l].L.row_token,
+                  lay[l].svi + lay[l].L.prev_row, s));
+    RC(pack_layer(lay[l], w[l], batch_sizes, s));
+  }
+  LayerCtx& c0 = lay[0];
+  LayerCtx& top = lay[nlayers - 1];
+
+  // ---- layer 0: inputs + input chain for every row whose input is known up front
+  CAPNET_HIP_CHECK(hipMemsetAsync(c0.sv + c0.L.X, 0, (size_t)N * E * sizeof(float), s));
+  RC(gather_inputs(captions, d0.T, features, emb, E, d0.V, c0.svi + c0.L.row_sample, c0.svi + c0.L.row_col,
+                   c0.svi + c0.L.row_token, c0.sv + c0.L.X, E, 0, N, dropout_p, seed, training && dropout_p > 0.f, 0,
+                   err_flag, s));
+  float* skws = scratch + (size_t)d0.B * d0.V + 64;
+  int* skctr = reinterpret_cast<int*>(skws + kSplitKWs);
+  CAPNET_HIP_CHECK(hipMemsetAsync(skctr, 0, kSplitKCounters * sizeof(int), s));
+  RC(input_chain(c0.d, c0.L, c0.sv, 0, N, skws, kSplitKWs, s, skctr));
+
+  // ---- recurrence, run by run
+  for (int t = 0; t < d0.steps;) {
+    int t1 = t + 1;
+    while (t1 < d0.steps && tf_mask[t1]) ++t1;
+    const int b = batch_sizes[t], r0 = off[t], r1 = off[t1];
+    if (t > 0 && !tf_mask[t]) {
+      // predicted = argmax(C h_{t-1}) of the TOP layer for the b surviving rows; then this step's input chain
+      const float* h_prev = top.hid + (size_t)off[t - 1] * H;
+      RC(sgemm_splitk(false, true, b, d0.V, H, h_prev, H, Cw, H, scratch, d0.V, Cb, 0, skws, kSplitKWs, s, skctr,
+                      kSplitKCounters));
+      RC(argmax_rows(scratch, b, d0.V, d0.V, c0.svi + c0.L.row_token + r0, s));
+      RC(gather_inputs(captions, d0.T, features, emb, E, d0.V, c0.svi + c0.L.row_sample, c0.svi + c0.L.row_col,
+                       c0.svi + c0.L.row_token, c0.sv + c0.L.X, E, r0, r0 + b, dropout_p, seed, 0, 1, err_flag, s));
+      RC(input_chain(c0.d, c0.L, c0.sv, r0, r0 + b, skws, kSplitKWs, s, skctr));
+    }
+    for (int l = 0; l < nlayers; ++l) {
+      LayerCtx& c = lay[l];
+      if (l > 0) {
+        // X_l = dropout(hidden of the layer below) for the run's rows, then its input chain
+        RC(rows_dropout(lay[l - 1].hid, c.sv + c.L.X, r0, r1, H, dropout_p, seed, l, training && dropout_p > 0.f, s));
+        RC(input_chain(c.d, c.L, c.sv, r0, r1, skws, kSplitKWs, s, skctr));
+      }
+      RC(recur(c, off, batch_sizes, t, t1, skws, skctr, err_flag, s));
+    }
+    t = t1;
+  }
+  return kOk;
+}
+
+int seq_forward(const SeqDims& d, const int* batch_sizes, const unsigned char* tf_mask,
+                const long long* captions, const float* features, const float* emb,
+                const SeqWeights& w, const float* Cw, const float* Cb, float dropout_p,
+                unsigned long long seed, int training, float* saved, int* saved_i, float* scratch,
+                float* hiddens, int* err_flag, hipStream_t s) {
+  CAPNET_REQUIRE(saved && saved_i && hiddens, "seq_forward: null argument");
+  float* sv[1] = {saved};
+  int* svi[1] = {saved_i};
+  float* hid[1] = {hiddens};
+  return seq_forward_stacked(d, 1, batch_sizes, tf_mask, captions, features, emb, &w, Cw, Cb, dropout_p, seed, training, sv,
+                             svi, scratch, hid, err_flag, s);
+}
+
+// layer > 0 (a stacked layer above the first): the input gradient goes to dH_below = d hidden of the layer below (through
+// the dropout between the layers) instead of the embedding / feature scatter
+static int seq_backward_layer(const SeqDims& d, const int* batch_sizes, const float* dH, const float* hiddens,
+                              const float* saved, const int* saved_i, float* scratch, const SeqGrads& g,
+                              float dropout_p, unsigned long long seed, int training, int layer, float* dH_below,
+                              hipStream_t s) {
   RC(check_dims(d, batch_sizes));
   CAPNET_REQUIRE(dH && hiddens && saved && saved_i && scratch, "seq_backward: null argument");
-  CAPNET_REQUIRE(g.dWcat && g.dbUW && g.dVcat && g.dEmb, "seq_backward: null gradient buffer");
+  CAPNET_REQUIRE(g.dWcat && g.dbUW && g.dVcat && (layer > 0 ? dH_below != nullptr : g.dEmb != nullptr), "seq_backward: null gradient buffer");
   const Layout L = make_layout(d);
   const int E = d.E, F = d.F, H = d.H, N = d.N;
   const GateOrder go = gate_order(d.cell);
@@ -345,11 +417,38 @@ int seq_backward(const SeqDims& d, const int* batch_sizes, const float* dH, cons
     RC(sgemm_splitk(false, false, N, E, 4 * H, dPre, 4 * H, sv + L.Vcat, E, dX, E, nullptr, 0, skws,
                     kSplitKFloats, s));
   }
+  if (layer > 0) return rows_dropout(dX, dH_below, 0, N, E, dropout_p, seed, layer, training && dropout_p > 0.f, s);
   CAPNET_HIP_CHECK(hipMemsetAsync(g.dEmb, 0, (size_t)d.V * E * sizeof(float), s));
   if (g.dFeat) CAPNET_HIP_CHECK(hipMemsetAsync(g.dFeat, 0, (size_t)d.B * E * sizeof(float), s));
   RC(scatter_input_grad(dX, E, N, E, saved_i + L.row_sample, saved_i + L.row_col,
                         saved_i + L.row_token, g.dEmb, g.dFeat, d.V, dropout_p, seed,
                         training && dropout_p > 0.f, s));
+  return kOk;
+}
+
+int seq_backward(const SeqDims& d, const int* batch_sizes, const float* dH, const float* hiddens,
+                 const float* saved, const int* saved_i, float* scratch, const SeqGrads& g,
+                 float dropout_p, unsigned long long seed, int training, hipStream_t s) {
+  return seq_backward_layer(d, batch_sizes, dH, hiddens, saved, saved_i, scratch, g, dropout_p, seed, training, 0, nullptr, s);
+}
+
+// BPTT of seq_forward_stacked, top layer first: a layer's whole backward through time, then its input gradient becomes the
+// hidden-state gradient of the layer below (only the top layer's hiddens have consumers outside the stack).
+// dH_work: nlayers - 1 buffers [N][H]; grads: one SeqGrads per layer (dEmb / dFeat of layer 0 only).
+int seq_backward_stacked(const SeqDims& d0, int nlayers, const int* batch_sizes, const float* dH_top,
+                         const float* const* hiddens, const float* const* saved, const int* const* saved_i, float* scratch,
+                         float* const* dH_work, const SeqGrads* g, float dropout_p, unsigned long long seed, int training,
+                         hipStream_t s) {
+  CAPNET_REQUIRE(nlayers >= 1 && nlayers <= 8 && hiddens && saved && saved_i && g && (nlayers == 1 || dH_work),
+                 "seq_backward_stacked: bad argument");
+  const float* dH = dH_top;
+  for (int l = nlayers - 1; l >= 0; --l) {
+    const SeqDims d = l == 0 ? d0 : upper_dims(d0);
+    float* below = l > 0 ? dH_work[l - 1] : nullptr;
+    RC(seq_backward_layer(d, batch_sizes, dH, hiddens[l], saved[l], saved_i[l], scratch, g[l], dropout_p, seed, training, l,
+                          below, s));
+    dH = below;
+  }
   return kOk;
 }
 

@@ -208,6 +208,10 @@ int colsum(const float* x, long ld, int rows, int C, float* out, int accumulate,
 // out[m][n] = sum_k slab[k][m][n] (+ bias[n]) (+ out[m][n]), fixed order (gemm_f32.hip)
 int reduce_slabs(const float* slab, int count, int M, int N, float* out, long ldc, const float* bias,
                  int accumulate, hipStream_t stream);
+// dst[r][e] = src[r][e] * mask(seed, layer, r, e) / keep for rows [r0, r1) of width C (the dropout between stacked layers;
+// use_dropout 0: a copy). The same call maps a gradient back through the mask.
+int rows_dropout(const float* src, float* dst, int r0, int r1, int C, float p, unsigned long long seed, int layer,
+                 int use_dropout, hipStream_t stream);
 int scatter_input_grad(const float* dX, long ldx, int N, int E, const int* row_sample, const int* row_col,
                        const int* row_token, float* dEmb, float* dFeat, int V, float p,
                        unsigned long long seed, int use_dropout, hipStream_t stream);
@@ -327,6 +331,16 @@ int seq_forward(const SeqDims& d, const int* batch_sizes, const unsigned char* t
                 const SeqWeights& w, const float* Cw, const float* Cb, float dropout_p,
                 unsigned long long seed, int training, float* saved, int* saved_i, float* scratch,
                 float* hiddens, int* err_flag, hipStream_t s);
+SeqDims seq_upper_dims(const SeqDims& d0);
+int seq_forward_stacked(const SeqDims& d0, int nlayers, const int* batch_sizes, const unsigned char* tf_mask,
+                        const long long* captions, const float* features, const float* emb, const SeqWeights* w,
+                        const float* Cw, const float* Cb, float dropout_p, unsigned long long seed, int training,
+                        float* const* saved, int* const* saved_i, float* scratch, float* const* hiddens, int* err_flag,
+                        hipStream_t s);
+int seq_backward_stacked(const SeqDims& d0, int nlayers, const int* batch_sizes, const float* dH_top,
+                         const float* const* hiddens, const float* const* saved, const int* const* saved_i, float* scratch,
+                         float* const* dH_work, const SeqGrads* g, float dropout_p, unsigned long long seed, int training,
+                         hipStream_t s);
 int seq_backward(const SeqDims& d, const int* batch_sizes, const float* dH, const float* hiddens,
                  const float* saved, const int* saved_i, float* scratch, const SeqGrads& g,
                  float dropout_p, unsigned long long seed, int training, hipStream_t s);

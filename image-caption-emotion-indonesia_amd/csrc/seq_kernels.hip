@@ -471,6 +471,32 @@ int beam_topk_batched(const float* logits, long ld, int V, const float* prev, co
   return kOk;
 }
 
+// ---- dropout between stacked layers: dst = src * mask / keep over rows [r0, r1) ------------------------------------
+__global__ __launch_bounds__(256) void rows_dropout_kernel(const float* __restrict__ src, float* __restrict__ dst, int r0,
+                                                           int rows, int C, float p, unsigned long long seed, int layer,
+                                                           int use_dropout) {
+  const long total = (long)rows * C;
+  const float inv_keep = p < 1.f ? 1.f / (1.f - p) : 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int r = r0 + (int)(i / C), e = (int)(i % C);
+    float v = src[(long)r * C + e];
+    // (the mask's stream: the layer number stands where the input dropout has the caption column, offset out of its range)
+    if (use_dropout) v *= dropout_scale(seed, r, 0x40000000 + layer, e, p, inv_keep);
+    dst[(long)r * C + e] = v;
+  }
+}
+
+int rows_dropout(const float* src, float* dst, int r0, int r1, int C, float p, unsigned long long seed, int layer,
+                 int use_dropout, hipStream_t stream) {
+  CAPNET_REQUIRE(src && dst && r0 >= 0 && r1 >= r0 && C > 0, "rows_dropout: bad argument");
+  if (r1 == r0) return kOk;
+  const long total = (long)(r1 - r0) * C;
+  hipLaunchKernelGGL(rows_dropout_kernel, dim3((int)(cdiv(total, 256) > 2048 ? 2048 : cdiv(total, 256))), dim3(256), 0, stream,
+                     src, dst, r0, r1 - r0, C, p, seed, layer, use_dropout);
+  CAPNET_LAUNCH_CHECK();
+  return kOk;
+}
+
 // ---- out[r] = idx[r] >= 0 ? src[idx[r]] : 0  (rows of width C) ----------------------------
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src,
                                                           const int* __restrict__ idx,

@@ -15,7 +15,10 @@ tree to be equal to. The semantics built here are SURVEY.md App. A-1's, modelled
 With num_layers = 1 it is DecoderFactoredLSTM's function (tests/test_stacked_gpu.py); the numbers for more layers are
 checked against the same definition restated on the CPU (oracle/decoders_ref.py: stacked_factored_lstm_forward).
 
-Engine: runs of teacher-forced steps are processed layer by layer -- a layer's input chain U(S(V x)) over all rows of
+Engine (default, `engine = "c"`): the whole stacked recurrence is ONE C call each way (StackedSeqFn ->
+capnet_seq_forward_stacked / capnet_seq_backward_stacked, csrc/decoder_seq.cpp: the single-layer driver with a layer loop
+inside; embedding gather, dropout masks, chains, persistent runs, BPTT are all kernels of the library).
+The op-by-op engines of round 3 stay for comparison (`engine = "python"`): runs of teacher-forced steps are processed layer by layer -- a layer's input chain U(S(V x)) over all rows of
 the run as three MFMA GEMMs (the four gates' layers stacked: GateLinearFn), then the run's recurrence in ONE launch of the persistent kernel with its
 own backward through time (LstmRunFn below; H = 512, <= 128 rows) -- or, for a lone step and for sizes the persistent
 kernel does not take, step by step (W GEMM + the fused cell kernel, ops.lstm_cell, torch autograd composing the
@@ -156,6 +159,95 @@ class GateLinearFn(torch.autograd.Function):
         return dx, dw, ops.colsum(dy)
 
 
+class StackedSeqFn(torch.autograd.Function):
+    """The whole stacked recurrence as ONE C call each way (capnet_seq_forward_stacked / capnet_seq_backward_stacked,
+    csrc/decoder_seq.cpp): embedding gather, dropout masks (input and between layers), the gate chains, the persistent
+    runs, free-running steps and the full BPTT are kernels of the library; no torch operator on the path.
+        weights: num_layers x 32 tensors in DecoderSeqFn's order (V w x4, V b x4, S w x4, S b x4, U w x4, U b x4,
+        W w x4, W b x4), layer 0 first.  -> the top layer's hiddens [N, H] in pack_padded_sequence order."""
+
+    @staticmethod
+    def forward(ctx, cfg, captions, features, emb, Cw, Cb, *weights):
+        ops._need_cuda(captions, features, emb, Cw, Cb, *weights)
+        nl = cfg["num_layers"]
+        if len(weights) != 32 * nl:
+            raise CapnetError("stacked decoder takes 32 weight tensors per layer")
+        captions = captions.contiguous()
+        if captions.dtype != torch.int64:
+            raise CapnetError("captions must be int64")
+        dev = emb.device
+        bs, tf = cfg["batch_sizes"], cfg["tf_mask"]
+        B, T = captions.shape
+        V, E = emb.shape
+        H, F = cfg["hidden_size"], cfg["factored_size"]
+        N = sum(bs)
+        if len(tf) != len(bs) or bs[0] != B:
+            raise CapnetError("stacked decoder: batch_sizes / tf_mask do not match the batch")
+        if features is not None:
+            features = features.contiguous()
+            if tuple(features.shape) != (B, E):
+                raise CapnetError("features must be [batch, embed_size]")
+        dims = [[B, T, len(bs), N, E if l == 0 else H, F, H, V, int(features is not None) if l == 0 else 0, ops.CELL_FACTORED]
+                for l in range(nl)]
+        ws = [w.contiguous() for w in weights]
+        emb_c, Cw_c, Cb_c = emb.contiguous(), Cw.contiguous(), Cb.contiguous()
+        L = _lib.lib()
+        cd = [int_array(d) for d in dims]
+        saved = [torch.empty(L.capnet_seq_saved_floats(c), dtype=torch.float32, device=dev) for c in cd]
+        saved_i = [torch.empty(L.capnet_seq_saved_ints(c), dtype=torch.int32, device=dev) for c in cd]
+        scratch = torch.empty(L.capnet_seq_fwd_scratch_floats(cd[0]), dtype=torch.float32, device=dev)
+        hid = [torch.empty((N, H), dtype=torch.float32, device=dev) for _ in range(nl)]
+        tfm = (_lib.C.c_ubyte * len(tf))(*[1 if x else 0 for x in tf])
+        check(L.capnet_seq_forward_stacked(cd[0], nl, int_array(bs), tfm, ptr(captions), ptr(features), ptr(emb_c),
+                                           _lib.ptr_array(ws), ptr(Cw_c), ptr(Cb_c), float(cfg["dropout"]), int(cfg["seed"]),
+                                           int(cfg["training"]), _lib.ptr_array(saved), _lib.ptr_array(saved_i), ptr(scratch),
+                                           _lib.ptr_array(hid), ptr(ops.err_flag(dev)), current_stream()),
+              "capnet_seq_forward_stacked")
+        ctx.cfg, ctx.dims, ctx.has_features = cfg, dims, features is not None
+        ctx.save_for_backward(*(saved + saved_i + hid))
+        return hid[-1]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, d_hiddens):
+        cfg, dims = ctx.cfg, ctx.dims
+        nl = cfg["num_layers"]
+        t = ctx.saved_tensors
+        saved, saved_i, hid = list(t[:nl]), list(t[nl:2 * nl]), list(t[2 * nl:])
+        B, T, steps, N, E, F, H, V, _, _ = dims[0]
+        dev = saved[0].device
+        L = _lib.lib()
+        cd = [int_array(d) for d in dims]
+        scratch = torch.empty(max(L.capnet_seq_bwd_scratch_floats(c) for c in cd), dtype=torch.float32, device=dev)
+
+        def new(*shape):
+            return torch.empty(shape, dtype=torch.float32, device=dev)
+
+        dEmb = new(V, E)
+        dFeat = new(B, E) if ctx.has_features else None
+        grads, per_layer = [], []
+        for l in range(nl):
+            El = E if l == 0 else H
+            g = [new(4 * F, El), new(4 * F), new(4, F, F), new(4 * F), new(4, H, F), new(4 * H), new(4 * H, H),
+                 dEmb if l == 0 else None, dFeat if l == 0 else None]
+            grads += g
+            per_layer.append(g)
+        dh_work = [new(N, H) for _ in range(nl - 1)]
+        check(L.capnet_seq_backward_stacked(cd[0], nl, int_array(cfg["batch_sizes"]), ptr(d_hiddens.contiguous()),
+                                            _lib.ptr_array(hid), _lib.ptr_array(saved), _lib.ptr_array(saved_i), ptr(scratch),
+                                            _lib.ptr_array(dh_work) if dh_work else None, _lib.ptr_array(grads),
+                                            float(cfg["dropout"]), int(cfg["seed"]), int(cfg["training"]), current_stream()),
+              "capnet_seq_backward_stacked")
+        wg = []
+        for dV, dbV, dS, dbS, dU, dbUW, dW, _, _ in per_layer:
+            wg += ([dV[g * F:(g + 1) * F] for g in range(4)] + [dbV[g * F:(g + 1) * F] for g in range(4)] +
+                   [dS[g] for g in range(4)] + [dbS[g * F:(g + 1) * F] for g in range(4)] + [dU[g] for g in range(4)] +
+                   [dbUW[g * H:(g + 1) * H] for g in range(4)] + [dW[g * H:(g + 1) * H] for g in range(4)] +
+                   [dbUW[g * H:(g + 1) * H].clone() for g in range(4)])
+        # cfg, captions, features, emb, Cw, Cb, *weights
+        return (None, None, dFeat, dEmb, None, None) + tuple(wg)
+
+
 class StackedFactoredLSTM(nn.Module):
     """DecoderFactoredLSTM(embed_size, hidden_size, factored_size, vocab_size, num_layers, ...) whose num_layers is
     honoured. Layer 0 carries the reference's parameter names, layer l > 0 the same names with the layer number in
@@ -172,7 +264,8 @@ class StackedFactoredLSTM(nn.Module):
         self.vocab_size, self.num_layers = vocab_size, num_layers
         self.feature_size, self.max_seq_length = feature_size, max_seq_length
         self.dropout_p = dropout
-        self.fast_runs = True        # runs of teacher-forced steps through the persistent kernel (False: step by step)
+        self.fast_runs = True        # Python engines only: runs of teacher-forced steps through the persistent kernel (False: step by step)
+        self.engine = "c"            # "c": the whole recurrence as one C call each way (StackedSeqFn); "python": the op-by-op engines below
         self.B = _Embedding(vocab_size, embed_size)
         for l in range(num_layers):
             tag = "" if l == 0 else str(l)
@@ -245,6 +338,18 @@ class StackedFactoredLSTM(nn.Module):
         if len(tf_mask) < steps:
             raise CapnetError("tf_mask has %d entries, %d steps needed" % (len(tf_mask), steps))
         tf_mask = [bool(v) for v in tf_mask[:steps]]         # (longer masks are cut, as the other decoders do)
+        if self.engine == "c":
+            from .model import _dropout_seed
+            cfg = {"batch_sizes": bs, "tf_mask": tf_mask, "hidden_size": H, "factored_size": self.factored_size,
+                   "num_layers": L, "dropout": self.dropout_p if self.training else 0.0,
+                   "seed": _dropout_seed(self.training, self.dropout_p), "training": self.training}
+            weights = []
+            for l in range(L):
+                V, S, U, W = self._mods(l, mode)
+                weights += ([m.weight for m in V] + [m.bias for m in V] + [m.weight for m in S] + [m.bias for m in S] +
+                            [m.weight for m in U] + [m.bias for m in U] + [m.weight for m in W] + [m.bias for m in W])
+            hiddens = StackedSeqFn.apply(cfg, captions, features, self.B.weight, self.C.weight, self.C.bias, *weights)
+            return ops.linear(hiddens, self.C.weight, self.C.bias)
         Bn = captions.size(0)
         emb = Fn.embedding(captions, self.B.weight)                       # B(captions)
         if self.training and self.dropout_p > 0:

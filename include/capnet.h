@@ -350,6 +350,25 @@ int capnet_seq_backward(const int* dims, const int* batch_sizes, const float* d_
                         float* scratch, float* const* grads, float dropout_p,
                         unsigned long long seed, int training, capnet_stream_t stream);
 
+/* Stacked FactoredLSTM layers (BASELINE configs[3] / [4]: "2-layer", "3-layer"). PERF-ONLY, PARITY UNPINNED: the reference
+ * advertises lstm_layers 1, 2, 3 (README.md:24) but its decoders ignore num_layers (stylenet/model.py:37); the semantics
+ * are SURVEY App. A-1's, modelled on the only stacking in the tree (seq2seq/model.py:45-49): layer l > 0 is the same
+ * factored cell on dropout(hidden of layer l - 1) at the same step (V: Linear(H -> F)), the top layer's hidden feeds C.
+ * dims = capnet_seq_forward's of layer 0; the layers above have E = H and no features (sizes: capnet_seq_saved_floats
+ * etc. with those dims). weights: nlayers x 32 pointers in capnet_seq_forward's order; saved / saved_i / hiddens: one
+ * buffer per layer (the top layer's hiddens [N][H] are the output); scratch as capnet_seq_forward's.
+ * Backward: d_hiddens of the top layer in; grads: nlayers x 9 pointers in capnet_seq_backward's order (dEmb / dFeat of
+ * layer 0 only); dh_work: nlayers - 1 buffers [N][H]; scratch: the largest capnet_seq_bwd_scratch_floats of the layers. */
+int capnet_seq_forward_stacked(const int* dims, int nlayers, const int* batch_sizes, const unsigned char* tf_mask,
+                               const long long* captions, const float* features, const float* emb,
+                               const float* const* weights, const float* Cw, const float* Cb, float dropout_p,
+                               unsigned long long seed, int training, float* const* saved, int* const* saved_i,
+                               float* scratch, float* const* hiddens, int* err_flag, capnet_stream_t stream);
+int capnet_seq_backward_stacked(const int* dims, int nlayers, const int* batch_sizes, const float* d_hiddens,
+                                const float* const* hiddens, const float* const* saved, const int* const* saved_i,
+                                float* scratch, float* const* dh_work, float* const* grads, float dropout_p,
+                                unsigned long long seed, int training, capnet_stream_t stream);
+
 /* ---- attention decoders: DecoderFactoredLSTMAtt.forward (stylenet/model_att.py:238-305) and
  * DecoderRNNAtt.forward (nic/model_att.py:152-202) ----
  * dims (host int[12]) = {B, T, steps, N, E, F, H, V, A, P, C, cell}: A attention size, P pixels

@@ -83,18 +83,21 @@ def test_one_layer_is_the_reference_decoder(dev):
     assert rel_err(dec.B.weight.grad, ref.B.weight.grad) < 1e-4
 
 
-def test_runs_through_the_persistent_kernel_equal_the_step_by_step_engine(dev):
-    """Three layers at the size the persistent kernel takes (H = 512): logits, loss and every gradient of the engine
-    that runs each teacher-forced run of a layer in one launch (capnet.stacked.LstmRunFn: forward on
-    csrc/lstm_persist.hip, its own backward through time) against the step-by-step engine (W GEMM + cell kernel per step,
-    autograd composing the backward), same weights, same scheduled-sampling decisions, shrinking batches."""
+@pytest.mark.parametrize("engine_a", ["c", "python"])
+def test_runs_through_the_persistent_kernel_equal_the_step_by_step_engine(dev, engine_a):
+    """Three layers at the size the persistent kernel takes (H = 512): logits, loss and every gradient of (c) the whole
+    recurrence as one C call each way (capnet_seq_forward_stacked / _backward_stacked) and of (python) the engine that runs
+    each teacher-forced run of a layer in one launch (capnet.stacked.LstmRunFn) against the step-by-step engine (W GEMM +
+    cell kernel per step, torch autograd composing the backward), same weights, same scheduled-sampling decisions,
+    shrinking batches."""
     E, H, F, V, B, layers = 300, 512, 256, 500, 9, 3
     a = StackedFactoredLSTM(E, H, F, V, layers, dropout=0.0)
     p = synthetic.decoder_state(a.state_dict(), seed=21)
     a.load_state_dict(p)
     b = StackedFactoredLSTM(E, H, F, V, layers, dropout=0.0)
     b.load_state_dict(p)
-    b.fast_runs = False
+    b.engine, b.fast_runs = "python", False
+    a.engine = engine_a
     a.to(dev).train()
     b.to(dev).train()
     _, caps, lens = synthetic.make_batch(B, V, seed=4)
