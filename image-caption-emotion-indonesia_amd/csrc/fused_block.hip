@@ -74,31 +74,56 @@ __device__ __forceinline__ int fb_weight_shift(unsigned absmax_bits) {      // m
 // role 1: W1 [MID][C] (the next conv1, the B operand of phase B): cells [chunk C/32][nb MID/16][plane 2][lane 64]
 //         = W1[16 nb + (lane & 15)][32 chunk + kslot(lane >> 4, j)].
 __global__ __launch_bounds__(256) void fb_pack_kernel(const float* __restrict__ w, unsigned* __restrict__ img, int C, int MID,
-                                                      int role) {
+                                                      int role, int wide) {
   const int ew = fb_weight_shift(img[1]);
-  if (blockIdx.x == 0 && threadIdx.x == 0) img[0] = (unsigned)ew;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { img[0] = (unsigned)ew; img[2] = (unsigned)wide; }
   const float ws = ldexpf(1.f, ew);
   const long cells = (long)C * MID / 8 * 2;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < cells; i += (long)gridDim.x * blockDim.x) {
     long r = i;
     const int lane = (int)(r & 63); r >>= 6;
     const int plane = (int)(r & 1); r >>= 1;
-    const int g = lane >> 4, n = lane & 15;
     const float* src;
-    if (role == 0) {
-      const int blk = (int)(r & 1); r >>= 1;
-      const int ks = (int)(r % (MID / 32));
-      const int chunk = (int)(r / (MID / 32));
-      src = w + (long)(32 * chunk + 16 * blk + n) * MID + 32 * ks;
+    int koff[8];
+    if (!wide) {
+      const int g = lane >> 4, n = lane & 15;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) koff[j] = fb_kslot(g, j);
+      if (role == 0) {
+        const int blk = (int)(r & 1); r >>= 1;
+        const int ks = (int)(r % (MID / 32));
+        const int chunk = (int)(r / (MID / 32));
+        src = w + (long)(32 * chunk + 16 * blk + n) * MID + 32 * ks;
+      } else {
+        const int nb = (int)(r % (MID / 16));
+        const int chunk = (int)(r / (MID / 16));
+        src = w + (long)(16 * nb + n) * C + 32 * chunk;
+      }
     } else {
-      const int nb = (int)(r % (MID / 16));
-      const int chunk = (int)(r / (MID / 16));
-      src = w + (long)(16 * nb + n) * C + 32 * chunk;
+      // 32-row strips on v_mfma_f32_32x32x16_f16 (fb_fused_wide_kernel): lane (n = lane & 31, h = lane >> 5)
+      const int h = lane >> 5, n = lane & 31;
+      if (role == 0) {
+        // cells [chunk][k16 step][plane][lane]: W3[32 chunk + n][16 ks + 8 h + j]
+        const int ks = (int)(r % (MID / 16));
+        const int chunk = (int)(r / (MID / 16));
+        src = w + (long)(32 * chunk + n) * MID + 16 * ks;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) koff[j] = 8 * h + j;
+      } else {
+        // cells [chunk][nb MID / 32][step 2][plane][lane]: W1[32 nb + n][32 chunk + 16 s + 8 (j >> 2) + 4 h + (j & 3)] -- the
+        // channel order in which phase A's accumulator registers 8 s .. 8 s + 7 hold a row's channels
+        const int st = (int)(r & 1); r >>= 1;
+        const int nb = (int)(r % (MID / 32));
+        const int chunk = (int)(r / (MID / 32));
+        src = w + (long)(32 * nb + n) * C + 32 * chunk + 16 * st;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) koff[j] = 8 * (j >> 2) + 4 * h + (j & 3);
+      }
     }
     unsigned out[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const float x0 = src[fb_kslot(g, 2 * q)] * ws, x1 = src[fb_kslot(g, 2 * q + 1)] * ws;
+      const float x0 = src[koff[2 * q]] * ws, x1 = src[koff[2 * q + 1]] * ws;
       const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
       const _Float16 l0 = (_Float16)(x0 - (float)h0), l1 = (_Float16)(x1 - (float)h1);
       const h2 p = plane == 0 ? h2{h0, h1} : h2{l0, l1};
@@ -686,6 +711,243 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void fb_fused_kernel(const FArgs g
   }
 }
 
+// The same launch on 32-ROW strips and v_mfma_f32_32x32x16_f16: four waves (one per SIMD, up to 512 registers) of 32 rows.
+// A weight fragment (1 KB) feeds 32 rows, not 16 -- half the LDS fragment traffic per row -- and a 32-cycle MFMA leaves six
+// issue slots in its shadow where a 16-cycle one leaves two. Built on the expectation that a lone wave would then hide its
+// fragment reads and address arithmetic behind its own MFMAs; MEASURED SLOWER than eight waves of 16 rows (104 vs 79 us
+// alone at stage 3, -6 % images/s in the pipelined step): a lone wave per SIMD does not overlap its own phases, whatever
+// the MFMA shape. Opt-in (CAPNET_FB_WIDE=1), kept under test as the other A/B arms are. Phase A transposed as before: its D tile (lane
+// (n = l & 31, h = l >> 5): channels (r & 3) + 8 (r >> 2) + 4 h of row n in register r) is phase B's A operand in place --
+// registers 8 s .. 8 s + 7 are k step s, and the W1 image carries that channel order (fb_pack_kernel, wide).
+template <int MID>
+__global__ __launch_bounds__(256, 1) void fb_fused_wide_kernel(const FArgs g) {
+  constexpr int C = 4 * MID, KS = MID / 16, NB = MID / 32, NCH = C / 32, NW = 4;
+  constexpr int SLOT = MID * 128;
+  constexpr int NDMA = SLOT / 1024 / NW;
+  constexpr int L = 4;                                // identity loads = out stores per wave and chunk (32 rows x 32 channels)
+  constexpr int TR = 32 * NW;
+  constexpr int NT = 64 * NW;
+  static_assert(NDMA >= 1 && 4 * NDMA + 2 * L <= 63, "vmcnt range");
+  __shared__ __attribute__((aligned(16))) unsigned char ring[4 * SLOT];
+  __shared__ __attribute__((aligned(16))) float par[4][C];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lh = lane >> 5, li = lane & 31;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const unsigned ring0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)ring);
+  const int tile0 = (int)blockIdx.x * TR;
+  const bool fold_res = g.sd != nullptr;
+  const float* const w3img = reinterpret_cast<const float*>(g.w3 + kFHdr);
+  const float* const w1img = reinterpret_cast<const float*>(g.w1 + kFHdr);
+  auto dma = [&](const float* img, int cc, int slot) __attribute__((always_inline)) {
+    const float* src = img + (long)cc * (SLOT / 4);
+#pragma unroll
+    for (int q = 0; q < NDMA; ++q)
+      glds16(src, (wave_u * NDMA + q) * 1024 + lane * 16, ring0 + (unsigned)(slot * SLOT + (wave_u * NDMA + q) * 1024));
+  };
+  // identity rows of chunk cc: lane (li, lh) takes channels 32 cc + 8 q + 4 lh .. + 3 of its row, q = 0 .. 3
+  const int myrow = min(tile0 + wave * 32 + li, g.M - 1);          // rows past M repeat row M - 1 (see the 16-row kernel)
+  const unsigned idoff = (unsigned)(((long)myrow * C + 4 * lh) * 4);
+  f32x4 idA[4], idB[4];
+  auto fetch_id = [&](int cc, f32x4 (&id)[4]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) gload16(id[q], g.res, idoff + (unsigned)((32 * cc + 8 * q) * 4));
+  };
+  dma(w3img, 0, 0);
+  dma(w1img, 0, 1);
+  fetch_id(0, idA);
+  fetch_id(NCH > 1 ? 1 : 0, idB);
+  {
+    const float x3 = ldexpf(1.f, -((int)g.w3[0] + g.e3));
+    for (int i = tid; i < C; i += NT) {
+      par[0][i] = g.s3[i] * x3;
+      par[1][i] = g.t3[i];
+      par[2][i] = fold_res ? g.sd[i] : 1.f;
+      par[3][i] = fold_res ? g.td[i] : 0.f;
+    }
+  }
+  // a2 of the wave's 32 rows as the B operand of phase A: lane (row li, half lh) holds k = 16 ks + 8 lh + j
+  h8 ah[KS], al[KS];
+  {
+    const float is3 = ldexpf(1.f, g.e3);
+    const float* p = g.y2 + (long)myrow * MID + 8 * lh;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      f32x4 v0 = *reinterpret_cast<const f32x4*>(p + 16 * ks), v1 = *reinterpret_cast<const f32x4*>(p + 16 * ks + 4);
+      const f32x4 sa = *reinterpret_cast<const f32x4*>(g.s2 + 16 * ks + 8 * lh), sb = *reinterpret_cast<const f32x4*>(g.s2 + 16 * ks + 8 * lh + 4);
+      const f32x4 ta = *reinterpret_cast<const f32x4*>(g.t2 + 16 * ks + 8 * lh), tb = *reinterpret_cast<const f32x4*>(g.t2 + 16 * ks + 8 * lh + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v0[e] = fmaxf(fmaf(v0[e], sa[e], ta[e]), 0.f) * is3;
+        v1[e] = fmaxf(fmaf(v1[e], sb[e], tb[e]), 0.f) * is3;
+      }
+      h4 h0, l0, h1, l1;
+      fb_split4(v0, h0, l0);
+      fb_split4(v1, h1, l1);
+      ah[ks] = fb_cat(h0, h1);
+      al[ks] = fb_cat(l0, l1);
+    }
+  }
+  fb_wait_vmcnt<0>();
+  CAPNET_LANDED4(idA[0], idA[1], idA[2], idA[3]);
+  CAPNET_LANDED4(idB[0], idB[1], idB[2], idB[3]);
+  __syncthreads();
+
+  f32x16 acc[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+  const float is1 = ldexpf(1.f, g.e1);
+  typedef const __attribute__((address_space(3))) unsigned char* lds_bytes;
+  typedef const __attribute__((address_space(3))) h8* lds_h8;
+  const lds_bytes ring3 = (lds_bytes)ring;
+  constexpr int GB = 4;                               // groups (two fragments each) per batch of fragment reads
+  f32x16 d;
+  auto phase_a = [&](int cc) __attribute__((always_inline)) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) d[r] = 0.f;
+    unsigned wa_off = (unsigned)(((2 * cc) & 3) * SLOT + lane * 16);
+    asm volatile("" : "+v"(wa_off));
+    const lds_bytes wa = ring3 + wa_off;
+    constexpr int NBAT = (KS + GB - 1) / GB;          // group = k16 step: fragments (ks * 2 + plane) KB into the slot
+    h8 f[2][GB][2];
+#pragma unroll
+    for (int q = 0; q < GB; ++q)
+      if (q < KS) { f[0][q][0] = *(lds_h8)(wa + (q * 2) * 1024); f[0][q][1] = *(lds_h8)(wa + (q * 2 + 1) * 1024); }
+#pragma unroll
+    for (int b = 0; b < NBAT; ++b) {
+      if (b + 1 < NBAT) {
+#pragma unroll
+        for (int q = 0; q < GB; ++q) {
+          const int ks = (b + 1) * GB + q;
+          if (ks < KS) { f[(b + 1) & 1][q][0] = *(lds_h8)(wa + (ks * 2) * 1024); f[(b + 1) & 1][q][1] = *(lds_h8)(wa + (ks * 2 + 1) * 1024); }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < GB; ++q) {
+        const int ks = b * GB + q;
+        if (ks < KS) {
+          d = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[b & 1][q][1], ah[ks], d, 0, 0, 0);
+          d = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[b & 1][q][0], al[ks], d, 0, 0, 0);
+          d = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[b & 1][q][0], ah[ks], d, 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  auto phase_b = [&](int cc, f32x4 (&id)[4]) __attribute__((always_inline)) {
+    unsigned wb_off = (unsigned)(((2 * cc + 1) & 3) * SLOT + lane * 16);
+    asm volatile("" : "+v"(wb_off));
+    const lds_bytes wb = ring3 + wb_off;
+    constexpr int NG = NB * 2, NBATB = (NG + GB - 1) / GB;      // group = (nb, step): fragments (group * 2 + plane) KB
+    h8 fb[2][GB][2];
+#pragma unroll
+    for (int q = 0; q < GB; ++q)
+      if (q < NG) { fb[0][q][0] = *(lds_h8)(wb + (q * 2) * 1024); fb[0][q][1] = *(lds_h8)(wb + (q * 2 + 1) * 1024); }
+    __builtin_amdgcn_sched_barrier(0);
+    fb_wait_vmcnt<4 * NDMA + 2 * L>();
+    CAPNET_LANDED4(id[0], id[1], id[2], id[3]);
+    h4 hh[4], ll[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int ch = 32 * cc + 8 * q + 4 * lh;
+      const f32x4 sv = *reinterpret_cast<const f32x4*>(&par[0][ch]), tv = *reinterpret_cast<const f32x4*>(&par[1][ch]);
+      f32x4 r = id[q], o;
+      if (fold_res) {
+        const f32x4 dv = *reinterpret_cast<const f32x4*>(&par[2][ch]), ev = *reinterpret_cast<const f32x4*>(&par[3][ch]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = fmaf(r[e], dv[e], ev[e]);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = fmaxf(fmaf(d[4 * q + e], sv[e], tv[e]) + r[e], 0.f);
+      *reinterpret_cast<f32x4*>(g.out + (long)myrow * C + ch) = o;
+      fb_split4(o * is1, hh[q], ll[q]);
+    }
+    const h8 oh[2] = {fb_cat(hh[0], hh[1]), fb_cat(hh[2], hh[3])}, ol[2] = {fb_cat(ll[0], ll[1]), fb_cat(ll[2], ll[3])};
+    fetch_id(cc + 2 < NCH ? cc + 2 : NCH - 1, id);
+#pragma unroll
+    for (int b = 0; b < NBATB; ++b) {
+      if (b + 1 < NBATB) {
+#pragma unroll
+        for (int q = 0; q < GB; ++q) {
+          const int grp = (b + 1) * GB + q;
+          if (grp < NG) { fb[(b + 1) & 1][q][0] = *(lds_h8)(wb + (grp * 2) * 1024); fb[(b + 1) & 1][q][1] = *(lds_h8)(wb + (grp * 2 + 1) * 1024); }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < GB; ++q) {
+        const int grp = b * GB + q, nb = grp >> 1, st = grp & 1;
+        if (grp < NG) {
+          acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ol[st], fb[b & 1][q][0], acc[nb], 0, 0, 0);
+          acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(oh[st], fb[b & 1][q][1], acc[nb], 0, 0, 0);
+          acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(oh[st], fb[b & 1][q][0], acc[nb], 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  auto head = [&](int k) __attribute__((always_inline)) {
+    if (k < 4) fb_wait_vmcnt<0>(); else fb_wait_vmcnt<NDMA + 2 * L>();
+    __syncthreads();
+    const int p = k + 2 < 2 * NCH ? k + 2 : 2 * NCH - 2 + (k & 1);
+    dma((p & 1) ? w1img : w3img, p >> 1, (k + 2) & 3);
+  };
+  static_assert(NCH % 2 == 0, "chunks come in pairs (two named register sets)");
+  for (int k = 0; k < 2 * NCH; k += 4) {
+    const int c0 = k >> 1;
+    head(k);
+    phase_a(c0);
+    head(k + 1);
+    phase_b(c0, idA);
+    head(k + 2);
+    phase_a(c0 + 1);
+    head(k + 3);
+    phase_b(c0 + 1, idB);
+  }
+  fb_wait_vmcnt<0>();
+  CAPNET_LANDED4(idA[0], idA[1], idA[2], idA[3]);
+  CAPNET_LANDED4(idB[0], idB[1], idB[2], idB[3]);
+  __syncthreads();
+
+  // ---- epilogue: y1 = acc 2^-(ew1 + e1); D[r]: row (r & 3) + 8 (r >> 2) + 4 lh, column 32 nb + li
+  const float osc = ldexpf(1.f, -((int)g.w1[0] + g.e1));
+  float (*const scratch)[NW][MID] = reinterpret_cast<float (*)[NW][MID]>(ring);
+  float bad = 0.f;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    float cs = 0.f, cq = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = tile0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const float v = acc[nb][r] * osc;
+      if (row < g.M) {
+        g.y1[(long)row * MID + 32 * nb + li] = v;
+        cs += v;
+        cq = fmaf(v, v, cq);
+      }
+    }
+    if (g.part_sum) {
+      cs += __shfl_xor(cs, 32); cq += __shfl_xor(cq, 32);
+      if (lh == 0) { scratch[0][wave][32 * nb + li] = cs; scratch[1][wave][32 * nb + li] = cq; }
+    } else {
+      bad += cq;
+    }
+  }
+  if (!g.part_sum) {
+    if (g.err) flag_nonfinite(bad, g.err);
+    return;
+  }
+  __syncthreads();
+  for (int c = tid; c < MID; c += NT) {
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { a += scratch[0][w][c]; b += scratch[1][w][c]; }
+    g.part_sum[(long)blockIdx.x * MID + c] = a;
+    g.part_sq[(long)blockIdx.x * MID + c] = b;
+  }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -699,6 +961,15 @@ size_t fused_block_weight_words(int C, int MID, int role) {
   return (size_t)kFHdr + (size_t)C * MID * (role == 0 ? 2 : 1);
 }
 
+// 32-row strips on 32x32x16 MFMAs (fb_fused_wide_kernel) or 16-row strips on 16x16x32 ones: the weight images differ, so
+// the choice is a function of MID alone (and of CAPNET_FB_WIDE = 0 / 1, read when the images are packed AND at launch)
+static bool fb_wide(int MID) {
+  const char* e = getenv("CAPNET_FB_WIDE");
+  if (e && (e[0] == '0' || e[0] == '1')) return e[0] == '1';
+  (void)MID;
+  return false;      // measured: 104 us against 79 us alone on the 14 x 14 maps, -6 % images/s in the step: opt-in
+}
+
 // role 0: w = conv3's weights [C][MID]; role 1: w = the next conv1's weights [MID][C]
 int fused_block_pack(const float* w, unsigned* img, int C, int MID, int role, hipStream_t stream) {
   CAPNET_REQUIRE(w && img && aligned16(img) && C == 4 * MID && (MID == 64 || MID == 128 || MID == 256) && (role == 0 || role == 1),
@@ -707,7 +978,7 @@ int fused_block_pack(const float* w, unsigned* img, int C, int MID, int role, hi
   const long n = (long)C * MID;
   hipLaunchKernelGGL(fb_absmax_kernel, dim3((int)(cdiv(n, 256 * 8) > 1024 ? 1024 : cdiv(n, 256 * 8))), dim3(256), 0, stream, w, img, n);
   CAPNET_LAUNCH_CHECK();
-  hipLaunchKernelGGL(fb_pack_kernel, dim3((int)(cdiv(n / 4, 256) > 2048 ? 2048 : cdiv(n / 4, 256))), dim3(256), 0, stream, w, img, C, MID, role);
+  hipLaunchKernelGGL(fb_pack_kernel, dim3((int)(cdiv(n / 4, 256) > 2048 ? 2048 : cdiv(n / 4, 256))), dim3(256), 0, stream, w, img, C, MID, role, fb_wide(MID) ? 1 : 0);
   CAPNET_LAUNCH_CHECK();
   return kOk;
 }
@@ -764,6 +1035,7 @@ static void fb_shape(int MID, int* rs, int* nw) {
   if (*nw == 8) *rs = 1;
 }
 int fused_block_tiles(long M, int MID) {
+  if (fb_wide(MID)) return cdiv(M, 128);
   int rs, nw;
   fb_shape(MID, &rs, &nw);
   return cdiv(M, 16 * rs * nw);
@@ -785,6 +1057,14 @@ int fused_block_forward(const float* y2, const float* s2, const float* t2, const
   const dim3 grid(fused_block_tiles(M, MID));
   int rs, nw;
   fb_shape(MID, &rs, &nw);
+  if (fb_wide(MID)) {
+    const dim3 block(256);
+    if (MID == 256) CAPNET_LAUNCH_TIMED((fb_fused_wide_kernel<256>), grid, block, stream, a);
+    else if (MID == 128) CAPNET_LAUNCH_TIMED((fb_fused_wide_kernel<128>), grid, block, stream, a);
+    else CAPNET_LAUNCH_TIMED((fb_fused_wide_kernel<64>), grid, block, stream, a);
+    CAPNET_LAUNCH_CHECK();
+    return kOk;
+  }
   const dim3 block(64 * nw);
   if (nw == 8) {
     if (MID == 256) CAPNET_LAUNCH_TIMED((fb_fused_kernel<256, 1, 8>), grid, block, stream, a);

@@ -88,11 +88,13 @@ def test_prescales_keep_fp32_grade_results(dev, e3, e1, in_scale):
     ops.check_device_errors()
 
 
-@pytest.mark.parametrize("env", [{"CAPNET_FB_NW": "4", "CAPNET_FB_RS": "2"}, {"CAPNET_FB_NW": "4", "CAPNET_FB_RS": "1"}])
+@pytest.mark.parametrize("env", [{"CAPNET_FB_WIDE": "0", "CAPNET_FB_NW": "4", "CAPNET_FB_RS": "2"}, {"CAPNET_FB_WIDE": "0", "CAPNET_FB_NW": "4", "CAPNET_FB_RS": "1"},
+                                 {"CAPNET_FB_WIDE": "0"}, {"CAPNET_FB_WIDE": "1"}])
 @pytest.mark.parametrize("M,MID,ds", [(588, 256, True), (2352, 128, False), (1000, 64, False)])
 def test_the_other_tile_shapes_are_working_configurations(dev, monkeypatch, env, M, MID, ds):
-    """CAPNET_FB_NW / CAPNET_FB_RS (read at launch) select four waves of two or one 16-row strips instead of the default
-    eight waves of one: the A/B arms of DESIGN 4m stay correct."""
+    """CAPNET_FB_WIDE (read when the weight images are packed and at launch: 32-row strips on 32x32x16 MFMAs, opt-in,
+    or the default 16-row strips on 16x16x32 ones) and CAPNET_FB_NW / CAPNET_FB_RS (read at launch: the 16-row form
+    with four waves of two or one strips instead of eight waves of one): the A/B arms of DESIGN 4m stay correct."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     y2, s2, t2, w3, w1, gamma, beta, res, sd, td = _case(M, MID, ds, 3 * M + MID)
