@@ -607,28 +607,67 @@ int colsum(const float* x, long ld, int rows, int C, float* out, int accumulate,
 }
 
 // ---- embedding / feature gradient scatter --------------------------------------------------
-// dX [N][E] -> dEmb[token] (atomic, tokens repeat) or dFeat[sample] (one row per sample).
+// dX [N][E] -> dEmb[token] += the rows of that token, dFeat[sample] = the sample's feature row. Tokens repeat: the FIRST row
+// of a token sums every row of it in row order and adds the sum -- one writer per table row, a fixed order (an atomic add per
+// row was the one launch of the step whose result depended on arrival order: the checkpoint round trip's bitwise comparison
+// failed one run in three on the last bit of the third loss). Every workgroup scans the N tokens, 128 at a time, through wave
+// ballots; the others leave at the first earlier match.
+constexpr int kScatterE = 4;                 // columns per thread and sweep: E <= 512 in one
 __global__ __launch_bounds__(128) void scatter_input_grad_kernel(
-    const float* __restrict__ dX, long ldx, int E, const int* __restrict__ row_sample,
+    const float* __restrict__ dX, long ldx, int N, int E, const int* __restrict__ row_sample,
     const int* __restrict__ row_col, const int* __restrict__ row_token, float* __restrict__ dEmb,
     float* __restrict__ dFeat, int V, float p, unsigned long long seed, int use_dropout) {
-  const int r = blockIdx.x;
-  const int sample = row_sample[r];
-  const int col = row_col[r];
+  __shared__ unsigned long long s_mask[2][2];
+  const int r = blockIdx.x, tid = threadIdx.x;
   const float inv_keep = p < 1.f ? 1.f / (1.f - p) : 0.f;
-  if (col == -1) {
+  if (row_col[r] == -1) {
+    const int sample = row_sample[r];
     if (dFeat)
-      for (int e = threadIdx.x; e < E; e += blockDim.x)
+      for (int e = tid; e < E; e += blockDim.x)
         dFeat[(long)sample * E + e] = dX[(long)r * ldx + e];
     return;
   }
-  int tok = row_token[r];
+  const int tok = row_token[r];
   if (tok < 0 || tok >= V) return;
-  const bool drop = (col >= 0) && use_dropout;
-  for (int e = threadIdx.x; e < E; e += blockDim.x) {
-    float g = dX[(long)r * ldx + e];
-    if (drop) g *= dropout_scale(seed, sample, col, e, p, inv_keep);
-    atomicAdd(dEmb + (long)tok * E + e, g);
+  for (int e0 = 0; e0 < E; e0 += 128 * kScatterE) {
+    float acc[kScatterE];
+#pragma unroll
+    for (int u = 0; u < kScatterE; ++u) acc[u] = 0.f;
+    for (int base = 0, it = 0; base < N; base += 128, ++it) {
+      const int rr = base + tid;
+      const bool match = rr < N && row_col[rr] != -1 && row_token[rr] == tok;
+      const unsigned long long m = __ballot(match);
+      if ((tid & 63) == 0) s_mask[it & 1][tid >> 6] = m;
+      __syncthreads();                         // (two buffers: the next round's writes cannot pass this round's reads)
+      unsigned long long m0 = s_mask[it & 1][0], m1 = s_mask[it & 1][1];
+      if (base <= r && (m0 | m1)) {            // rows at or before r in this round: r is the owner iff it is the first match
+        const int first = base + (m0 ? __builtin_ctzll(m0) : 64 + __builtin_ctzll(m1));
+        if (first < r) return;                 // (uniform: every thread reads the same masks)
+      }
+      for (int half = 0; half < 2; ++half) {
+        unsigned long long mm = half ? m1 : m0;
+        while (mm) {
+          const int j = base + 64 * half + __builtin_ctzll(mm);
+          mm &= mm - 1;
+          const int sample = row_sample[j], col = row_col[j];
+          const bool drop = (col >= 0) && use_dropout;
+#pragma unroll
+          for (int u = 0; u < kScatterE; ++u) {
+            const int e = e0 + u * 128 + tid;
+            if (e < E) {
+              float g = dX[(long)j * ldx + e];
+              if (drop) g *= dropout_scale(seed, sample, col, e, p, inv_keep);
+              acc[u] += g;
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kScatterE; ++u) {
+      const int e = e0 + u * 128 + tid;
+      if (e < E) dEmb[(long)tok * E + e] += acc[u];
+    }
   }
 }
 
@@ -636,7 +675,7 @@ int scatter_input_grad(const float* dX, long ldx, int N, int E, const int* row_s
                        const int* row_token, float* dEmb, float* dFeat, int V, float p,
                        unsigned long long seed, int use_dropout, hipStream_t stream) {
   if (N <= 0) return kOk;
-  hipLaunchKernelGGL(scatter_input_grad_kernel, dim3(N), dim3(128), 0, stream, dX, ldx, E, row_sample,
+  hipLaunchKernelGGL(scatter_input_grad_kernel, dim3(N), dim3(128), 0, stream, dX, ldx, N, E, row_sample,
                      row_col, row_token, dEmb, dFeat, V, p, seed, use_dropout);
   CAPNET_LAUNCH_CHECK();
   return kOk;

@@ -233,6 +233,36 @@ def test_dropout_is_deterministic_and_scaled(dev):
     assert torch.equal(d1, d2)
 
 
+@pytest.mark.parametrize("E,V,ratio,p", [(300, 7, 1.0, 0.0), (600, 7, 0.6, 0.0), (64, 23, 1.0, 0.5)])
+def test_gradients_are_bit_reproducible_when_tokens_repeat(dev, E, V, ratio, p):
+    """The embedding gradient sums the rows of a token in row order (scatter_input_grad_kernel: one writer per table row):
+    twelve backward passes over captions of a handful of words give the same bits (E = 600: two column sweeps). Values
+    are the oracle tests' business."""
+    B, H = 48, 64
+    dec = DecoderFactoredLSTM(E, H, H, V, 1, dropout=p).to(dev).train()
+    dec.load_state_dict(synthetic.decoder_state(dec.state_dict(), seed=3))
+    _, captions, lengths = synthetic.make_batch(B, V, seed=4, images=False, min_len=4, max_len=22)
+    feats = torch.randn(B, E, generator=torch.Generator().manual_seed(1))
+    grads = []
+    for _ in range(12):
+        junk = torch.randn(1 << 18, device=dev)          # (moves the allocations of the pass around)
+        torch.manual_seed(5)
+        _, loss, f = _run_product(dec, captions, lengths, feats, 9, ratio, dev, mode="factual")
+        grads.append({k: q.grad.clone() for k, q in dec.named_parameters() if q.grad is not None})
+        grads[-1]["features"] = f.grad.clone()
+        del junk
+    for g in grads[1:]:
+        for k, v in g.items():
+            assert torch.equal(v, grads[0][k]), k
+    emb = grads[0]["B.weight"]
+    used = torch.unique(captions)
+    assert float(emb[used].abs().max()) > 0
+    unused = torch.ones(V, dtype=torch.bool)
+    unused[used] = False
+    if ratio == 1.0 and unused.any():                    # (free-running steps feed whatever word they predicted)
+        assert float(emb[unused.to(dev)].abs().max()) == 0.0
+
+
 def test_bad_inputs_raise(dev):
     dec = DecoderFactoredLSTM(8, 8, 8, 11, 1, dropout=0.0).to(dev)
     cap = torch.ones(2, 4, dtype=torch.long, device=dev)
