@@ -133,6 +133,7 @@ SIGNATURES = {
                                C.POINTER(_vp), C.POINTER(_l), _ip, C.c_float, C.c_float,
                                C.c_float, C.c_float, C.c_float, _i, _vp, _vp]),
     "capnet_lstm_persist_set_mode": (_i, [_i]),
+    "capnet_att_set_chain_mode": (_i, [_i]),
     "capnet_lstm_pointwise_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "capnet_conv1x1_fwd_areg": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _l, _i, _i, _i, _vp]),
     "capnet_trunk_set_timing": (_i, [_vp, _i]),

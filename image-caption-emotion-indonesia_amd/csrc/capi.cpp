@@ -454,6 +454,7 @@ static int to_aweights(const float* const* p, AttWeights* w, int cell) {
   w->full_att_w = p[40]; w->full_att_b = p[41]; w->f_beta_w = p[42]; w->f_beta_b = p[43];
   return kOk;
 }
+int capnet_att_set_chain_mode(int mode) { return att_set_chain_mode(mode); }
 size_t capnet_att_saved_floats(const int* dims) { return att_saved_floats(to_adims(dims)); }
 size_t capnet_att_saved_ints(const int* dims) { return att_saved_ints(to_adims(dims)); }
 size_t capnet_att_fwd_scratch_floats(const int* dims) { return att_fwd_scratch_floats(to_adims(dims)); }

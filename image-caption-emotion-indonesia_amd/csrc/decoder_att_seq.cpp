@@ -17,6 +17,7 @@
 // (gate order i,f,g,o; h = o tanh(c)) and Wz = [weight_hh; decoder_att; f_beta].
 // encoder_att(features) is hoisted out of the time loop (the reference recomputes it
 // every step) and its weight gradient is accumulated per sample and reduced by one GEMM.
+#include <cstdlib>
 #include <vector>
 
 #include "common.h"
@@ -27,7 +28,7 @@ namespace capnet {
 namespace {
 
 struct ALayout {
-  size_t XA, Zf, A1, A2, Cst, alpha, awe, att1, mean, h0, c0, Vcat, Scat, Ucat, Wz, bV, bS, bz, total;
+  size_t XA, Zf, A1, A2, Cst, alpha, awe, att1, mean, h0, c0, Vcat, Scat, Ucat, Wz, bV, bS, bz, US, Weff, c1, total;
   size_t row_sample, row_col, row_token, prev_row, itotal;
   int ZW, XW;
 };
@@ -58,6 +59,10 @@ ALayout make_alayout(const AttDims& d) {
   L.bV = take(4 * F);
   L.bS = take(4 * F);
   L.bz = take(L.ZW);
+  // the factored chain as ONE matrix (steps of few rows, see chain_collapsed): U_g S_g [H][F], U_g S_g V_g [4H][E+C], S_g bV_g + bS_g
+  L.US = take(fac ? 4 * H * F : 4);
+  L.Weff = take(fac ? 4 * H * L.XW : 4);
+  L.c1 = take(4 * F);
   L.total = o;
   size_t io = 0;
   auto itake = [&](size_t n) { size_t r = io; io += (n + 3) / 4 * 4; return r; };
@@ -67,6 +72,23 @@ ALayout make_alayout(const AttDims& d) {
   L.prev_row = itake(N);
   L.itotal = io;
   return L;
+}
+
+// Steps of at most 16 rows are a chain of dependent launches of 8-12 us each, whatever they compute (NOTEBOOK 4l): the
+// factored input product U_g (S_g (V_g x + bV_g) + bS_g) is three of them per step and three more on the way back. With
+// few rows the chain is run as ONE product per step against W_g = U_g S_g V_g (formed once per call: a 512 x 512 x 512
+// and a 512 x 512 x 2348 product per gate, ~5 GFLOP, where the steps' own products are 0.05 GFLOP each) and bias
+// U_g (S_g bV_g + bS_g); the intermediate rows A1 = V x + bV, A2 = S A1 + bS the weight gradients need, and their
+// gradients dA2 = dgates U, dA1 = dA2 S, are formed for ALL rows at once after the backward loop -- the same sums in another
+// association (fp32 rounding apart: the fixtures of the reference's own class hold either way). 0 = by shape (B <= 16),
+// 1 = always, -1 = never.
+int g_att_chain_mode = [] {
+  const char* e = getenv("CAPNET_ATT_CHAIN");        // "3": three products per step everywhere, "1": one everywhere (A/B)
+  return e && e[0] == '3' ? -1 : (e && e[0] == '1' ? 1 : 0);
+}();
+bool chain_collapsed(const AttDims& d) {
+  if (d.cell != kCellFactored || g_att_chain_mode < 0) return false;
+  return g_att_chain_mode > 0 || d.B <= 16;
 }
 
 constexpr size_t kAttSplitKFloats = 32ull * 64 * 4608;
@@ -99,6 +121,12 @@ struct GateOrderA { int gi, gf, go, gg, tanh_out; };  // column block of each ga
 
 }  // namespace
 
+int att_set_chain_mode(int mode) {
+  const int old = g_att_chain_mode;
+  g_att_chain_mode = mode < 0 ? -1 : (mode > 0 ? 1 : 0);
+  return old;
+}
+
 size_t att_saved_floats(const AttDims& d) { return make_alayout(d).total; }
 size_t att_saved_ints(const AttDims& d) { return make_alayout(d).itotal; }
 size_t att_fwd_scratch_floats(const AttDims& d) {
@@ -107,9 +135,9 @@ size_t att_fwd_scratch_floats(const AttDims& d) {
 size_t att_bwd_scratch_floats(const AttDims& d) {
   const ALayout L = make_alayout(d);
   const size_t N = d.N;
-  return N * L.ZW + 2 * (d.cell == kCellFactored ? N * 4 * d.F : 8) + N * L.XW + N * d.H + 2 * (size_t)d.B * d.H +
+  return N * L.ZW + 4 * (d.cell == kCellFactored ? N * 4 * d.F : 8) + N * L.XW + N * d.H + 2 * (size_t)d.B * d.H +
          (size_t)d.B * (d.C / 256) * d.P + (size_t)d.B * d.P * d.A + N * d.A + N + N * d.P + 4096 +
-         kAttSplitKFloats;
+         kAttSplitKFloats + (size_t)cdiv(L.ZW, 256) * d.B * d.H + 4;
 }
 
 int att_seq_forward(const AttDims& d, const int* bs, const unsigned char* tf,
@@ -162,6 +190,16 @@ int att_seq_forward(const AttDims& d, const int* bs, const unsigned char* tf,
     ct.add(sv + L.bz + 4 * H + A, w.f_beta_b, C);
     RC(multi_copy(ct, s));
   }
+  const bool one_product = chain_collapsed(d);
+  if (one_product) {
+    // US_g = U_g S_g;  Weff_g = US_g V_g;  bz[gate g] += U_g (S_g bV_g + bS_g)
+    RC(sgemm(false, false, H, F, F, sv + L.Ucat, F, sv + L.Scat, F, sv + L.US, F, nullptr, 0, 4, (long)H * F, (long)F * F,
+             (long)H * F, 0, 0, s));
+    RC(sgemm(false, false, H, XW, F, sv + L.US, F, sv + L.Vcat, XW, sv + L.Weff, XW, nullptr, 0, 4, (long)H * F,
+             (long)F * XW, (long)H * XW, 0, 0, s));
+    RC(sgemm(false, true, 1, F, F, sv + L.bV, F, sv + L.Scat, F, sv + L.c1, F, sv + L.bS, 0, 4, F, (long)F * F, F, F, 0, s));
+    RC(sgemm(false, true, 1, H, F, sv + L.c1, F, sv + L.Ucat, F, sv + L.bz, H, nullptr, 1, 4, F, (long)H * F, H, 0, 0, s));
+  }
 
   // ---- time-invariant parts
   RC(global_avgpool(feat, sv + L.mean, d.B, P, C, s));
@@ -199,7 +237,13 @@ int att_seq_forward(const AttDims& d, const int* bs, const unsigned char* tf,
                        saved_i + L.row_col, saved_i + L.row_token, sv + L.XA, XW, r0, r0 + b,
                        dropout_p, seed, 0, 1, err_flag, s));
     }
-    if (fac) {
+    int x_slabs = 0;      // the input product's K-chunk partials, summed by the gate kernel (no hand-off inside the product's launch)
+    if (one_product) {
+      RC(sgemm_rows16_slabs(true, b, 4 * H, XW, sv + L.XA + (size_t)r0 * XW, XW, sv + L.Weff, XW, skws, kAttSplitKWs, &x_slabs, s));
+      if (!x_slabs)
+        RC(sgemm_splitk(false, true, b, 4 * H, XW, sv + L.XA + (size_t)r0 * XW, XW, sv + L.Weff, XW, Z, ZW, nullptr, 1, skws,
+                        kAttSplitKWs, s, skctr, kSplitKCounters));
+    } else if (fac) {
       // factored chain on [x | gated context]
       RC(sgemm_splitk(false, true, b, 4 * F, XW, sv + L.XA + (size_t)r0 * XW, XW, sv + L.Vcat, XW,
                       sv + L.A1 + (size_t)r0 * 4 * F, 4 * F, sv + L.bV, 0, skws, kAttSplitKWs, s, skctr, kSplitKCounters));
@@ -214,7 +258,7 @@ int att_seq_forward(const AttDims& d, const int* bs, const unsigned char* tf,
                       ZW, nullptr, 1, skws, kAttSplitKWs, s, skctr, kSplitKCounters));
     }
     RC(lstm_pointwise_fwd(Z, ZW, cprev, sv + L.Cst + (size_t)r0 * H, hiddens + (size_t)r0 * H, b, H,
-                          go.gi, go.gf, go.go, go.gg, go.tanh_out, s));
+                          go.gi, go.gf, go.go, go.gg, go.tanh_out, s, x_slabs ? skws : nullptr, x_slabs));
   }
   return kOk;
 }
@@ -240,6 +284,11 @@ int att_seq_backward(const AttDims& d, const int* bs, const float* dH, const flo
   float* Zb = scratch + take((size_t)N * ZW);
   float* dA2 = scratch + take(fac ? (size_t)N * 4 * F : 4);
   float* dA1 = scratch + take(fac ? (size_t)N * 4 * F : 4);
+  const bool one_product = chain_collapsed(d);
+  float* A1c = scratch + take(one_product ? (size_t)N * 4 * F : 4);     // the chain's intermediate rows, formed here
+  float* A2c = scratch + take(one_product ? (size_t)N * 4 * F : 4);
+  const float* A1 = one_product ? A1c : sv + L.A1;
+  const float* A2 = one_product ? A2c : sv + L.A2;
   float* dXA = scratch + take((size_t)N * XW);
   float* Hprev = scratch + take((size_t)N * H);
   float* dh_rec = scratch + take((size_t)d.B * H);
@@ -255,15 +304,22 @@ int att_seq_backward(const AttDims& d, const int* bs, const float* dH, const flo
   CAPNET_HIP_CHECK(hipMemsetAsync(dh_rec, 0, (size_t)d.B * H * sizeof(float), s));
   CAPNET_HIP_CHECK(hipMemsetAsync(dc, 0, (size_t)d.B * H * sizeof(float), s));
 
+  // dh_{t-1} = dZ_t . Wz has K = 4H + A + C: eighteen 256-k chunks. With few rows its partials stay in the slab area and the
+  // gate kernel of step t - 1 -- the next launch -- sums them (the hand-off inside the launch was 8 of the product's 12.6 us)
+  float* dh_slabs_ws = scratch + take(d.B <= 16 ? (size_t)cdiv(ZW, 256) * d.B * H : 4);
+  int dh_slabs = 0;
   for (int t = d.steps - 1; t >= 0; --t) {
     const int b = bs[t], r0 = off[t];
     const int b_next = (t + 1 < d.steps) ? bs[t + 1] : 0;
     const float* cprev = t > 0 ? sv + L.Cst + (size_t)off[t - 1] * H : sv + L.c0;
     const float* Zf = sv + L.Zf + (size_t)r0 * ZW;
     float* Z = Zb + (size_t)r0 * ZW;
-    RC(lstm_pointwise_bwd(Zf, ZW, sv + L.Cst + (size_t)r0 * H, cprev, dH + (size_t)r0 * H, dh_rec, dc,
-                          Z, ZW, b, b_next, H, go.gi, go.gf, go.go, go.gg, go.tanh_out, s));
-    if (fac) {
+    RC(lstm_pointwise_bwd(Zf, ZW, sv + L.Cst + (size_t)r0 * H, cprev, dH + (size_t)r0 * H, dh_slabs ? dh_slabs_ws : dh_rec, dc,
+                          Z, ZW, b, b_next, H, go.gi, go.gf, go.go, go.gg, go.tanh_out, s, dh_slabs, (long)b_next * H));
+    if (one_product) {
+      RC(sgemm_splitk(false, false, b, XW, 4 * H, Z, ZW, sv + L.Weff, XW, dXA + (size_t)r0 * XW, XW,
+                      nullptr, 0, skws, kAttSplitKWs, s, skctr, kSplitKCounters));
+    } else if (fac) {
       RC(sgemm_splitk_batched(false, false, b, F, H, Z, ZW, sv + L.Ucat, F, dA2 + (size_t)r0 * 4 * F,
                               4 * F, nullptr, 0, 4, H, (long)H * F, F, 0, skws, kAttSplitKWs, s, skctr, kSplitKCounters));
       RC(sgemm_splitk_batched(false, false, b, F, F, dA2 + (size_t)r0 * 4 * F, 4 * F, sv + L.Scat, F,
@@ -281,17 +337,29 @@ int att_seq_backward(const AttDims& d, const int* bs, const float* dH, const flo
                     dalphas_bt, d.steps, t, b, P, A, C, dalpha_part, Z + 4 * H + A, Z + 4 * H, ZW,
                     de_all + (size_t)r0 * P, dwf_rows + (size_t)r0 * A, dbf_rows + r0, s));
     // dh_{t-1} (or dh0) = dZ . Wz
-    RC(sgemm_splitk(false, false, b, H, ZW, Z, ZW, sv + L.Wz, H, dh_rec, H, nullptr, 0, skws, kAttSplitKWs, s, skctr, kSplitKCounters));
+    dh_slabs = 0;
+    if (d.B <= 16)
+      RC(sgemm_rows16_slabs(false, b, H, ZW, Z, ZW, sv + L.Wz, H, dh_slabs_ws, (size_t)cdiv(ZW, 256) * d.B * H, &dh_slabs, s));
+    if (!dh_slabs)
+      RC(sgemm_splitk(false, false, b, H, ZW, Z, ZW, sv + L.Wz, H, dh_rec, H, nullptr, 0, skws, kAttSplitKWs, s, skctr, kSplitKCounters));
   }
+  if (dh_slabs) RC(reduce_slabs(dh_slabs_ws, dh_slabs, d.B, H, dh_rec, H, nullptr, 0, s));      // dh0: all B rows are alive at t = 0
   // ---- weight gradients over all rows at once
   RC(gather_prev_rows(hiddens, saved_i + L.prev_row, sv + L.h0, saved_i + L.row_sample, Hprev, N, H, s));
   RC(sgemm(true, false, ZW, H, N, Zb, ZW, Hprev, H, g.dWz, H, nullptr, 0, 1, 0, 0, 0, 0, 0, s));
   RC(colsum(Zb, ZW, N, ZW, g.dbz, 0, s));
+  if (one_product) {
+    // all rows at once: A1 = XA V^T + bV, A2_g = A1_g S_g^T + bS_g;  dA2_g = dgates_g U_g, dA1_g = dA2_g S_g
+    RC(sgemm(false, true, N, 4 * F, XW, sv + L.XA, XW, sv + L.Vcat, XW, A1c, 4 * F, sv + L.bV, 0, 1, 0, 0, 0, 0, 0, s));
+    RC(sgemm(false, true, N, F, F, A1c, 4 * F, sv + L.Scat, F, A2c, 4 * F, sv + L.bS, 0, 4, F, (long)F * F, F, F, 0, s));
+    RC(sgemm(false, false, N, F, H, Zb, ZW, sv + L.Ucat, F, dA2, 4 * F, nullptr, 0, 4, H, (long)H * F, F, 0, 0, s));
+    RC(sgemm(false, false, N, F, F, dA2, 4 * F, sv + L.Scat, F, dA1, 4 * F, nullptr, 0, 4, F, (long)F * F, F, 0, 0, s));
+  }
   if (fac) {
-    RC(sgemm(true, false, H, F, N, Zb, ZW, sv + L.A2, 4 * F, g.dUcat, F, nullptr, 0, 4, H, F,
+    RC(sgemm(true, false, H, F, N, Zb, ZW, A2, 4 * F, g.dUcat, F, nullptr, 0, 4, H, F,
              (long)H * F, 0, 0, s));
     RC(colsum(dA2, 4 * F, N, 4 * F, g.dbS, 0, s));
-    RC(sgemm(true, false, F, F, N, dA2, 4 * F, sv + L.A1, 4 * F, g.dScat, F, nullptr, 0, 4, F, F,
+    RC(sgemm(true, false, F, F, N, dA2, 4 * F, A1, 4 * F, g.dScat, F, nullptr, 0, 4, F, F,
              (long)F * F, 0, 0, s));
     RC(colsum(dA1, 4 * F, N, 4 * F, g.dbV, 0, s));
     RC(sgemm(true, false, 4 * F, XW, N, dA1, 4 * F, sv + L.XA, XW, g.dVcat, XW, nullptr, 0, 1, 0, 0, 0,

@@ -339,6 +339,7 @@ struct R16Args {
   const float* A; const float* B; float* slab; float* C; const float* bias; int* counters;
   long lda, ldb, ldc, sA, sB;
   int M, N, K, tiles_n, splits, sub, accumulate;   // a workgroup owns `sub` consecutive 256-k chunks
+  int slabs_only;                                  // leave the K-split partials in `slab` for the consumer to sum: no hand-off
 };
 
 template <bool TB>
@@ -441,6 +442,10 @@ __global__ __launch_bounds__(256) void gemm_rows16_kernel(const R16Args g) {
   const int m = r, n = n0 + 16 * wave + 4 * q4;
   const long ldo = (long)gridDim.z * g.N;               // a slab row: the batch members' columns side by side
   const long col = (long)z * g.N + n;
+  if (g.slabs_only) {                                   // slab[ks][M][N]: the next launch on the stream sums them, in slab order
+    if (m < g.M && n < g.N) *reinterpret_cast<f32x4v*>(g.slab + ((long)ks * g.M + m) * ldo + col) = acc;
+    return;
+  }
   if (g.splits == 1) {                                  // the whole K in this workgroup: no slab, no hand-off
     if (m < g.M && n < g.N) {
       float* o = g.C + (long)m * g.ldc + col;
@@ -516,6 +521,7 @@ static bool try_rows16(bool tb, int M, int N, int K, const float* A, long lda, c
   g.A = A; g.B = B; g.slab = ws; g.C = C; g.bias = bias; g.counters = counters;
   g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.sA = sA; g.sB = sB;
   g.M = M; g.N = N; g.K = K; g.tiles_n = tiles_n; g.splits = splits; g.sub = sub; g.accumulate = accumulate;
+  g.slabs_only = 0;
   static bool attr_set[2] = {false, false};
   const void* kern = tb ? (const void*)gemm_rows16_kernel<true> : (const void*)gemm_rows16_kernel<false>;
   if (!attr_set[tb]) {
@@ -528,6 +534,41 @@ static bool try_rows16(bool tb, int M, int N, int K, const float* A, long lda, c
   if (tb) hipLaunchKernelGGL(gemm_rows16_kernel<true>, dim3(tiles_n * splits, 1, batch), dim3(256), kR16LdsBytes, stream, g);
   else hipLaunchKernelGGL(gemm_rows16_kernel<false>, dim3(tiles_n * splits, 1, batch), dim3(256), kR16LdsBytes, stream, g);
   return true;
+}
+
+// The K-split partials of a product of at most 16 rows, left for the consumer: slab[k][M][N], k < *n_slabs (0: the
+// shape does not qualify). No hand-off inside the launch -- the cut only has to keep the grid within one wave of
+// workgroups, a workgroup then takes as few 256-k chunks as that allows (2.2 us each).
+int sgemm_rows16_slabs(bool tb, int M, int N, int K, const float* A, long lda, const float* B, long ldb, float* ws,
+                       size_t ws_floats, int* n_slabs, hipStream_t stream) {
+  *n_slabs = 0;
+  if (M <= 0 || M > 16 || N % 4 != 0 || N < 4 || K % 4 != 0 || lda % 4 != 0 || ldb % 4 != 0 || !aligned16(A) || !aligned16(B) ||
+      !ws || !aligned16(ws))
+    return kOk;
+  const int tiles_n = cdiv(N, 64), chunks = cdiv(K, kR16KC);
+  int sub = 1;
+  while ((long)tiles_n * cdiv(chunks, sub) > 256) ++sub;
+  const int splits = cdiv(chunks, sub);
+  if ((size_t)splits * M * N > ws_floats) return kOk;
+  R16Args g;
+  g.A = A; g.B = B; g.slab = ws; g.C = nullptr; g.bias = nullptr; g.counters = nullptr;
+  g.lda = lda; g.ldb = ldb; g.ldc = 0; g.sA = 0; g.sB = 0;
+  g.M = M; g.N = N; g.K = K; g.tiles_n = tiles_n; g.splits = splits; g.sub = sub; g.accumulate = 0;
+  g.slabs_only = 1;
+  const void* kern = tb ? (const void*)gemm_rows16_kernel<true> : (const void*)gemm_rows16_kernel<false>;
+  static bool attr_set[2] = {false, false};
+  if (!attr_set[tb]) {
+    if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kR16LdsBytes) != hipSuccess) {
+      (void)hipGetLastError();
+      return kOk;
+    }
+    attr_set[tb] = true;
+  }
+  if (tb) hipLaunchKernelGGL(gemm_rows16_kernel<true>, dim3(tiles_n * splits, 1, 1), dim3(256), kR16LdsBytes, stream, g);
+  else hipLaunchKernelGGL(gemm_rows16_kernel<false>, dim3(tiles_n * splits, 1, 1), dim3(256), kR16LdsBytes, stream, g);
+  CAPNET_LAUNCH_CHECK();
+  *n_slabs = splits;
+  return kOk;
 }
 
 int reduce_slabs(const float* slab, int count, int M, int N, float* out, long ldc, const float* bias,

@@ -19,6 +19,8 @@ int sgemm_splitk(bool ta, bool tb, int M, int N, int K, const float* A, long lda
                  size_t ws_floats, hipStream_t stream, int* counters = nullptr, size_t n_counters = 0);
 int sgemm_splitk_slabs(bool tb, int M, int N, int K, const float* A, long lda, const float* B, long ldb,
                        float* ws, size_t ws_floats, int* n_slabs, hipStream_t stream);
+int sgemm_rows16_slabs(bool tb, int M, int N, int K, const float* A, long lda, const float* B, long ldb, float* ws,
+                       size_t ws_floats, int* n_slabs, hipStream_t stream);
 int sgemm_splitk_batched(bool ta, bool tb, int M, int N, int K, const float* A, long lda,
                          const float* B, long ldb, float* C, long ldc, const float* bias,
                          int accumulate, int batch, long sA, long sB, long sC, long sBias, float* ws,
@@ -189,8 +191,10 @@ struct CopyTable {
   }
 };
 int multi_copy(const CopyTable& t, hipStream_t stream);
+// (slabs: n_slabs partial products [k][b][4H] still to be added to `pre`, in slab order -- sgemm_rows16_slabs)
 int lstm_pointwise_fwd(float* pre, long ldp, const float* c_prev, float* c_out, float* h_out, int b,
-                       int H, int gi, int gf, int go, int gg, int tanh_out, hipStream_t stream);
+                       int H, int gi, int gf, int go, int gg, int tanh_out, hipStream_t stream,
+                       const float* slabs = nullptr, int n_slabs = 0);
 int lstm_pointwise_bwd(const float* gates, long ldg, const float* c, const float* c_prev,
                        const float* dH, const float* dh_rec, float* dc_io, float* dpre, long ldq,
                        int b, int b_next, int H, int gi, int gf, int go, int gg, int tanh_out,
@@ -368,6 +372,7 @@ struct AttGrads {
   float* dWe; float* dbe; float* dwf; float* dbf; float* dWih; float* dbih; float* dWic;
   float* dbic; float* dEmb;
 };
+int att_set_chain_mode(int mode);      // the factored input product as one matrix per call: 0 by shape, 1 always, -1 never
 size_t att_saved_floats(const AttDims& d);
 size_t att_saved_ints(const AttDims& d);
 size_t att_fwd_scratch_floats(const AttDims& d);

@@ -216,15 +216,36 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-
 
 __global__ __launch_bounds__(256) void lstm_pointwise_fwd_kernel(
     float* __restrict__ pre, long ldp, const float* __restrict__ c_prev, float* __restrict__ c_out,
-    float* __restrict__ h_out, int b, int H, int gi, int gf, int go, int gg, int tanh_out) {
+    float* __restrict__ h_out, int b, int H, int gi, int gf, int go, int gg, int tanh_out,
+    const float* __restrict__ slabs, int n_slabs) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= b * H) return;
   const int row = idx / H, j = idx - row * H;
   float* p = pre + (long)row * ldp;
-  const float i = sigmoidf_(p[gi * H + j]);
-  const float f = sigmoidf_(p[gf * H + j]);
-  const float o = sigmoidf_(p[go * H + j]);
-  const float g = tanhf(p[gg * H + j]);
+  float x[4] = {p[gi * H + j], p[gf * H + j], p[go * H + j], p[gg * H + j]};
+  if (n_slabs > 0) {
+    // + the K-chunk partials of the input product (sgemm_rows16_slabs: [k][b][4H]), in slab order; all in flight at once
+    const int col[4] = {gi * H + j, gf * H + j, go * H + j, gg * H + j};
+    const float* sp = slabs + (long)row * 4 * H;
+    const long stride = (long)b * 4 * H;
+    for (int k = 0; k < n_slabs; k += 4) {
+      float v[4][4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[u][q] = sp[(long)min(k + u, n_slabs - 1) * stride + col[q]];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (k + u < n_slabs) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) x[q] += v[u][q];
+        }
+    }
+  }
+  const float i = sigmoidf_(x[0]);
+  const float f = sigmoidf_(x[1]);
+  const float o = sigmoidf_(x[2]);
+  const float g = tanhf(x[3]);
   const float cp = c_prev ? c_prev[(long)row * H + j] : 0.f;
   const float c = f * cp + i * g;
   p[gi * H + j] = i;
@@ -236,10 +257,11 @@ __global__ __launch_bounds__(256) void lstm_pointwise_fwd_kernel(
 }
 
 int lstm_pointwise_fwd(float* pre, long ldp, const float* c_prev, float* c_out, float* h_out, int b,
-                       int H, int gi, int gf, int go, int gg, int tanh_out, hipStream_t stream) {
+                       int H, int gi, int gf, int go, int gg, int tanh_out, hipStream_t stream,
+                       const float* slabs, int n_slabs) {
   if (b <= 0) return kOk;
   hipLaunchKernelGGL(lstm_pointwise_fwd_kernel, dim3(cdiv((long)b * H, 256)), dim3(256), 0, stream,
-                     pre, ldp, c_prev, c_out, h_out, b, H, gi, gf, go, gg, tanh_out);
+                     pre, ldp, c_prev, c_out, h_out, b, H, gi, gf, go, gg, tanh_out, slabs, slabs ? n_slabs : 0);
   CAPNET_LAUNCH_CHECK();
   return kOk;
 }

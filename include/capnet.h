@@ -383,6 +383,12 @@ int capnet_seq_backward_stacked(const int* dims, int nlayers, const int* batch_s
  * attention module's encoder_att  [38,39] decoder_att  [40,41] full_att  [42,43] f_beta.
  * Outputs: hiddens [N][H]; alphas [B][steps][P] (zero where a sequence has ended, :261,296).
  * encoder_att(features) is computed once per call, not once per step (:59,279). */
+/* Process-wide choice for the factored cell's input product U_g (S_g (V_g x + bV_g) + bS_g) (stylenet/model_att.py:196-236)
+ * inside capnet_att_seq_forward/backward: 0 = by shape (batches of at most 16 rows run it as ONE product per step against
+ * U_g S_g V_g, formed once per call, and form the intermediate rows for all steps at once in the backward: the steps of
+ * such a batch are chains of dependent launches, six of them this product's), 1 = always, -1 = never (three products per
+ * step each way). Returns the previous choice. Set it between calls, not between a forward and its backward. */
+int capnet_att_set_chain_mode(int mode);
 size_t capnet_att_saved_floats(const int* dims);
 size_t capnet_att_saved_ints(const int* dims);
 size_t capnet_att_fwd_scratch_floats(const int* dims);

@@ -22,6 +22,16 @@ def grad_close(a, b, rtol):
     return (a - b).abs().max().item() <= rtol * b.abs().max().item() + 1e-6
 
 
+@pytest.fixture(params=[-1, 1], ids=["chain-3-products", "chain-1-product"])
+def chain(request):
+    """Both forms of the factored input product U (S (V x)) inside capnet_att_seq_forward/backward: three products per step
+    each way, and one against U S V with the intermediate rows formed for all steps at once (the default for <= 16 rows)."""
+    from capnet._lib import lib
+    old = lib().capnet_att_set_chain_mode(request.param)
+    yield request.param
+    lib().capnet_att_set_chain_mode(old)
+
+
 def _step(dec, captions, lengths, feats, seed, ratio, mode, dev):
     dec.zero_grad()
     lens = [l - 1 for l in lengths]
@@ -37,7 +47,7 @@ def _step(dec, captions, lengths, feats, seed, ratio, mode, dev):
 
 @pytest.mark.parametrize("cname,seed,ratio", [("tf1_factual", 100, 1.0), ("tf0_happy", 101, 0.0),
                                               ("tfmix_factual", 3, 0.6), ("tfmix_sad", 5, 0.6)])
-def test_attention_decoder_matches_reference_fixture(dev, cname, seed, ratio):
+def test_attention_decoder_matches_reference_fixture(dev, chain, cname, seed, ratio):
     z = load_golden("decoder_att_tiny.npz")
     A, E, H, F, V, Cf, P = z["dims"].tolist()
     dec = DecoderFactoredLSTMAtt(A, E, H, F, V, 1, feature_size=Cf, dropout=0.0)
@@ -65,7 +75,7 @@ def test_attention_decoder_matches_reference_fixture(dev, cname, seed, ratio):
     (5, 203, 24, 20, 24, 28, 9, "angry", 0.7),
     (12, 1000, 512, 300, 512, 512, 196, "factual", 0.8),     # BASELINE config 4 cell at 12/GPU
 ])
-def test_attention_decoder_matches_oracle_seeded(dev, B, V, A, E, F, H, P, mode, ratio):
+def test_attention_decoder_matches_oracle_seeded(dev, chain, B, V, A, E, F, H, P, mode, ratio):
     Cf = 512 if P < 100 else 2048
     dec = DecoderFactoredLSTMAtt(A, E, H, F, V, 1, feature_size=Cf, dropout=0.0)
     p = synthetic.decoder_state(dec.state_dict(), seed=B, bias_range=0.05)
