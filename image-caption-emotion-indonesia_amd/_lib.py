@@ -137,6 +137,7 @@ SIGNATURES = {
     "capnet_lstm_pointwise_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "capnet_conv1x1_fwd_areg": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _l, _i, _i, _i, _vp]),
     "capnet_trunk_set_timing": (_i, [_vp, _i]),
+    "capnet_trunk_time_next_pass": (_i, [_vp]),
     "capnet_trunk_collect_timing": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(_l),
                                          C.POINTER(C.c_double)]),
     "capnet_packed_targets": (_i, [_vp, _i, _i, _ip, _vp, _vp]),

@@ -200,10 +200,14 @@ int att_step_fwd(const float* att1, const float* feat, const float* att2, float*
 // grid = (rows, C/256), 256 threads = 4 waves; a wave owns 14 pixels at a time (14 independent
 // 16-B loads in flight: 4 sweeps for P = 196), its lanes 256 channels (float4). dxa: gradient of the gated context
 // (ld ldx). Outputs: dgate_out (ld ldz) = d f_beta pre-activation; dalpha_part [rows][C/256][P].
+// dxa_slabs (optional): d[x | ctx] still lies in n_slabs K-chunk partials [k][rows][emb_cols + C] (sgemm_rows16_slabs); every
+// workgroup sums its own channels, in slab order, and the row's first one also sums the embedding columns into
+// dxa[-emb_cols .. 0) (what scatter_input_grad reads after the time loop).
 __global__ __launch_bounds__(kAttThreads) void att_context_bwd_kernel(
-    const float* __restrict__ feat, const float* __restrict__ dxa, long ldx,
+    const float* __restrict__ feat, float* __restrict__ dxa, long ldx,
     const float* __restrict__ gate, long ldzg, const float* __restrict__ awe, int P, int C,
-    float* __restrict__ dgate_out, long ldz, float* __restrict__ dalpha_part) {
+    float* __restrict__ dgate_out, long ldz, float* __restrict__ dalpha_part,
+    const float* __restrict__ dxa_slabs, int n_slabs, int emb_cols) {
   const int j = blockIdx.x, cb = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = cb * kCtxCh + lane * 4;
@@ -211,7 +215,26 @@ __global__ __launch_bounds__(kAttThreads) void att_context_bwd_kernel(
   {
     // (three independent 16-B loads, then the store: element-wise dword loads around a conditional store came out
     //  as four dependent round trips)
-    const float4 dg4 = *reinterpret_cast<const float4*>(dxa + (long)j * ldx + c);
+    float4 dg4;
+    if (n_slabs > 0) {
+      const long xw = emb_cols + C, stride = (long)gridDim.x * xw;
+      auto slab_sum = [&](const float* q) {
+        float4 v[8], a = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < n_slabs; k += 8) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(q + (long)min(k + u, n_slabs - 1) * stride);
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            if (k + u < n_slabs) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
+        }
+        return a;
+      };
+      dg4 = slab_sum(dxa_slabs + (long)j * xw + emb_cols + c);
+      if (cb == 0 && (int)threadIdx.x * 4 < emb_cols)
+        *reinterpret_cast<float4*>(dxa + (long)j * ldx - emb_cols + 4 * threadIdx.x) = slab_sum(dxa_slabs + (long)j * xw + 4 * threadIdx.x);
+    } else {
+      dg4 = *reinterpret_cast<const float4*>(dxa + (long)j * ldx + c);
+    }
     const float4 g4 = *reinterpret_cast<const float4*>(gate + (long)j * ldzg + c);
     const float4 aw4 = *reinterpret_cast<const float4*>(awe + (long)j * C + c);
     const float dg[4] = {dg4.x, dg4.y, dg4.z, dg4.w}, g[4] = {g4.x, g4.y, g4.z, g4.w}, aw[4] = {aw4.x, aw4.y, aw4.z, aw4.w};
@@ -323,22 +346,24 @@ __global__ __launch_bounds__(kAttThreads) void att_scores_bwd_kernel(
 
 int att_step_bwd(const float* att1, const float* feat, const float* att2, long ldz2,
                  const float* gate, long ldzg, const float* awe, const float* alpha,
-                 const float* wf, const float* dxa, long ldx, const float* dalphas_bt, int steps,
+                 const float* wf, float* dxa, long ldx, const float* dalphas_bt, int steps,
                  int t, int rows, int P, int A, int C, float* dalpha_part, float* dgate_out,
                  float* datt2, long ldz, float* de_out, float* dwf_rows, float* dbf_rows,
-                 hipStream_t stream) {
+                 hipStream_t stream, const float* dxa_slabs, int n_slabs, int emb_cols) {
   if (rows <= 0) return kOk;
   CAPNET_REQUIRE(att1 && feat && att2 && gate && awe && alpha && wf && dxa && dalpha_part &&
                      dgate_out && datt2 && de_out && dwf_rows && dbf_rows,
                  "att_step_bwd: null argument");
   CAPNET_REQUIRE(ldzg % 4 == 0 && aligned16(dxa) && aligned16(gate) && aligned16(awe) && aligned16(dgate_out) && aligned16(feat),
                  "att_step_bwd: 16-byte alignment of the context rows");
+  CAPNET_REQUIRE(!dxa_slabs || (emb_cols % 4 == 0 && emb_cols <= 4 * kAttThreads && aligned16(dxa_slabs)),
+                 "att_step_bwd: embedding columns of the slab form");
   CAPNET_REQUIRE(A % 4 == 0 && C % kCtxCh == 0 && P > 0 && ldz % 4 == 0 && ldx % 4 == 0 && ldz2 % 2 == 0 &&
                      (size_t)(P + 8 * kScoreBwdCh) * 4 <= 64 * 1024,
                  "att_step_bwd: A=%d C=%d P=%d", A, C, P);
   // gate rows use their own leading dimension (saved forward Z buffer)
   hipLaunchKernelGGL(att_context_bwd_kernel, dim3(rows, C / kCtxCh), dim3(kAttThreads), 0, stream, feat,
-                     dxa, ldx, gate, ldzg, awe, P, C, dgate_out, ldz, dalpha_part);
+                     dxa, ldx, gate, ldzg, awe, P, C, dgate_out, ldz, dalpha_part, dxa_slabs, dxa_slabs ? n_slabs : 0, emb_cols);
   hipLaunchKernelGGL(att_scores_bwd_kernel, dim3(rows, cdiv(A, kScoreBwdCh)), dim3(kAttThreads),
                      (P + 8 * kScoreBwdCh) * sizeof(float), stream, att1, att2, ldz2, wf, alpha,
                      dalpha_part, C / kCtxCh, dalphas_bt, steps, t, P, A, datt2, ldz, de_out, dwf_rows,

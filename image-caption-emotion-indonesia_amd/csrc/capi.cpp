@@ -554,6 +554,7 @@ int capnet_clamp_adam(int n, float* const* params, float* const* grads, float* c
 int capnet_trunk_set_timing(capnet_trunk_t* t, int enable) {
   return trunk_set_timing(reinterpret_cast<Trunk*>(t), enable);
 }
+int capnet_trunk_time_next_pass(capnet_trunk_t* t) { return trunk_time_next_pass(reinterpret_cast<Trunk*>(t)); }
 int capnet_trunk_collect_timing(capnet_trunk_t* t, double* conv_ms, long* conv_launches,
                                 double* conv_flops) {
   return trunk_collect_timing(reinterpret_cast<Trunk*>(t), conv_ms, conv_launches, conv_flops);

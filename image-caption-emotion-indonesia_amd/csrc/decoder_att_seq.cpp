@@ -164,6 +164,11 @@ int att_seq_forward(const AttDims& d, const int* bs, const unsigned char* tf,
     RC(build_rows(m, saved_i + L.row_sample, saved_i + L.row_col, saved_i + L.row_token,
                   saved_i + L.prev_row, s));
   }
+  float* skws = scratch + (size_t)d.B * d.V + 64;
+  float* escore = skws + kAttSplitKFloats;   // raw attention scores of the current step [b][P]
+  // tile counters of the one-launch products for steps of <= 16 rows (gemm_rows16_kernel): the tail of the slab area
+  int* skctr = reinterpret_cast<int*>(skws + kAttSplitKWs);
+  CAPNET_HIP_CHECK(hipMemsetAsync(skctr, 0, kSplitKCounters * sizeof(int), s));
   // ---- pack weights
   const bool fac = d.cell == kCellFactored;
   const GateOrderA go = fac ? GateOrderA{0, 1, 2, 3, 0} : GateOrderA{0, 1, 3, 2, 1};
@@ -197,16 +202,19 @@ int att_seq_forward(const AttDims& d, const int* bs, const unsigned char* tf,
              (long)H * F, 0, 0, s));
     RC(sgemm(false, false, H, XW, F, sv + L.US, F, sv + L.Vcat, XW, sv + L.Weff, XW, nullptr, 0, 4, (long)H * F,
              (long)F * XW, (long)H * XW, 0, 0, s));
-    RC(sgemm(false, true, 1, F, F, sv + L.bV, F, sv + L.Scat, F, sv + L.c1, F, sv + L.bS, 0, 4, F, (long)F * F, F, F, 0, s));
-    RC(sgemm(false, true, 1, H, F, sv + L.c1, F, sv + L.Ucat, F, sv + L.bz, H, nullptr, 1, 4, F, (long)H * F, H, 0, 0, s));
+    RC(sgemm_splitk_batched(false, true, 1, F, F, sv + L.bV, F, sv + L.Scat, F, sv + L.c1, F, sv + L.bS, 0, 4, F, (long)F * F, F, F,
+                            skws, kAttSplitKWs, s, skctr, kSplitKCounters));
+    RC(sgemm_splitk_batched(false, true, 1, H, F, sv + L.c1, F, sv + L.Ucat, F, sv + L.bz, H, nullptr, 1, 4, F, (long)H * F, H, 0,
+                            skws, kAttSplitKWs, s, skctr, kSplitKCounters));
   }
 
   // ---- time-invariant parts
   RC(global_avgpool(feat, sv + L.mean, d.B, P, C, s));
-  RC(sgemm(false, true, d.B, H, C, sv + L.mean, C, w.init_h_w, C, sv + L.h0, H, w.init_h_b, 0, 1, 0,
-           0, 0, 0, 0, s));
-  RC(sgemm(false, true, d.B, H, C, sv + L.mean, C, w.init_c_w, C, sv + L.c0, H, w.init_c_b, 0, 1, 0,
-           0, 0, 0, 0, s));
+  // (B x 512 x 2048: a handful of 64 x 64 tiles walking the whole K took 80 us each at 12 rows; K-split: 9)
+  RC(sgemm_splitk(false, true, d.B, H, C, sv + L.mean, C, w.init_h_w, C, sv + L.h0, H, w.init_h_b, 0, skws, kAttSplitKWs, s,
+                  skctr, kSplitKCounters));
+  RC(sgemm_splitk(false, true, d.B, H, C, sv + L.mean, C, w.init_c_w, C, sv + L.c0, H, w.init_c_b, 0, skws, kAttSplitKWs, s,
+                  skctr, kSplitKCounters));
   RC(sgemm(false, true, d.B * P, A, C, feat, C, w.enc_att_w, C, sv + L.att1, A, w.enc_att_b, 0, 1,
            0, 0, 0, 0, 0, s));
   CAPNET_HIP_CHECK(hipMemsetAsync(sv + L.XA, 0, (size_t)N * XW * sizeof(float), s));
@@ -215,11 +223,6 @@ int att_seq_forward(const AttDims& d, const int* bs, const unsigned char* tf,
                    saved_i + L.row_token, sv + L.XA, XW, 0, N, dropout_p, seed,
                    training && dropout_p > 0.f, 0, err_flag, s));
 
-  float* skws = scratch + (size_t)d.B * d.V + 64;
-  float* escore = skws + kAttSplitKFloats;   // raw attention scores of the current step [b][P]
-  // tile counters of the one-launch products for steps of <= 16 rows (gemm_rows16_kernel): the tail of the slab area
-  int* skctr = reinterpret_cast<int*>(skws + kAttSplitKWs);
-  CAPNET_HIP_CHECK(hipMemsetAsync(skctr, 0, kSplitKCounters * sizeof(int), s));
   for (int t = 0; t < d.steps; ++t) {
     const int b = bs[t], r0 = off[t];
     const float* hprev = t > 0 ? hiddens + (size_t)off[t - 1] * H : sv + L.h0;
@@ -316,9 +319,12 @@ int att_seq_backward(const AttDims& d, const int* bs, const float* dH, const flo
     float* Z = Zb + (size_t)r0 * ZW;
     RC(lstm_pointwise_bwd(Zf, ZW, sv + L.Cst + (size_t)r0 * H, cprev, dH + (size_t)r0 * H, dh_slabs ? dh_slabs_ws : dh_rec, dc,
                           Z, ZW, b, b_next, H, go.gi, go.gf, go.go, go.gg, go.tanh_out, s, dh_slabs, (long)b_next * H));
+    int dx_slabs = 0;     // d[x | ctx] as K-chunk partials: the context kernel -- the next launch -- sums them
     if (one_product) {
-      RC(sgemm_splitk(false, false, b, XW, 4 * H, Z, ZW, sv + L.Weff, XW, dXA + (size_t)r0 * XW, XW,
-                      nullptr, 0, skws, kAttSplitKWs, s, skctr, kSplitKCounters));
+      RC(sgemm_rows16_slabs(false, b, XW, 4 * H, Z, ZW, sv + L.Weff, XW, skws, kAttSplitKWs, &dx_slabs, s));
+      if (!dx_slabs)
+        RC(sgemm_splitk(false, false, b, XW, 4 * H, Z, ZW, sv + L.Weff, XW, dXA + (size_t)r0 * XW, XW,
+                        nullptr, 0, skws, kAttSplitKWs, s, skctr, kSplitKCounters));
     } else if (fac) {
       RC(sgemm_splitk_batched(false, false, b, F, H, Z, ZW, sv + L.Ucat, F, dA2 + (size_t)r0 * 4 * F,
                               4 * F, nullptr, 0, 4, H, (long)H * F, F, 0, skws, kAttSplitKWs, s, skctr, kSplitKCounters));
@@ -335,7 +341,7 @@ int att_seq_backward(const AttDims& d, const int* bs, const float* dH, const flo
     RC(att_step_bwd(sv + L.att1, feat, Zf + 4 * H, ZW, Zf + 4 * H + A, ZW, sv + L.awe + (size_t)r0 * C,
                     sv + L.alpha + (size_t)r0 * P, w.full_att_w, dXA + (size_t)r0 * XW + E, XW,
                     dalphas_bt, d.steps, t, b, P, A, C, dalpha_part, Z + 4 * H + A, Z + 4 * H, ZW,
-                    de_all + (size_t)r0 * P, dwf_rows + (size_t)r0 * A, dbf_rows + r0, s));
+                    de_all + (size_t)r0 * P, dwf_rows + (size_t)r0 * A, dbf_rows + r0, s, dx_slabs ? skws : nullptr, dx_slabs, E));
     // dh_{t-1} (or dh0) = dZ . Wz
     dh_slabs = 0;
     if (d.B <= 16)
@@ -350,7 +356,8 @@ int att_seq_backward(const AttDims& d, const int* bs, const float* dH, const flo
   RC(colsum(Zb, ZW, N, ZW, g.dbz, 0, s));
   if (one_product) {
     // all rows at once: A1 = XA V^T + bV, A2_g = A1_g S_g^T + bS_g;  dA2_g = dgates_g U_g, dA1_g = dA2_g S_g
-    RC(sgemm(false, true, N, 4 * F, XW, sv + L.XA, XW, sv + L.Vcat, XW, A1c, 4 * F, sv + L.bV, 0, 1, 0, 0, 0, 0, 0, s));
+    RC(sgemm_splitk(false, true, N, 4 * F, XW, sv + L.XA, XW, sv + L.Vcat, XW, A1c, 4 * F, sv + L.bV, 0, skws, kAttSplitKWs, s,
+                    skctr, kSplitKCounters));
     RC(sgemm(false, true, N, F, F, A1c, 4 * F, sv + L.Scat, F, A2c, 4 * F, sv + L.bS, 0, 4, F, (long)F * F, F, F, 0, s));
     RC(sgemm(false, false, N, F, H, Zb, ZW, sv + L.Ucat, F, dA2, 4 * F, nullptr, 0, 4, H, (long)H * F, F, 0, 0, s));
     RC(sgemm(false, false, N, F, F, dA2, 4 * F, sv + L.Scat, F, dA1, 4 * F, nullptr, 0, 4, F, (long)F * F, F, 0, 0, s));

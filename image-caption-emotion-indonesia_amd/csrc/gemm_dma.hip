@@ -346,7 +346,8 @@ int sgemm_nt_dma(int M, int N, int K, const float* A, long lda, const float* B, 
   NtArgs a{};
   a.A = A; a.B = B; a.C = C; a.bias = bias;
   a.M = M; a.N = N; a.K = K;
-  const int BN = pick_bn(N);
+  // (128-column tiles once they alone fill the chip: encoder_att over 12 x 196 pixels, 2352 x 512, was 76 workgroups)
+  const int BN = (pick_bn(N) == 128 && (long)cdiv(M, DBM) * (N / 128) >= 200) ? 128 : 64;
   a.tiles_m = cdiv(M, DBM); a.tiles_n = N / BN;
   magic_div((unsigned)a.tiles_n, &a.tn_mul, &a.tn_sh);
   a.conv = 0; a.lda = (int)lda;

@@ -149,6 +149,7 @@ int trunk_conv_tile_n(const Trunk* t, int i);
 double trunk_flops(const Trunk* t);
 double trunk_conv_flops(const Trunk* t, int i);
 int trunk_set_timing(Trunk* t, int enable);
+int trunk_time_next_pass(Trunk* t);
 int trunk_collect_timing(Trunk* t, double* conv_ms, long* conv_launches, double* conv_flops);
 int trunk_set_tail_balance(Trunk* t, int on);
 int trunk_update_running(Trunk* t, const float* workspace, float* const* bn_rmean, float* const* bn_rvar,
@@ -246,10 +247,10 @@ int att_step_fwd(const float* att1, const float* feat, const float* att2, float*
                  float* xa_out, long ldx, float* escore, hipStream_t stream);
 int att_step_bwd(const float* att1, const float* feat, const float* att2, long ldz2,
                  const float* gate, long ldzg, const float* awe, const float* alpha,
-                 const float* wf, const float* dxa, long ldx, const float* dalphas_bt, int steps,
+                 const float* wf, float* dxa, long ldx, const float* dalphas_bt, int steps,
                  int t, int rows, int P, int A, int C, float* dalpha_part, float* dgate_out,
                  float* datt2, long ldz, float* de_out, float* dwf_rows, float* dbf_rows,
-                 hipStream_t stream);
+                 hipStream_t stream, const float* dxa_slabs = nullptr, int n_slabs = 0, int emb_cols = 0);
 int att_datt1(const float* att1, const float* att2_rows, long ldz2, const float* de_rows,
               const float* wf, const int* off, int steps, int B, int P, int A, float* datt1,
               hipStream_t stream);

@@ -335,33 +335,54 @@ int lstm_pointwise_bwd(const float* gates, long ldg, const float* c, const float
 }
 
 // ---- row argmax (first maximum, like torch.max(1) on CPU) --------------------------------
+// (16-B loads, eight in flight per thread, when the row allows it; a thread meets its indices in increasing order, so a
+//  strict comparison keeps the first maximum, and ties between threads go to the lower index)
 __global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restrict__ x, int ld,
                                                           int V, int* __restrict__ out) {
   const int row = blockIdx.x;
   const float* p = x + (long)row * ld;
   float best = -INFINITY;
   int bi = 0x7fffffff;
-  for (int j = threadIdx.x; j < V; j += blockDim.x) {
+  int done = 0;
+  if (ld % 4 == 0 && (reinterpret_cast<size_t>(x) & 15) == 0) {
+    const int V4 = V / 4;
+    for (int j0 = threadIdx.x; j0 < V4; j0 += 8 * 256) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(p + 4 * (long)min(j0 + 256 * u, V4 - 1));
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int j = 4 * (j0 + 256 * u);
+        if (j0 + 256 * u < V4) {
+          if (v[u].x > best) { best = v[u].x; bi = j; }
+          if (v[u].y > best) { best = v[u].y; bi = j + 1; }
+          if (v[u].z > best) { best = v[u].z; bi = j + 2; }
+          if (v[u].w > best) { best = v[u].w; bi = j + 3; }
+        }
+      }
+    }
+    done = 4 * V4;
+  }
+  for (int j = done + threadIdx.x; j < V; j += blockDim.x) {
     const float v = p[j];
     if (v > best || (v == best && j < bi)) { best = v; bi = j; }
   }
-  __shared__ float s_v[256];
-  __shared__ int s_i[256];
-  s_v[threadIdx.x] = best;
-  s_i[threadIdx.x] = bi;
-  __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if (threadIdx.x < s) {
-      const float v = s_v[threadIdx.x + s];
-      const int i2 = s_i[threadIdx.x + s];
-      if (v > s_v[threadIdx.x] || (v == s_v[threadIdx.x] && i2 < s_i[threadIdx.x])) {
-        s_v[threadIdx.x] = v;
-        s_i[threadIdx.x] = i2;
-      }
-    }
-    __syncthreads();
+  // wave: six exchange rounds; then the four waves' winners through LDS
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float v = __shfl_xor(best, o);
+    const int i2 = __shfl_xor(bi, o);
+    if (v > best || (v == best && i2 < bi)) { best = v; bi = i2; }
   }
-  if (threadIdx.x == 0) out[row] = s_i[0] == 0x7fffffff ? 0 : s_i[0];
+  __shared__ float s_v[4];
+  __shared__ int s_i[4];
+  if ((threadIdx.x & 63) == 0) { s_v[threadIdx.x >> 6] = best; s_i[threadIdx.x >> 6] = bi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w)
+      if (s_v[w] > best || (s_v[w] == best && s_i[w] < bi)) { best = s_v[w]; bi = s_i[w]; }
+    out[row] = bi == 0x7fffffff ? 0 : bi;
+  }
 }
 
 int argmax_rows(const float* x, int rows, int ld, int V, int* out, hipStream_t stream) {

@@ -67,6 +67,7 @@ struct Trunk {
   int timing_every = 1;   // ... on every N-th pass (an event pair is a bubble in the stream: 310 per pass cost 2.5 % images/s)
   long pass_no = 0;
   bool timing_now = false;
+  bool timing_once = false;   // trunk_time_next_pass: the next pass is bracketed whatever `timing` says
   std::vector<hipEvent_t> ev_pool;    // events are created once and handed out again after every collect
   size_t ev_next = 0;
   std::vector<hipEvent_t> ev;
@@ -223,6 +224,14 @@ int trunk_set_timing(Trunk* t, int enable) {
   t->timing_every = enable > 1 ? enable : 1;
   t->pass_no = 0;
   t->timing_now = false;
+  return kOk;
+}
+
+// The next pass only (a caller that replays the other passes from hipGraphs, where events cannot ride, launches every
+// N-th pass directly and brackets that one).
+int trunk_time_next_pass(Trunk* t) {
+  CAPNET_REQUIRE(t != nullptr, "trunk_time_next_pass: null");
+  t->timing_once = true;
   return kOk;
 }
 
@@ -661,7 +670,8 @@ int trunk_forward(Trunk* t, const float* images_nchw, const float* const* w_pack
   Ctx c{t, w_packed, bn_gamma, bn_beta, bn_rmean, bn_rvar, train, momentum, eps, workspace, stream};
   c.in_exps = in_exps;
   c.err = err_flag;
-  t->timing_now = t->timing && (t->pass_no++ % t->timing_every == 0);
+  t->timing_now = t->timing_once || (t->timing && (t->pass_no++ % t->timing_every == 0));
+  t->timing_once = false;
   const int B = t->B;
   float* X[2] = {workspace + t->off_x[0], workspace + t->off_x[1]};
   float* Y1 = workspace + t->off_y1;

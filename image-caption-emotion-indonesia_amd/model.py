@@ -138,6 +138,7 @@ class _TrunkRunner:
                     self.convs.append(blk.downsample[0]); self.bns.append(blk.downsample[1])
         self.plans = {}
         self.timing = False
+        self.timing_every, self._graph_timing, self._timed_passes = 1, False, 0
         self.packed = None
         self.packed_key = None
         self._exp_epoch = 0
@@ -325,8 +326,18 @@ class _TrunkRunner:
             f = torch.empty((b, side, side, 2048), dtype=torch.float32, device=dev) if want_map else None
             return p, f
 
-        use_graph = (graph and train and defer_stats and not self.timing and
-                     os.environ.get("CAPNET_NO_GRAPH") != "1")
+        use_graph = graph and train and defer_stats and os.environ.get("CAPNET_NO_GRAPH") != "1"
+        if use_graph and self.timing:
+            # event records cannot ride in a replayed graph: every N-th pass is launched directly and bracketed
+            # (capnet_trunk_time_next_pass), the others replay; the C side's own every-N-th counter stays off, so that
+            # the launches under capture are never bracketed
+            if not self._graph_timing:
+                check(L.capnet_trunk_set_timing(plan["handle"], 0), "capnet_trunk_set_timing")
+                self._graph_timing = True
+            self._timed_passes += 1
+            if (self._timed_passes - 1) % self.timing_every == 0:
+                check(L.capnet_trunk_time_next_pass(plan["handle"]), "capnet_trunk_time_next_pass")
+                use_graph = False
         if use_graph:
             # The pass is ~330 launches with fixed arguments: captured once per (slot, outputs,
             # tile mode) into a hipGraph and replayed -- one launch call on the host instead of
@@ -367,6 +378,8 @@ class _TrunkRunner:
         """Per-conv hipEvent timing (bench.py roofline); event records cannot ride in a replayed
         graph, so timed passes are launched directly."""
         self.timing = bool(on)
+        self.timing_every = max(int(on), 1)
+        self._graph_timing, self._timed_passes = False, 0
         check(_lib.lib().capnet_trunk_set_timing(plan["handle"], int(on)), "capnet_trunk_set_timing")
 
 

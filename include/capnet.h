@@ -142,6 +142,9 @@ int capnet_trunk_update_running(const capnet_trunk_t* t, const void* workspace,
  * collect synchronises on them and returns the totals since the previous collect. enable = N > 1:
  * only every N-th pass is bracketed (an event pair is a bubble in its stream). */
 int capnet_trunk_set_timing(capnet_trunk_t* t, int enable);
+/* Brackets the NEXT capnet_trunk_forward only, whatever capnet_trunk_set_timing says: for a caller that replays most passes
+ * from hipGraphs (events cannot ride in a replayed graph) and launches every N-th one directly. */
+int capnet_trunk_time_next_pass(capnet_trunk_t* t);
 int capnet_trunk_collect_timing(capnet_trunk_t* t, double* conv_ms, long* conv_launches,
                                 double* conv_flops);
 /* Weight image convolution i expects: 0 = rows [Cout][row_stride] (capnet_pack_conv_weight),

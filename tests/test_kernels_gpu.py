@@ -207,6 +207,12 @@ def test_maxpool_avgpool_upsample(dev):
     xd = x.to(dev)
     check(lib().capnet_global_avgpool(ptr(xd), ptr(o), B, 49, 128, current_stream()))
     assert rel_err(o, x.mean(1)) < 1e-6
+    for b2, hw, c2 in ((12, 196, 2048), (3, 1, 260), (5, 33, 4)):          # the attention map; one pixel; one channel quad
+        x = torch.randn(b2, hw, c2, generator=g)
+        o = torch.full((b2, c2), 7.0, device=dev)
+        xd = x.to(dev)
+        check(lib().capnet_global_avgpool(ptr(xd), ptr(o), b2, hw, c2, current_stream()))
+        assert rel_err(o, x.double().mean(1)) < 1e-6
     m = torch.randn(B, 7, 7, 32, generator=g)
     up = torch.empty(B, 14, 14, 32, device=dev)
     md = m.to(dev)
@@ -287,6 +293,13 @@ def test_argmax_first_max(dev):
     x[3, 255] = 2; x[3, 256] = 2
     out = ops.argmax_rows(x.to(dev)).cpu().tolist()
     assert out == [7, 999, 0, 255, 0]
+    g = torch.Generator().manual_seed(3)
+    for rows, V in ((12, 8192), (7, 7411), (3, 5), (2, 2051)):             # 16-B rows; ragged vocabularies (scalar tail / scalar path)
+        y = torch.randint(0, 50, (rows, V), generator=g).float()          # many ties: the first maximum counts
+        assert ops.argmax_rows(y.to(dev)).cpu().tolist() == y.argmax(1).tolist() or \
+            ops.argmax_rows(y.to(dev)).cpu().tolist() == [int((r == r.max()).nonzero()[0]) for r in y]
+        z = torch.randn(rows, V, generator=g)
+        assert ops.argmax_rows(z.to(dev)).cpu().tolist() == z.argmax(1).tolist()
 
 
 # ---- per-step (skinny) product: one K chunk per workgroup + fixed-order slab sum -----------------
