@@ -80,15 +80,25 @@ ALayout make_alayout(const AttDims& d) {
 // and a 512 x 512 x 2348 product per gate, ~5 GFLOP, where the steps' own products are 0.05 GFLOP each) and bias
 // U_g (S_g bV_g + bS_g); the intermediate rows A1 = V x + bV, A2 = S A1 + bS the weight gradients need, and their
 // gradients dA2 = dgates U, dA1 = dA2 S, are formed for ALL rows at once after the backward loop -- the same sums in another
-// association (fp32 rounding apart: the fixtures of the reference's own class hold either way). 0 = by shape (B <= 16),
-// 1 = always, -1 = never.
+// association (fp32 rounding apart: the fixtures of the reference's own class hold either way). It pays up to the 128 rows
+// the K-split step products take (64 / 96 rows: +5.4 % / +4.1 % images per second). 0 = by shape (B <= 128), 1 = always,
+// -1 = never.
 int g_att_chain_mode = [] {
   const char* e = getenv("CAPNET_ATT_CHAIN");        // "3": three products per step everywhere, "1": one everywhere (A/B)
   return e && e[0] == '3' ? -1 : (e && e[0] == '1' ? 1 : 0);
 }();
 bool chain_collapsed(const AttDims& d) {
   if (d.cell != kCellFactored || g_att_chain_mode < 0) return false;
-  return g_att_chain_mode > 0 || d.B <= 16;
+  return g_att_chain_mode > 0 || d.B <= 128;
+}
+
+// The K-chunk partials of a step product, left for its consumer to sum: slab[k][M][N], k < *n (0: the shape qualifies
+// for neither kernel and the caller takes the summed form).
+int product_slabs(bool tb, int M, int N, int K, const float* A, long lda, const float* B, long ldb, float* ws, size_t ws_floats,
+                  int* n, hipStream_t s) {
+  const int rc = sgemm_rows16_slabs(tb, M, N, K, A, lda, B, ldb, ws, ws_floats, n, s);
+  if (rc || *n) return rc;
+  return sgemm_splitk_slabs(tb, M, N, K, A, lda, B, ldb, ws, ws_floats, n, s);
 }
 
 constexpr size_t kAttSplitKFloats = 32ull * 64 * 4608;
@@ -137,7 +147,7 @@ size_t att_bwd_scratch_floats(const AttDims& d) {
   const size_t N = d.N;
   return N * L.ZW + 4 * (d.cell == kCellFactored ? N * 4 * d.F : 8) + N * L.XW + N * d.H + 2 * (size_t)d.B * d.H +
          (size_t)d.B * (d.C / 256) * d.P + (size_t)d.B * d.P * d.A + N * d.A + N + N * d.P + 4096 +
-         kAttSplitKFloats + (size_t)cdiv(L.ZW, 256) * d.B * d.H + 4;
+         kAttSplitKFloats + (d.B <= 128 ? (size_t)cdiv(L.ZW, 64) * d.B * d.H : 4) + 4;
 }
 
 int att_seq_forward(const AttDims& d, const int* bs, const unsigned char* tf,
@@ -241,12 +251,14 @@ int att_seq_forward(const AttDims& d, const int* bs, const unsigned char* tf,
                        dropout_p, seed, 0, 1, err_flag, s));
     }
     int x_slabs = 0;      // the input product's K-chunk partials, summed by the gate kernel (no hand-off inside the product's launch)
-    if (one_product) {
-      RC(sgemm_rows16_slabs(true, b, 4 * H, XW, sv + L.XA + (size_t)r0 * XW, XW, sv + L.Weff, XW, skws, kAttSplitKWs, &x_slabs, s));
+    // one product per step: [x | gated context] . Wx^T with Wx = U S V (the collapsed chain) or nn.LSTMCell's weight_ih
+    const float* Wx = one_product ? sv + L.Weff : (fac ? nullptr : sv + L.Vcat);
+    if (Wx) {
+      RC(product_slabs(true, b, 4 * H, XW, sv + L.XA + (size_t)r0 * XW, XW, Wx, XW, skws, kAttSplitKWs, &x_slabs, s));
       if (!x_slabs)
-        RC(sgemm_splitk(false, true, b, 4 * H, XW, sv + L.XA + (size_t)r0 * XW, XW, sv + L.Weff, XW, Z, ZW, nullptr, 1, skws,
+        RC(sgemm_splitk(false, true, b, 4 * H, XW, sv + L.XA + (size_t)r0 * XW, XW, Wx, XW, Z, ZW, nullptr, 1, skws,
                         kAttSplitKWs, s, skctr, kSplitKCounters));
-    } else if (fac) {
+    } else {
       // factored chain on [x | gated context]
       RC(sgemm_splitk(false, true, b, 4 * F, XW, sv + L.XA + (size_t)r0 * XW, XW, sv + L.Vcat, XW,
                       sv + L.A1 + (size_t)r0 * 4 * F, 4 * F, sv + L.bV, 0, skws, kAttSplitKWs, s, skctr, kSplitKCounters));
@@ -255,10 +267,6 @@ int att_seq_forward(const AttDims& d, const int* bs, const unsigned char* tf,
                               (long)F * F, F, F, skws, kAttSplitKWs, s, skctr, kSplitKCounters));
       RC(sgemm_splitk_batched(false, true, b, H, F, sv + L.A2 + (size_t)r0 * 4 * F, 4 * F, sv + L.Ucat,
                               F, Z, ZW, nullptr, 1, 4, F, (long)H * F, H, 0, skws, kAttSplitKWs, s, skctr, kSplitKCounters));
-    } else {
-      // nn.LSTMCell input product: gates += [x | gated context] . weight_ih^T
-      RC(sgemm_splitk(false, true, b, 4 * H, XW, sv + L.XA + (size_t)r0 * XW, XW, sv + L.Vcat, XW, Z,
-                      ZW, nullptr, 1, skws, kAttSplitKWs, s, skctr, kSplitKCounters));
     }
     RC(lstm_pointwise_fwd(Z, ZW, cprev, sv + L.Cst + (size_t)r0 * H, hiddens + (size_t)r0 * H, b, H,
                           go.gi, go.gf, go.go, go.gg, go.tanh_out, s, x_slabs ? skws : nullptr, x_slabs));
@@ -307,9 +315,11 @@ int att_seq_backward(const AttDims& d, const int* bs, const float* dH, const flo
   CAPNET_HIP_CHECK(hipMemsetAsync(dh_rec, 0, (size_t)d.B * H * sizeof(float), s));
   CAPNET_HIP_CHECK(hipMemsetAsync(dc, 0, (size_t)d.B * H * sizeof(float), s));
 
-  // dh_{t-1} = dZ_t . Wz has K = 4H + A + C: eighteen 256-k chunks. With few rows its partials stay in the slab area and the
-  // gate kernel of step t - 1 -- the next launch -- sums them (the hand-off inside the launch was 8 of the product's 12.6 us)
-  float* dh_slabs_ws = scratch + take(d.B <= 16 ? (size_t)cdiv(ZW, 256) * d.B * H : 4);
+  // dh_{t-1} = dZ_t . Wz has K = 4H + A + C: eighteen 256-k chunks. Its partials stay in the slab area and the gate kernel of
+  // step t - 1 -- the next launch -- sums them (<= 16 rows: the hand-off inside the launch was 8 of the product's 12.6 us;
+  // up to 128 rows: a splitk_reduce launch less per step)
+  const size_t dh_ws_floats = d.B <= 128 ? (size_t)cdiv(ZW, 64) * d.B * H : 4;
+  float* dh_slabs_ws = scratch + take(dh_ws_floats);
   int dh_slabs = 0;
   for (int t = d.steps - 1; t >= 0; --t) {
     const int b = bs[t], r0 = off[t];
@@ -320,12 +330,14 @@ int att_seq_backward(const AttDims& d, const int* bs, const float* dH, const flo
     RC(lstm_pointwise_bwd(Zf, ZW, sv + L.Cst + (size_t)r0 * H, cprev, dH + (size_t)r0 * H, dh_slabs ? dh_slabs_ws : dh_rec, dc,
                           Z, ZW, b, b_next, H, go.gi, go.gf, go.go, go.gg, go.tanh_out, s, dh_slabs, (long)b_next * H));
     int dx_slabs = 0;     // d[x | ctx] as K-chunk partials: the context kernel -- the next launch -- sums them
-    if (one_product) {
-      RC(sgemm_rows16_slabs(false, b, XW, 4 * H, Z, ZW, sv + L.Weff, XW, skws, kAttSplitKWs, &dx_slabs, s));
+    const float* Wx = one_product ? sv + L.Weff : (fac ? nullptr : sv + L.Vcat);
+    if (Wx) {
+      // d[x | ctx] = d gates . Wx
+      RC(product_slabs(false, b, XW, 4 * H, Z, ZW, Wx, XW, skws, kAttSplitKWs, &dx_slabs, s));
       if (!dx_slabs)
-        RC(sgemm_splitk(false, false, b, XW, 4 * H, Z, ZW, sv + L.Weff, XW, dXA + (size_t)r0 * XW, XW,
+        RC(sgemm_splitk(false, false, b, XW, 4 * H, Z, ZW, Wx, XW, dXA + (size_t)r0 * XW, XW,
                         nullptr, 0, skws, kAttSplitKWs, s, skctr, kSplitKCounters));
-    } else if (fac) {
+    } else {
       RC(sgemm_splitk_batched(false, false, b, F, H, Z, ZW, sv + L.Ucat, F, dA2 + (size_t)r0 * 4 * F,
                               4 * F, nullptr, 0, 4, H, (long)H * F, F, 0, skws, kAttSplitKWs, s, skctr, kSplitKCounters));
       RC(sgemm_splitk_batched(false, false, b, F, F, dA2 + (size_t)r0 * 4 * F, 4 * F, sv + L.Scat, F,
@@ -333,10 +345,6 @@ int att_seq_backward(const AttDims& d, const int* bs, const float* dH, const flo
                               skws, kAttSplitKWs, s, skctr, kSplitKCounters));
       RC(sgemm_splitk(false, false, b, XW, 4 * F, dA1 + (size_t)r0 * 4 * F, 4 * F, sv + L.Vcat, XW,
                       dXA + (size_t)r0 * XW, XW, nullptr, 0, skws, kAttSplitKWs, s, skctr, kSplitKCounters));
-    } else {
-      // d[x | ctx] = d gates . weight_ih
-      RC(sgemm_splitk(false, false, b, XW, 4 * H, Z, ZW, sv + L.Vcat, XW, dXA + (size_t)r0 * XW, XW,
-                      nullptr, 0, skws, kAttSplitKWs, s, skctr, kSplitKCounters));
     }
     RC(att_step_bwd(sv + L.att1, feat, Zf + 4 * H, ZW, Zf + 4 * H + A, ZW, sv + L.awe + (size_t)r0 * C,
                     sv + L.alpha + (size_t)r0 * P, w.full_att_w, dXA + (size_t)r0 * XW + E, XW,
@@ -344,8 +352,7 @@ int att_seq_backward(const AttDims& d, const int* bs, const float* dH, const flo
                     de_all + (size_t)r0 * P, dwf_rows + (size_t)r0 * A, dbf_rows + r0, s, dx_slabs ? skws : nullptr, dx_slabs, E));
     // dh_{t-1} (or dh0) = dZ . Wz
     dh_slabs = 0;
-    if (d.B <= 16)
-      RC(sgemm_rows16_slabs(false, b, H, ZW, Z, ZW, sv + L.Wz, H, dh_slabs_ws, (size_t)cdiv(ZW, 256) * d.B * H, &dh_slabs, s));
+    if (d.B <= 128) RC(product_slabs(false, b, H, ZW, Z, ZW, sv + L.Wz, H, dh_slabs_ws, dh_ws_floats, &dh_slabs, s));
     if (!dh_slabs)
       RC(sgemm_splitk(false, false, b, H, ZW, Z, ZW, sv + L.Wz, H, dh_rec, H, nullptr, 0, skws, kAttSplitKWs, s, skctr, kSplitKCounters));
   }
