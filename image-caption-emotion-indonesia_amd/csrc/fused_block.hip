@@ -515,7 +515,10 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void fb_fused_kernel(const FArgs g
   // behind them ST x L, LD x L. The same stream for both groups, one iteration apart.
   //   before barrier k: D(k), issued in iteration k - 2; younger than it: one A and one B iteration      -> NDMA + 2 L
   //   the tail of B(c): LD(c), issued by B(c - 2), four iterations back; younger: D, D ST LD, D, D        -> 4 NDMA + 2 L
-  constexpr int GB = NW == 8 ? 2 : 4;
+#ifndef CAPNET_FB_GB8
+#define CAPNET_FB_GB8 2
+#endif
+  constexpr int GB = NW == 8 ? CAPNET_FB_GB8 : 4;      // fragment groups read ahead as one batch
   typedef const __attribute__((address_space(3))) unsigned char* lds_bytes;
   const lds_bytes ring3 = (lds_bytes)ring;
   f32x4 d[RS][2];

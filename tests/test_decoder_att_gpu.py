@@ -73,6 +73,9 @@ def test_attention_decoder_matches_reference_fixture(dev, chain, cname, seed, ra
 
 @pytest.mark.parametrize("B,V,A,E,F,H,P,mode,ratio", [
     (5, 203, 24, 20, 24, 28, 9, "angry", 0.7),
+    (1, 203, 24, 20, 24, 28, 9, "happy", 0.7),                # one caption
+    (20, 203, 72, 68, 64, 64, 9, "sad", 0.7),                 # 17 .. 128 rows: the 64-row K-split kernels' partials
+    (40, 1000, 512, 300, 512, 512, 196, "factual", 0.8),      # the full cell at 40 rows
     (12, 1000, 512, 300, 512, 512, 196, "factual", 0.8),     # BASELINE config 4 cell at 12/GPU
 ])
 def test_attention_decoder_matches_oracle_seeded(dev, chain, B, V, A, E, F, H, P, mode, ratio):
@@ -140,9 +143,10 @@ def test_nic_attention_decoder_matches_reference_fixture(dev, cname, seed, ratio
     assert n == 19
 
 
-def test_nic_attention_decoder_matches_oracle_full_size(dev):
+@pytest.mark.parametrize("B", [12, 33])          # <= 16 rows: the one-launch products; above: the 64-row K-split kernels
+def test_nic_attention_decoder_matches_oracle_full_size(dev, B):
     from capnet.nic_model_att import DecoderRNNAtt
-    B, V, A, E, H, P, Cf, ratio = 12, 1000, 512, 300, 512, 196, 2048, 0.8
+    V, A, E, H, P, Cf, ratio = 1000, 512, 300, 512, 196, 2048, 0.8
     dec = DecoderRNNAtt(A, E, H, V, 1, feature_size=Cf, dropout=0.0)
     p = synthetic.decoder_state(dec.state_dict(), seed=3, bias_range=0.05)
     dec.load_state_dict(p)
