@@ -407,6 +407,10 @@ struct FArgs {
   int* err;
 };
 
+#ifndef CAPNET_FB_DBG
+#define CAPNET_FB_DBG 0        // probes only: 1 = no MFMAs (fragments still read), 2 = no weight DMA (waits and barriers stay),
+                               // 3 = neither MFMAs nor fragment reads (DMA, barriers, tail), 4 = as 3 without the weight DMA
+#endif
 template <int N>
 __device__ __forceinline__ void fb_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -436,7 +440,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void fb_fused_kernel(const FArgs g
   auto dma = [&](const float* img, int cc, int slot) __attribute__((always_inline)) {
     const float* src = img + (long)cc * (SLOT / 4);
 #pragma unroll
-    for (int q = 0; q < NDMA; ++q)
+    for (int q = 0; q < ((CAPNET_FB_DBG == 2 || CAPNET_FB_DBG == 4) ? 0 : NDMA); ++q)
       glds16(src, (wave_u * NDMA + q) * 1024 + lane * 16, ring0 + (unsigned)(slot * SLOT + (wave_u * NDMA + q) * 1024));
   };
   // identity rows of chunk cc: lane (gq, ln) takes channels 32 cc + 16 blk + 4 gq .. + 3 of its row in each strip
@@ -518,7 +522,11 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void fb_fused_kernel(const FArgs g
 #ifndef CAPNET_FB_GB8
 #define CAPNET_FB_GB8 2
 #endif
-  constexpr int GB = NW == 8 ? CAPNET_FB_GB8 : 4;      // fragment groups read ahead as one batch
+  constexpr int GB = NW == 8 ? CAPNET_FB_GB8 : 4;      // fragment groups of a batch
+#ifndef CAPNET_FB_FD
+#define CAPNET_FB_FD 1
+#endif
+  constexpr int FD = CAPNET_FB_FD;                     // batches read ahead
   typedef const __attribute__((address_space(3))) unsigned char* lds_bytes;
   const lds_bytes ring3 = (lds_bytes)ring;
   f32x4 d[RS][2];
@@ -531,22 +539,25 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void fb_fused_kernel(const FArgs g
     asm volatile("" : "+v"(wa_off));
     const lds_bytes wa = ring3 + wa_off;
     constexpr int GA = KS * 2, NBAT = (GA + GB - 1) / GB;          // group = (ks, blk): fragments (group * 2 + plane) KB into the slot
-    h8 f[2][GB][2];
+    // fragments are read FD batches ahead of the MFMAs that use them (a batch is GB groups = 3 GB MFMAs: 96 cycles at GB = 2,
+    // an LDS read under eight waves' load comes back after 200-300)
+    h8 f[FD + 1][GB][2];
+    auto read_a = [&](int bb) __attribute__((always_inline)) {
 #pragma unroll
-    for (int q = 0; q < GB; ++q)
-      if (q < GA) { f[0][q][0] = *(const __attribute__((address_space(3))) h8*)(wa + (q * 2) * 1024); f[0][q][1] = *(const __attribute__((address_space(3))) h8*)(wa + (q * 2 + 1) * 1024); }
-#pragma unroll
-    for (int b = 0; b < NBAT; ++b) {
-      if (b + 1 < NBAT) {
-#pragma unroll
-        for (int q = 0; q < GB; ++q) {
-          const int grp = (b + 1) * GB + q;
-          if (grp < GA) {
-            f[(b + 1) & 1][q][0] = *(const __attribute__((address_space(3))) h8*)(wa + (grp * 2) * 1024);
-            f[(b + 1) & 1][q][1] = *(const __attribute__((address_space(3))) h8*)(wa + (grp * 2 + 1) * 1024);
-          }
+      for (int q = 0; q < GB; ++q) {
+        const int grp = bb * GB + q;
+        if (grp < GA && CAPNET_FB_DBG < 3) {
+          f[bb % (FD + 1)][q][0] = *(const __attribute__((address_space(3))) h8*)(wa + (grp * 2) * 1024);
+          f[bb % (FD + 1)][q][1] = *(const __attribute__((address_space(3))) h8*)(wa + (grp * 2 + 1) * 1024);
         }
       }
+    };
+#pragma unroll
+    for (int bb = 0; bb < FD; ++bb)
+      if (bb < NBAT) read_a(bb);
+#pragma unroll
+    for (int b = 0; b < NBAT; ++b) {
+      if (b + FD < NBAT) read_a(b + FD);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int q = 0; q < GB; ++q) {
@@ -554,9 +565,11 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void fb_fused_kernel(const FArgs g
         if (grp < GA) {
 #pragma unroll
           for (int s = 0; s < RS; ++s) {
-            d[s][blk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f[b & 1][q][1], ah[s][ks], d[s][blk], 0, 0, 0);
-            d[s][blk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f[b & 1][q][0], al[s][ks], d[s][blk], 0, 0, 0);
-            d[s][blk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f[b & 1][q][0], ah[s][ks], d[s][blk], 0, 0, 0);
+            if (CAPNET_FB_DBG >= 3) continue;
+            if (CAPNET_FB_DBG == 1) { asm volatile("" :: "v"(f[b % (FD + 1)][q][1]), "v"(f[b % (FD + 1)][q][0])); continue; }
+            d[s][blk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f[b % (FD + 1)][q][1], ah[s][ks], d[s][blk], 0, 0, 0);
+            d[s][blk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f[b % (FD + 1)][q][0], al[s][ks], d[s][blk], 0, 0, 0);
+            d[s][blk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f[b % (FD + 1)][q][0], ah[s][ks], d[s][blk], 0, 0, 0);
           }
         }
       }
@@ -569,10 +582,21 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void fb_fused_kernel(const FArgs g
     asm volatile("" : "+v"(wb_off));
     const lds_bytes wb = ring3 + wb_off;
     constexpr int NBATB = (NB + GB - 1) / GB;                       // group = nb
-    h8 fb[2][GB][2];
+    h8 fb[FD + 1][GB][2];
+    auto read_b = [&](int bb) __attribute__((always_inline)) {
+#pragma unroll
+      for (int q = 0; q < GB; ++q) {
+        const int nb = bb * GB + q;
+        if (nb < NB && CAPNET_FB_DBG < 3) {
+          fb[bb % (FD + 1)][q][0] = *(const __attribute__((address_space(3))) h8*)(wb + (nb * 2) * 1024);
+          fb[bb % (FD + 1)][q][1] = *(const __attribute__((address_space(3))) h8*)(wb + (nb * 2 + 1) * 1024);
+        }
+      }
+    };
     // the first fragments BEFORE the tail, whose VALU work then covers their round trip
 #pragma unroll
-    for (int q = 0; q < GB; ++q) { fb[0][q][0] = *(const __attribute__((address_space(3))) h8*)(wb + (q * 2) * 1024); fb[0][q][1] = *(const __attribute__((address_space(3))) h8*)(wb + (q * 2 + 1) * 1024); }
+    for (int bb = 0; bb < FD; ++bb)
+      if (bb < NBATB) read_b(bb);
     __builtin_amdgcn_sched_barrier(0);
     fb_wait_vmcnt<4 * NDMA + 2 * L>();
     if constexpr (RS == 2) CAPNET_LANDED4(id[0][0], id[0][1], id[1][0], id[1][1]);
@@ -605,16 +629,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void fb_fused_kernel(const FArgs g
     fetch_id(cc + 2 < NCH ? cc + 2 : NCH - 1, id);
 #pragma unroll
     for (int b = 0; b < NBATB; ++b) {
-      if (b + 1 < NBATB) {
-#pragma unroll
-        for (int q = 0; q < GB; ++q) {
-          const int nb = (b + 1) * GB + q;
-          if (nb < NB) {
-            fb[(b + 1) & 1][q][0] = *(const __attribute__((address_space(3))) h8*)(wb + (nb * 2) * 1024);
-            fb[(b + 1) & 1][q][1] = *(const __attribute__((address_space(3))) h8*)(wb + (nb * 2 + 1) * 1024);
-          }
-        }
-      }
+      if (b + FD < NBATB) read_b(b + FD);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int q = 0; q < GB; ++q) {
@@ -622,9 +637,11 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void fb_fused_kernel(const FArgs g
         if (nb < NB) {
 #pragma unroll
           for (int s = 0; s < RS; ++s) {
-            acc[s][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ol[s], fb[b & 1][q][0], acc[s][nb], 0, 0, 0);
-            acc[s][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(oh[s], fb[b & 1][q][1], acc[s][nb], 0, 0, 0);
-            acc[s][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(oh[s], fb[b & 1][q][0], acc[s][nb], 0, 0, 0);
+            if (CAPNET_FB_DBG >= 3) continue;
+            if (CAPNET_FB_DBG == 1) { asm volatile("" :: "v"(fb[b % (FD + 1)][q][1]), "v"(fb[b % (FD + 1)][q][0])); continue; }
+            acc[s][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ol[s], fb[b % (FD + 1)][q][0], acc[s][nb], 0, 0, 0);
+            acc[s][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(oh[s], fb[b % (FD + 1)][q][1], acc[s][nb], 0, 0, 0);
+            acc[s][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(oh[s], fb[b % (FD + 1)][q][0], acc[s][nb], 0, 0, 0);
           }
         }
       }
@@ -743,7 +760,7 @@ __global__ __launch_bounds__(256, 1) void fb_fused_wide_kernel(const FArgs g) {
   auto dma = [&](const float* img, int cc, int slot) __attribute__((always_inline)) {
     const float* src = img + (long)cc * (SLOT / 4);
 #pragma unroll
-    for (int q = 0; q < NDMA; ++q)
+    for (int q = 0; q < ((CAPNET_FB_DBG == 2 || CAPNET_FB_DBG == 4) ? 0 : NDMA); ++q)
       glds16(src, (wave_u * NDMA + q) * 1024 + lane * 16, ring0 + (unsigned)(slot * SLOT + (wave_u * NDMA + q) * 1024));
   };
   // identity rows of chunk cc: lane (li, lh) takes channels 32 cc + 8 q + 4 lh .. + 3 of its row, q = 0 .. 3
