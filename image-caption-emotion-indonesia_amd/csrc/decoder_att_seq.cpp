@@ -398,7 +398,7 @@ int att_seq_backward(const AttDims& d, const int* bs, const float* dH, const flo
   CAPNET_HIP_CHECK(hipMemsetAsync(g.dEmb, 0, (size_t)d.V * E * sizeof(float), s));
   RC(scatter_input_grad(dXA, XW, N, E, saved_i + L.row_sample, saved_i + L.row_col,
                         saved_i + L.row_token, g.dEmb, nullptr, d.V, dropout_p, seed,
-                        training && dropout_p > 0.f, s));
+                        training && dropout_p > 0.f, s, reinterpret_cast<int*>(skws), kAttSplitKWs));
   return kOk;
 }
 

@@ -420,9 +420,10 @@ static int seq_backward_layer(const SeqDims& d, const int* batch_sizes, const fl
   if (layer > 0) return rows_dropout(dX, dH_below, 0, N, E, dropout_p, seed, layer, training && dropout_p > 0.f, s);
   CAPNET_HIP_CHECK(hipMemsetAsync(g.dEmb, 0, (size_t)d.V * E * sizeof(float), s));
   if (g.dFeat) CAPNET_HIP_CHECK(hipMemsetAsync(g.dFeat, 0, (size_t)d.B * E * sizeof(float), s));
+  // (the split-K slab area is free by now: the scatter's two integer tables over the vocabulary go there)
   RC(scatter_input_grad(dX, E, N, E, saved_i + L.row_sample, saved_i + L.row_col,
                         saved_i + L.row_token, g.dEmb, g.dFeat, d.V, dropout_p, seed,
-                        training && dropout_p > 0.f, s));
+                        training && dropout_p > 0.f, s, reinterpret_cast<int*>(skws), kSplitKFloats));
   return kOk;
 }
 

@@ -219,7 +219,7 @@ int rows_dropout(const float* src, float* dst, int r0, int r1, int C, float p, u
                  int use_dropout, hipStream_t stream);
 int scatter_input_grad(const float* dX, long ldx, int N, int E, const int* row_sample, const int* row_col,
                        const int* row_token, float* dEmb, float* dFeat, int V, float p,
-                       unsigned long long seed, int use_dropout, hipStream_t stream);
+                       unsigned long long seed, int use_dropout, hipStream_t stream, int* tables, size_t table_ints);
 
 // lstm_step.hip
 bool lstm_step_fused_supported(int b, int H);

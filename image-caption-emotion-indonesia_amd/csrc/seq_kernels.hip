@@ -653,13 +653,27 @@ int colsum(const float* x, long ld, int rows, int C, float* out, int accumulate,
 // dX [N][E] -> dEmb[token] += the rows of that token, dFeat[sample] = the sample's feature row. Tokens repeat: the FIRST row
 // of a token sums every row of it in row order and adds the sum -- one writer per table row, a fixed order (an atomic add per
 // row was the one launch of the step whose result depended on arrival order: the checkpoint round trip's bitwise comparison
-// failed one run in three on the last bit of the third loss). Every workgroup scans the N tokens, 128 at a time, through wave
-// ballots; the others leave at the first earlier match.
+// failed one run in three on the last bit of the third loss).
+// Who is first and how many rows a token has comes from two integer tables over the vocabulary (scatter_count_kernel:
+// atomicMax / atomicAdd on ints -- order-free): most tokens occur once and their row is copied without looking at any
+// other; an owner of several rows scans the tokens from its own row on, 128 at a time through wave ballots, until it has met
+// them all. (Every workgroup scanning all N tokens for its turn, the first form: 255 us at 2 000 rows.)
 constexpr int kScatterE = 4;                 // columns per thread and sweep: E <= 512 in one
+__global__ __launch_bounds__(256) void scatter_count_kernel(const int* __restrict__ row_col, const int* __restrict__ row_token,
+                                                            int N, int V, int* __restrict__ first_enc, int* __restrict__ cnt) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= N || row_col[r] == -1) return;
+  const int tok = row_token[r];
+  if (tok < 0 || tok >= V) return;
+  atomicMax(first_enc + tok, N - r);         // (zero-initialised: the first row has the largest N - r)
+  atomicAdd(cnt + tok, 1);
+}
+
 __global__ __launch_bounds__(128) void scatter_input_grad_kernel(
     const float* __restrict__ dX, long ldx, int N, int E, const int* __restrict__ row_sample,
     const int* __restrict__ row_col, const int* __restrict__ row_token, float* __restrict__ dEmb,
-    float* __restrict__ dFeat, int V, float p, unsigned long long seed, int use_dropout) {
+    float* __restrict__ dFeat, int V, float p, unsigned long long seed, int use_dropout,
+    const int* __restrict__ first_enc, const int* __restrict__ cnt) {
   __shared__ unsigned long long s_mask[2][2];
   const int r = blockIdx.x, tid = threadIdx.x;
   const float inv_keep = p < 1.f ? 1.f / (1.f - p) : 0.f;
@@ -672,39 +686,59 @@ __global__ __launch_bounds__(128) void scatter_input_grad_kernel(
   }
   const int tok = row_token[r];
   if (tok < 0 || tok >= V) return;
+  if (first_enc[tok] != N - r) return;
+  const int want = cnt[tok];                 // rows of this token, this one included
   for (int e0 = 0; e0 < E; e0 += 128 * kScatterE) {
     float acc[kScatterE];
 #pragma unroll
     for (int u = 0; u < kScatterE; ++u) acc[u] = 0.f;
-    for (int base = 0, it = 0; base < N; base += 128, ++it) {
-      const int rr = base + tid;
-      const bool match = rr < N && row_col[rr] != -1 && row_token[rr] == tok;
-      const unsigned long long m = __ballot(match);
-      if ((tid & 63) == 0) s_mask[it & 1][tid >> 6] = m;
-      __syncthreads();                         // (two buffers: the next round's writes cannot pass this round's reads)
-      unsigned long long m0 = s_mask[it & 1][0], m1 = s_mask[it & 1][1];
-      if (base <= r && (m0 | m1)) {            // rows at or before r in this round: r is the owner iff it is the first match
-        const int first = base + (m0 ? __builtin_ctzll(m0) : 64 + __builtin_ctzll(m1));
-        if (first < r) return;                 // (uniform: every thread reads the same masks)
-      }
-      for (int half = 0; half < 2; ++half) {
-        unsigned long long mm = half ? m1 : m0;
-        while (mm) {
-          const int j = base + 64 * half + __builtin_ctzll(mm);
-          mm &= mm - 1;
-          const int sample = row_sample[j], col = row_col[j];
-          const bool drop = (col >= 0) && use_dropout;
+    // rows j[0 .. n) in order, their loads all in flight before the first add (a token of many rows -- <start>: one per
+    // caption -- was a chain of n dependent round trips: 97 us at 64 captions)
+    auto add_rows = [&](const int (&j)[8], int n) {
+      float g[8][kScatterE];
 #pragma unroll
-          for (int u = 0; u < kScatterE; ++u) {
-            const int e = e0 + u * 128 + tid;
-            if (e < E) {
-              float g = dX[(long)j * ldx + e];
-              if (drop) g *= dropout_scale(seed, sample, col, e, p, inv_keep);
-              acc[u] += g;
-            }
+      for (int k = 0; k < 8; ++k) {
+        const int jk = j[k < n ? k : 0];
+        const int sample = row_sample[jk], col = row_col[jk];
+        const bool drop = (col >= 0) && use_dropout;
+#pragma unroll
+        for (int u = 0; u < kScatterE; ++u) {
+          const int e = e0 + u * 128 + tid;
+          float v = (e < E) ? dX[(long)jk * ldx + e] : 0.f;
+          if (drop && e < E) v *= dropout_scale(seed, sample, col, e, p, inv_keep);
+          g[k][u] = v;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (k < n) {
+#pragma unroll
+          for (int u = 0; u < kScatterE; ++u) acc[u] += g[k][u];
+        }
+    };
+    int jb[8] = {r, r, r, r, r, r, r, r};
+    if (want == 1) {
+      add_rows(jb, 1);
+    } else {
+      int met = 0, nb = 0;
+      for (int base = r & ~127, it = 0; base < N && met < want; base += 128, ++it) {
+        const int rr = base + tid;
+        const bool match = rr < N && rr >= r && row_col[rr] != -1 && row_token[rr] == tok;
+        const unsigned long long m = __ballot(match);
+        if ((tid & 63) == 0) s_mask[it & 1][tid >> 6] = m;
+        __syncthreads();                       // (two buffers: the next round's writes cannot pass this round's reads)
+        const unsigned long long m0 = s_mask[it & 1][0], m1 = s_mask[it & 1][1];
+        for (int half = 0; half < 2; ++half) {
+          unsigned long long mm = half ? m1 : m0;
+          while (mm) {
+            jb[nb++] = base + 64 * half + __builtin_ctzll(mm);
+            mm &= mm - 1;
+            ++met;
+            if (nb == 8) { add_rows(jb, 8); nb = 0; }
           }
         }
       }
+      if (nb) add_rows(jb, nb);
     }
 #pragma unroll
     for (int u = 0; u < kScatterE; ++u) {
@@ -714,12 +748,18 @@ __global__ __launch_bounds__(128) void scatter_input_grad_kernel(
   }
 }
 
+// tables: workspace of at least 2 V ints
 int scatter_input_grad(const float* dX, long ldx, int N, int E, const int* row_sample, const int* row_col,
                        const int* row_token, float* dEmb, float* dFeat, int V, float p,
-                       unsigned long long seed, int use_dropout, hipStream_t stream) {
+                       unsigned long long seed, int use_dropout, hipStream_t stream, int* tables, size_t table_ints) {
   if (N <= 0) return kOk;
+  CAPNET_REQUIRE(tables && table_ints >= 2 * (size_t)V, "scatter_input_grad: workspace for two tables of V = %d ints", V);
+  int* first_enc = tables;
+  int* cnt = tables + V;
+  CAPNET_HIP_CHECK(hipMemsetAsync(tables, 0, 2 * (size_t)V * sizeof(int), stream));
+  hipLaunchKernelGGL(scatter_count_kernel, dim3(cdiv(N, 256)), dim3(256), 0, stream, row_col, row_token, N, V, first_enc, cnt);
   hipLaunchKernelGGL(scatter_input_grad_kernel, dim3(N), dim3(128), 0, stream, dX, ldx, N, E, row_sample,
-                     row_col, row_token, dEmb, dFeat, V, p, seed, use_dropout);
+                     row_col, row_token, dEmb, dFeat, V, p, seed, use_dropout, first_enc, cnt);
   CAPNET_LAUNCH_CHECK();
   return kOk;
 }
