@@ -98,8 +98,8 @@ __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" :
 // Split-f16 arithmetic on v_mfma_f32_16x16x32_f16 (the trunk's scheme, conv_f16x3.hip): x = hi + lo with
 // hi = f16(x), lo = f16(x - hi) (the subtraction is exact in fp32), and x w = lo hi' + hi lo' + hi hi' accumulated in
 // fp32; the dropped lo lo' term is 2^-22 of a product. W is split once per pack, scaled by 2^kWExp so that the
-// residuals of weights down to 2^-22 are normal f16 numbers (|w| < 2^(15 - kWExp) = 32 is the domain; beyond it the
-// f16 piece is inf and the loss is NaN, nothing is silent); h is split as it is (|h| < 65 504; its residual is a
+// residuals of weights down to 2^-22 are normal f16 numbers (|w| < 2^(16 - kWExp) = 64 is the domain; beyond it the
+// f16 piece is inf, the loss NaN, and the pack says so: error word bit 5, lstm_persist_pack_kernel); h is split as it is (|h| < 65 504; its residual is a
 // subnormal f16 below |h| = 0.12, i.e. an absolute error of 2^-25 per element, fp32's own rounding at |h| = 0.5 --
 // subnormal operands run at full rate, tools/probes/native/mfma_f16_denorm.hip).
 // 48 MFMAs of 16 cycles per wave and step where the f32 4x4x1 form issued 256 of 8..10 (round 2).
@@ -260,6 +260,7 @@ __global__ __launch_bounds__(256) void lstm_persist_kernel(const PersistArgs a) 
   if (s_abort) return;
   const bool local = s_local != 0;
   if (tid == 0 && slot == 0) ctl[kCtlAbort + 1 + shard] = local ? 1 : 2;   // diagnostics: mode taken
+  if (tid == 0 && blockIdx.x == 0 && reinterpret_cast<const unsigned*>(a.Wp)[4l * kPH * kPH] != 0u) atomicOr(a.err_flag, 32);
 
   // ---- epilogue role: thread e -> (row m of the shard, unit u of the slot)
   const int em = tid >> 4, eu = tid & 15;
@@ -455,10 +456,15 @@ __global__ __launch_bounds__(256) void lstm_persist_pack_kernel(const float* __r
     const long q = ((long)(slot * 4 + w) * 32 + (4 * nb + g) * 2) * 256 + lane * 4 + jp;
     Wp[q] = h;
     Wp[q + 256] = l;
+    // a weight whose scaled value leaves f16's range (|w| >= 2^(16 - kWExp) = 64; NaN included) becomes inf in the image: the
+    // word behind the image says so and the sequence kernel raises bit 5 of the error word (the caller's remedy: the launch-per-
+    // step path, CAPNET_NO_PERSISTENT_LSTM=1)
+    const float lim = 65504.f / (float)(1 << kWExp);
+    if (!(fabsf(src[0]) <= lim && fabsf(src[1]) <= lim)) Wp[4l * kPH * kPH] = 1u;
   }
 }
 
-size_t lstm_persist_w_floats() { return 4ul * kPH * kPH; }
+size_t lstm_persist_w_floats() { return 4ul * kPH * kPH + 4; }   // the image + its out-of-domain word
 size_t lstm_persist_ctl_ints() { return kCtlInts; }
 
 // Process-wide mode of the persistent path: bit 0 off (launch per step everywhere), bit 1 SAFE mode forced
@@ -500,6 +506,7 @@ bool lstm_persist_supported(int b, int H) {
 
 int lstm_persist_pack(const float* Wcat, float* Wp, int gi, int gf, int go, int gg, hipStream_t stream) {
   CAPNET_REQUIRE(Wcat && Wp && aligned16(Wp), "lstm_persist_pack: bad argument");
+  CAPNET_HIP_CHECK(hipMemsetAsync(Wp + 4l * kPH * kPH, 0, 4 * sizeof(float), stream));
   hipLaunchKernelGGL(lstm_persist_pack_kernel, dim3(1024), dim3(256), 0, stream, Wcat, reinterpret_cast<unsigned*>(Wp), gi, gf,
                      go, gg);
   CAPNET_LAUNCH_CHECK();

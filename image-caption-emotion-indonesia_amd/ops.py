@@ -52,6 +52,8 @@ _ERR_BITS = {1: "token id out of range", 2: "target out of range",
                 "-- or a genuine fp32 overflow)",
              4: "a bounded wait of the persistent LSTM kernel expired (its 256 workgroups were not co-resident in time); "
                 "the process now runs one launch per LSTM step, as CAPNET_NO_PERSISTENT_LSTM=1 does from the start",
+             32: "a recurrent LSTM weight beyond |w| < 64, the range the persistent LSTM kernel's f16 weight image covers (the "
+                 "step's results are not finite); CAPNET_NO_PERSISTENT_LSTM=1 runs one launch per step on f32 operands",
              16: "another rank of the data-parallel job raised its error word: this rank dropped the same steps so that "
                  "the replicas stay identical (capnet.parallel)"}
 

@@ -476,7 +476,9 @@ int capnet_lstm_step_fused_supported(int b, int H);
  *   batch_sizes  [t1] non-increasing rows per step (host array)
  *   ctl          capnet_lstm_persist_ctl_ints() ints, zeroed once before the first segment of a
  *                forward pass; segment = 1, 2, ... numbers the launches that share it
- *   err_flag     bit 2 (value 4) is set if a bounded wait expired (the results are then invalid; capnet_clamp_adam
+ *   err_flag     bit 5 (value 32) is set if the weight image holds a value beyond f16's range (a recurrent weight with
+ *                |w| >= 64: capnet_lstm_persist_pack marks the image, the results are not finite);
+ *                bit 2 (value 4) is set if a bounded wait expired (the results are then invalid; capnet_clamp_adam
  *                given the same word skips its update)
  *   stamps       NULL, or ([t1-t0][256][8] + [256][2]) uint64 s_memtime readings (diagnostic instantiation) */
 int capnet_lstm_persist_supported(int b, int H);

@@ -177,6 +177,42 @@ def test_dropped_steps_leave_parameters_moments_and_step_counts_consistent(dev):
     assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2])
 
 
+def test_recurrent_weight_beyond_the_persistent_kernels_range_is_diagnosed(dev):
+    """The persistent LSTM kernel's f16 weight image covers |w| < 64 (2^10 scale, lstm_persist.hip); a larger recurrent
+    weight used to end in an undiagnosed NaN loss. The pack marks the image, the kernel raises bit 5 of the error word, and
+    the launch-per-step path (f32 operands) takes the same weights."""
+    from capnet._lib import lib
+    E, H, V, B = 32, 512, 101, 6
+    _, captions, lengths = synthetic.make_batch(B, V, seed=1, images=False, min_len=4, max_len=9)
+    feats = torch.randn(B, E, generator=torch.Generator().manual_seed(2)).to(dev)
+
+    def run(dec):
+        random.seed(3)
+        out = dec(captions.to(dev), lengths, feats, teacher_forcing_ratio=1.0)
+        return out
+
+    dec = DecoderFactoredLSTM(E, H, 32, V, 1, dropout=0.0).to(dev).train()
+    if not lib().capnet_lstm_persist_supported(B, H):
+        pytest.skip("persistent LSTM path not available on this device")
+    with torch.no_grad():
+        dec.W_i.weight[3, 5] = 100.0
+    run(dec)
+    with pytest.raises(capnet.CapnetError, match="beyond .w. < 64"):
+        ops.check_device_errors()
+    old = lib().capnet_lstm_persist_set_mode(1)
+    try:
+        out = run(dec)
+        ops.check_device_errors()
+        assert torch.isfinite(out).all()
+    finally:
+        lib().capnet_lstm_persist_set_mode(old)
+    with torch.no_grad():
+        dec.W_i.weight[3, 5] = 40.0                  # inside the range (round 3's documented limit of 32 was conservative)
+    out2 = run(dec)
+    ops.check_device_errors()
+    assert torch.isfinite(out2).all()
+
+
 def test_error_word_rides_behind_the_flat_gradient(dev):
     slot = torch.full((1,), 7.0, device=dev)
     err = ops.err_flag(dev)
