@@ -10,8 +10,9 @@ dev = torch.device("cuda:0")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 enc = EncoderCNN(300).to(dev).train()
 imgs = synthetic.make_batch(B, 100, seed=0)[0].to(dev)
-for D in (1, 2, 3, 4, 3, 2):
+for D in tuple(int(x) for x in os.environ.get('DEPTHS', '1,2,3,4,3,2').split(',')):
     streams = [torch.cuda.Stream() for _ in range(D)]
+    extra = torch.cuda.Stream(priority=-1) if os.environ.get('SIDE') else None       # (the step's high-priority side stream, idle)
     def run(n):
         for i in range(n):
             k = i % D
