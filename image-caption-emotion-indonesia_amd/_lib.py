@@ -22,6 +22,8 @@ SIGNATURES = {
     "capnet_abi_version": (_i, []),
     "capnet_sgemm": (_i, [_i, _i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, _vp, _i, _i, _l, _l, _l,
                           _l, _i, _vp]),
+    "capnet_sgemm_b3": (_i, [_i, _i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, _vp, _i, _i, _l, _l, _l, _l, _vp, _sz, _vp]),
+    "capnet_sgemm_b3_eligible": (_i, [_i, _i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, _vp, _i, _l, _l, _l, _l]),
     "capnet_sgemm_splitk": (_i, [_i, _i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, _vp, _i, _vp, _sz, _vp]),
     "capnet_sgemm_splitk_fused": (_i, [_i, _i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, _vp, _i, _vp, _sz, _vp, _sz, _vp]),
     "capnet_colsum": (_i, [_vp, _l, _i, _i, _vp, _i, _vp]),

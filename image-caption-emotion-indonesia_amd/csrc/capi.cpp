@@ -28,6 +28,19 @@ int capnet_sgemm(int transA, int transB, int M, int N, int K, const float* A, lo
                strideA, strideB, strideC, strideBias, force_tile, S(stream));
 }
 
+int capnet_sgemm_b3(int transA, int transB, int M, int N, int K, const float* A, long lda, const float* B, long ldb,
+                    float* C, long ldc, const float* bias, int accumulate, int batch, long strideA, long strideB,
+                    long strideC, long strideBias, float* ws, size_t ws_floats, capnet_stream_t stream) {
+  return sgemm_b3(transA != 0, transB != 0, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, batch, strideA, strideB,
+                  strideC, strideBias, S(stream), ws, ws_floats);
+}
+int capnet_sgemm_b3_eligible(int transA, int transB, int M, int N, int K, const float* A, long lda, const float* B, long ldb,
+                             const float* C, long ldc, const float* bias, int batch, long strideA, long strideB,
+                             long strideC, long strideBias) {
+  return sgemm_b3_eligible(transA != 0, transB != 0, M, N, K, A, lda, B, ldb, C, ldc, bias, batch, strideA, strideB, strideC,
+                           strideBias) ? 1 : 0;
+}
+
 int capnet_sgemm_nt_dma_eligible(int M, int N, int K, const float* A, long lda, const float* B,
                                  long ldb, const float* C, long ldc) {
   return sgemm_nt_dma_eligible(M, N, K, A, lda, B, ldb, C, ldc) ? 1 : 0;

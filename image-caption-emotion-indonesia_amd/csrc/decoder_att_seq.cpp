@@ -225,8 +225,9 @@ int att_seq_forward(const AttDims& d, const int* bs, const unsigned char* tf,
                   skctr, kSplitKCounters));
   RC(sgemm_splitk(false, true, d.B, H, C, sv + L.mean, C, w.init_c_w, C, sv + L.c0, H, w.init_c_b, 0, skws, kAttSplitKWs, s,
                   skctr, kSplitKCounters));
-  RC(sgemm(false, true, d.B * P, A, C, feat, C, w.enc_att_w, C, sv + L.att1, A, w.enc_att_b, 0, 1,
-           0, 0, 0, 0, 0, s));
+  // (through the K-split entry: with few images its 128 x 128 tiles are few and the product is cut over the chip)
+  RC(sgemm_splitk(false, true, d.B * P, A, C, feat, C, w.enc_att_w, C, sv + L.att1, A, w.enc_att_b, 0, skws, kAttSplitKWs, s,
+                  skctr, kSplitKCounters));
   CAPNET_HIP_CHECK(hipMemsetAsync(sv + L.XA, 0, (size_t)N * XW * sizeof(float), s));
   CAPNET_HIP_CHECK(hipMemsetAsync(alphas_bt, 0, (size_t)d.B * d.steps * P * sizeof(float), s));
   RC(gather_inputs(captions, d.T, nullptr, emb, E, d.V, saved_i + L.row_sample, saved_i + L.row_col,
@@ -359,7 +360,7 @@ int att_seq_backward(const AttDims& d, const int* bs, const float* dH, const flo
   if (dh_slabs) RC(reduce_slabs(dh_slabs_ws, dh_slabs, d.B, H, dh_rec, H, nullptr, 0, s));      // dh0: all B rows are alive at t = 0
   // ---- weight gradients over all rows at once
   RC(gather_prev_rows(hiddens, saved_i + L.prev_row, sv + L.h0, saved_i + L.row_sample, Hprev, N, H, s));
-  RC(sgemm(true, false, ZW, H, N, Zb, ZW, Hprev, H, g.dWz, H, nullptr, 0, 1, 0, 0, 0, 0, 0, s));
+  RC(sgemm_splitk(true, false, ZW, H, N, Zb, ZW, Hprev, H, g.dWz, H, nullptr, 0, skws, kAttSplitKWs, s));
   RC(colsum(Zb, ZW, N, ZW, g.dbz, 0, s));
   if (one_product) {
     // all rows at once: A1 = XA V^T + bV, A2_g = A1_g S_g^T + bS_g;  dA2_g = dgates_g U_g, dA1_g = dA2_g S_g
@@ -388,7 +389,7 @@ int att_seq_backward(const AttDims& d, const int* bs, const float* dH, const flo
   // encoder_att: d att1 summed per sample over its steps in one pass over att1
   RC(att_datt1(sv + L.att1, sv + L.Zf + 4 * H, ZW, de_all, w.full_att_w, off.data(), d.steps, d.B, P, A,
                datt1, s));
-  RC(sgemm(true, false, A, C, d.B * P, datt1, A, feat, C, g.dWe, C, nullptr, 0, 1, 0, 0, 0, 0, 0, s));
+  RC(sgemm_splitk(true, false, A, C, d.B * P, datt1, A, feat, C, g.dWe, C, nullptr, 0, skws, kAttSplitKWs, s));
   RC(colsum(datt1, A, d.B * P, A, g.dbe, 0, s, skws, kAttSplitKWs));
   // init_h / init_c: dh0 = dh_rec, dc0 = dc (all B rows are alive at t = 0)
   RC(sgemm(true, false, H, C, d.B, dh_rec, H, sv + L.mean, C, g.dWih, C, nullptr, 0, 1, 0, 0, 0, 0, 0, s));

@@ -391,7 +391,7 @@ static int seq_backward_layer(const SeqDims& d, const int* batch_sizes, const fl
   }
   // recurrent weight gradient over all steps at once: dWcat = dPre^T . h_{t-1}
   RC(gather_rows(hiddens, saved_i + L.prev_row, Hprev, N, H, s));
-  RC(sgemm(true, false, 4 * H, H, N, dPre, 4 * H, Hprev, H, g.dWcat, H, nullptr, 0, 1, 0, 0, 0, 0, 0, s));
+  RC(sgemm_splitk(true, false, 4 * H, H, N, dPre, 4 * H, Hprev, H, g.dWcat, H, nullptr, 0, skws, kSplitKFloats, s));
   RC(colsum(dPre, 4 * H, N, 4 * H, g.dbUW, 0, s));
 
   if (d.cell == kCellFactored) {

@@ -5,6 +5,8 @@
 //   transB = 0: B stored [K][N]      transB = 1: B stored [N][K]   (nn.Linear weight)
 // Replaces the torch.nn.Linear / autograd matmuls of the reference decoders
 // (stylenet/model.py:119-150,189-194; nic/model.py:77,105-113).
+#include <cstdlib>
+
 #include "common.h"
 #include "mfma_core.h"
 #include "kernels.h"
@@ -126,6 +128,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   }
 }
 
+static bool b3_enabled() {
+  static const bool on = [] { const char* e = getenv("CAPNET_NO_B3"); return !(e && e[0] == '1'); }();
+  return on;
+}
+
 // Tile choice: the chip has 256 CUs and this kernel keeps ~3-4 workgroups per CU resident;
 // prefer the 128x128 tile (best operand reuse) once it alone fills the chip, else 64x64.
 int sgemm(bool ta, bool tb, int M, int N, int K, const float* A, long lda, const float* B,
@@ -138,6 +145,13 @@ int sgemm(bool ta, bool tb, int M, int N, int K, const float* A, long lda, const
                  "sgemm: leading dimension too small (lda=%ld ldb=%ld ldc=%ld M=%d N=%d K=%d)",
                  lda, ldb, ldc, M, N, K);
   CAPNET_REQUIRE(batch <= 65535, "sgemm: batch too large");
+  // Large products: the bf16 matrix cores on three exact pieces per operand (gemm_b3.hip: 1.1-1.9 x this file's and
+  // gemm_dma.hip's f32-MFMA kernels on the decoders' shapes, errors against fp64 the same or smaller); CAPNET_NO_B3=1 keeps
+  // everything here.
+  // (without a workspace for split-K partials it needs a grid of its own: >= 128 tiles of 128 x 128)
+  if (force_tile == 0 && b3_enabled() && (long)cdiv(M, 128) * cdiv(N, 128) * batch >= 128 && (double)M * N * K * batch >= 2.5e8 &&
+      sgemm_b3_eligible(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, batch, sA, sB, sC, sBias))
+    return sgemm_b3(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, batch, sA, sB, sC, sBias, stream);
   // y = x . W^T + b with dense K-contiguous operands and enough rows for 128-row tiles: the LDS-DMA
   // core (gemm_dma.hip) -- the vocabulary projection, encoder_att over all pixels, ...
   if (!ta && tb && batch == 1 && !accumulate && force_tile == 0 && M > 64 &&
@@ -596,6 +610,12 @@ int sgemm_splitk_batched(bool ta, bool tb, int M, int N, int K, const float* A, 
     // many rows but few output tiles and a long K (dH = dlogits . C: 1037 x 512 x 8192): the
     // k-loop kernel with K cut into slabs, enough of them to put ~4 workgroups on every CU
     const long tiles64 = (long)cdiv(M, 64) * cdiv(N, 64);
+    // (gemm_b3.hip cuts K itself when its 128 x 128 tiles are few)
+    if (ws && batch == 1 && M > 128 && K >= 512 && b3_enabled() && (double)M * N * K >= 2.5e8 &&
+        sgemm_b3_eligible(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, 1, 0, 0, 0, 0)) {
+      CAPNET_REQUIRE(A && B && C, "sgemm_splitk: null operand");
+      return sgemm_b3(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, 1, 0, 0, 0, 0, stream, ws, ws_floats);
+    }
     if (ws && batch == 1 && M > 128 && tiles64 < 256 && K >= 1024) {
       CAPNET_REQUIRE(A && B && C, "sgemm_splitk: null operand");
       int splitk = (int)(1024 / tiles64);

@@ -10,6 +10,14 @@ int sgemm(bool ta, bool tb, int M, int N, int K, const float* A, long lda, const
           long ldb, float* C, long ldc, const float* bias, int accumulate, int batch, long sA,
           long sB, long sC, long sBias, int force_tile, hipStream_t stream);
 
+// gemm_b3.hip: the same product on the bf16 matrix cores, three bf16 pieces per fp32 operand and six products per multiply
+// (fp32-grade, fp32's range); sgemm takes it by itself for large products
+bool sgemm_b3_eligible(bool ta, bool tb, int M, int N, int K, const float* A, long lda, const float* B, long ldb,
+                       const float* C, long ldc, const float* bias, int batch, long sA, long sB, long sC, long sBias);
+int sgemm_b3(bool ta, bool tb, int M, int N, int K, const float* A, long lda, const float* B, long ldb, float* C, long ldc,
+             const float* bias, int accumulate, int batch, long sA, long sB, long sC, long sBias, hipStream_t stream,
+             float* ws = nullptr, size_t ws_floats = 0);
+
 // counters (optional): n_counters ints, zero before the first use and left zero by every call -- one per 64-column
 // output tile and batch member; with them, products of M <= 16 rows are ONE launch (gemm_rows16_kernel: the
 // workgroup that arrives last at a tile sums the K-chunk partials)

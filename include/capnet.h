@@ -45,6 +45,18 @@ int capnet_sgemm(int transA, int transB, int M, int N, int K, const float* A, lo
                  const float* B, long ldb, float* C, long ldc, const float* bias, int accumulate,
                  int batch, long strideA, long strideB, long strideC, long strideBias,
                  int force_tile, capnet_stream_t stream);
+/* The same product on the bf16 matrix cores: each fp32 operand cut into three bf16 pieces (exactly), six piece products
+ * per multiply accumulated in fp32 -- fp32-grade results over fp32's whole exponent range, no prescale (csrc/gemm_b3.hip).
+ * capnet_sgemm takes this path by itself for large products (CAPNET_NO_B3=1 in the environment keeps everything on the f32
+ * MFMA). Eligible: 16-B aligned operands, leading dimensions and batch strides multiples of 4, K % 4 == 0 when an operand
+ * is K-contiguous, M % 4 == 0 / N % 4 == 0 when A / B is stored with that dimension contiguous. ws (optional, batch 1):
+ * ws_floats floats for split-K partials -- products of few 128 x 128 tiles and a long K are cut over the chip. */
+int capnet_sgemm_b3(int transA, int transB, int M, int N, int K, const float* A, long lda, const float* B, long ldb,
+                    float* C, long ldc, const float* bias, int accumulate, int batch, long strideA, long strideB,
+                    long strideC, long strideBias, float* ws, size_t ws_floats, capnet_stream_t stream);
+int capnet_sgemm_b3_eligible(int transA, int transB, int M, int N, int K, const float* A, long lda, const float* B, long ldb,
+                             const float* C, long ldc, const float* bias, int batch, long strideA, long strideB,
+                             long strideC, long strideBias);
 
 /* The same product for the per-time-step shapes of the decoders (M <= 128 rows, A not transposed):
  * K is cut into chunks, one workgroup per (64x64 tile, chunk) loads its chunk in one round trip and

@@ -392,12 +392,63 @@ def test_sgemm_nt_dma_matches_fp64(dev, M, N, K, bias):
     assert lib().capnet_sgemm_nt_dma_eligible(M, N, K, ptr(Ad), K, ptr(Bd), K, ptr(out), N) == 1
     check(lib().capnet_sgemm_nt_dma(M, N, K, ptr(Ad), K, ptr(Bd), ptr(out), ptr(bd), current_stream()))
     assert rel_err(out, ref) < 3e-6
-    # capnet_sgemm (ops.linear) takes this path by itself once there are enough 128-row tiles
+    # capnet_sgemm (ops.linear) takes this path by itself once there are enough 128-row tiles (and gemm_b3.hip beyond 2.5e8
+    # multiply-adds)
     out2 = ops.linear(Ad, Bd, bd)
-    if M > 64 and ((M + 127) // 128) * (N // 64) >= 64:
+    if M > 64 and ((M + 127) // 128) * (N // 64) >= 64 and M * N * K < 2.5e8:
         assert torch.equal(out2, out)
     else:
         assert rel_err(out2, ref) < 3e-6
+
+
+@pytest.mark.parametrize("ta,tb", [(0, 1), (0, 0), (1, 0), (1, 1)])
+@pytest.mark.parametrize("M,N,K,batch,split", [
+    (1344, 8192, 512, 1, False),       # the vocabulary projection's family at configs[1]'s row count
+    (1036, 512, 8192, 1, True),        # few tiles, long K: cut over the chip, partials summed by reduce_slabs
+    (260, 132, 300, 1, False),         # ragged tiles, K = 9 whole steps + 12 (the embedding width)
+    (128, 128, 32, 1, False),          # one tile, one step
+    (4, 4, 4, 1, False),               # the smallest eligible product
+    (516, 2348, 2048, 1, True),        # the attention cell's input width as N
+    (200, 256, 96, 4, False),          # batched (the four gates)
+])
+def test_sgemm_b3_matches_fp64(dev, ta, tb, M, N, K, batch, split):
+    """csrc/gemm_b3.hip: three bf16 pieces per operand, six products -- fp32-grade against float64 on every layout, with
+    bias and accumulation, over leading dimensions wider than the matrices, and with operands of 1e-9 and 1e+5 (bf16 pieces
+    have fp32's range: no prescale)."""
+    g = torch.Generator().manual_seed(M + N + K + 7 * ta + 3 * tb)
+    pad = 4
+    Ash, Bsh = ((K, M) if ta else (M, K)), ((N, K) if tb else (K, N))
+    A = torch.randn(batch, Ash[0], Ash[1] + pad, generator=g)
+    B = torch.randn(batch, Bsh[0], Bsh[1] + pad, generator=g)
+    A[..., :, : Ash[1] // 2] *= 1e-9                      # (half of each operand's columns tiny, a few entries huge)
+    B.view(-1)[::97] *= 3e4
+    bias = torch.randn(batch, N, generator=g)
+    C0 = torch.randn(batch, M, N + pad, generator=g)
+    Av, Bv = A[..., : Ash[1]].double(), B[..., : Bsh[1]].double()
+    ref = (Av.transpose(1, 2) if ta else Av) @ (Bv.transpose(1, 2) if tb else Bv) + bias.double()[:, None, :] + C0[..., :N].double()
+    Ad, Bd, bd, Cd = A.to(dev), B.to(dev), bias.to(dev), C0.to(dev)
+    ws = torch.empty(8 << 20, device=dev) if split else None
+    L = lib()
+    assert L.capnet_sgemm_b3_eligible(ta, tb, M, N, K, ptr(Ad), Ash[1] + pad, ptr(Bd), Bsh[1] + pad, ptr(Cd), N + pad, ptr(bd),
+                                      batch, Ad.stride(0), Bd.stride(0), Cd.stride(0), N) == 1
+    check(L.capnet_sgemm_b3(ta, tb, M, N, K, ptr(Ad), Ash[1] + pad, ptr(Bd), Bsh[1] + pad, ptr(Cd), N + pad, ptr(bd), 1, batch,
+                            Ad.stride(0), Bd.stride(0), Cd.stride(0), N, ptr(ws), ws.numel() if split else 0, current_stream()))
+    torch.cuda.synchronize()
+    got = Cd[..., :N].double().cpu()
+    assert torch.equal(Cd[..., N:].cpu(), C0[..., N:])                     # nothing written past a row
+    # error against the sum of absolute products (what fp32 accumulation is held to), per element
+    mag = ((Av.abs().transpose(1, 2) if ta else Av.abs()) @ (Bv.abs().transpose(1, 2) if tb else Bv.abs()) +
+           bias.double().abs()[:, None, :] + C0[..., :N].double().abs())
+    assert float(((got - ref).abs() / mag).max()) < 2e-6
+
+
+def test_sgemm_b3_rejects_ineligible(dev):
+    L = lib()
+    A, B, Cc = torch.zeros(8, 42, device=dev), torch.zeros(16, 42, device=dev), torch.zeros(8, 16, device=dev)
+    # K = 42 is no multiple of 4 and both operands are K-contiguous
+    assert L.capnet_sgemm_b3_eligible(0, 1, 8, 16, 42, ptr(A), 42, ptr(B), 42, ptr(Cc), 16, None, 1, 0, 0, 0, 0) == 0
+    assert L.capnet_sgemm_b3(0, 1, 8, 16, 42, ptr(A), 42, ptr(B), 42, ptr(Cc), 16, None, 0, 1, 0, 0, 0, 0, None, 0,
+                             current_stream()) != 0
 
 
 def test_sgemm_nt_dma_rejects_ineligible(dev):
