@@ -445,7 +445,9 @@ class LinearFn(torch.autograd.Function):
         x, w = _c(x), _c(w)
         ctx.save_for_backward(x, w)
         ctx.has_bias = b is not None
-        return sgemm(x, w, transB=True, bias=b)
+        # (through the K-split entry: the encoder head's 64 x 300 x 2048 is five 64 x 64 tiles walking the whole K on the
+        #  plain one -- 94 us; large products go to the same kernels either way)
+        return sgemm_splitk(x, w, transB=True, bias=b)
 
     @staticmethod
     @once_differentiable
