@@ -682,7 +682,7 @@ def main():
                 "peak": round(MFMA_BF16_PEAK_TFLOPS / 6.0, 1) if b3 else MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(fl / us_v / 1e6 / (MFMA_BF16_PEAK_TFLOPS / 6.0 if b3 else MFMA_F32_PEAK_TFLOPS), 4),
                 "vs_f32_matrix_peak": round(fl / us_v / 1e6 / MFMA_F32_PEAK_TFLOPS, 4), "us": round(us_v, 1)})(
-                    os.environ.get("CAPNET_NO_B3") != "1" and float(Nt) * V * Hh >= 2.5e8 and ((Nt + 127) // 128) * (V // 128) >= 128),
+                    os.environ.get("CAPNET_NO_B3") != "1" and float(Nt) * V * Hh >= 2.5e8 and ((Nt + 127) // 128) * (V // 128) >= 192),
             "attention_step": {"bound": "hbm", "kernel": "att_scores_fwd + att_context_fwd (b=64, P=196, A=512, "
                                "C=2048; att1 + feature map read once per row)", "achieved": round(by / us_a / 1e3, 1),
                                "peak": 8000.0, "unit": "GB/s", "frac": round(by / us_a / 1e3 / 8000.0, 4),

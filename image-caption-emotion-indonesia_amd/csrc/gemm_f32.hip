@@ -148,8 +148,9 @@ int sgemm(bool ta, bool tb, int M, int N, int K, const float* A, long lda, const
   // Large products: the bf16 matrix cores on three exact pieces per operand (gemm_b3.hip: 1.1-1.9 x this file's and
   // gemm_dma.hip's f32-MFMA kernels on the decoders' shapes, errors against fp64 the same or smaller); CAPNET_NO_B3=1 keeps
   // everything here.
-  // (without a workspace for split-K partials it needs a grid of its own: >= 128 tiles of 128 x 128)
-  if (force_tile == 0 && b3_enabled() && (long)cdiv(M, 128) * cdiv(N, 128) * batch >= 128 && (double)M * N * K * batch >= 2.5e8 &&
+  // (without a workspace for split-K partials it needs a grid of its own: a workgroup alone on its CU takes 1.8 us per
+  //  32-k step, and below ~190 tiles of 128 x 128 the f32 kernels' 64 x 64 tiles win -- tools/probes/b3_small.py)
+  if (force_tile == 0 && b3_enabled() && (long)cdiv(M, 128) * cdiv(N, 128) * batch >= 192 && (double)M * N * K * batch >= 2.5e8 &&
       sgemm_b3_eligible(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, batch, sA, sB, sC, sBias))
     return sgemm_b3(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, batch, sA, sB, sC, sBias, stream);
   // y = x . W^T + b with dense K-contiguous operands and enough rows for 128-row tiles: the LDS-DMA

@@ -395,7 +395,7 @@ def test_sgemm_nt_dma_matches_fp64(dev, M, N, K, bias):
     # capnet_sgemm (ops.linear) takes this path by itself once there are enough 128-row tiles (and gemm_b3.hip beyond 2.5e8
     # multiply-adds)
     out2 = ops.linear(Ad, Bd, bd)
-    if M > 64 and ((M + 127) // 128) * (N // 64) >= 64 and M * N * K < 2.5e8:
+    if M > 64 and ((M + 127) // 128) * (N // 64) >= 64 and (M * N * K < 2.5e8 or ((M + 127) // 128) * ((N + 127) // 128) < 192):
         assert torch.equal(out2, out)
     else:
         assert rel_err(out2, ref) < 3e-6
